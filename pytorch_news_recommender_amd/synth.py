@@ -1,0 +1,177 @@
+"""Deterministic synthetic NRMS parameters and MIND-shaped batches.
+
+There is no MIND / GloVe data offline, so tests, the golden-vector generator and
+bench.py all draw their inputs from here.  Everything is produced by numpy's
+``default_rng`` (PCG64, platform-stable), so a fixture only has to store the
+*outputs* for a given (shape, seed); inputs and weights are regenerated.
+
+Parameter names and shapes follow the reference model so state dicts interchange
+(/root/reference/MIND_2020/model/nrms_v0.py:35-37,91-93,134-139,149-152,183-186).
+Batch keys / dtypes / padding follow ``MyDataset.__getitem__``
+(/root/reference/MIND_2020/data_handler.py:185-250): right-zero-padded titles,
+left-aligned history, uint8 masks, int64 ids.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+ENCODERS = ("news_encoder", "user_encoder")
+
+
+@dataclass(frozen=True)
+class Shape:
+    """Problem shape. Names follow the reference's config fields (config.py:30-35,46,52,71,88)."""
+    n_words: int = 45800          # V
+    word_embed_size: int = 300    # d
+    num_attention_heads: int = 10 # h
+    query_vector_dim: int = 200   # q
+    batch_size: int = 512         # B
+    history_len: int = 50         # H
+    n_candidates: int = 5         # C  (= sample_size + 1 in training)
+    n_words_title: int = 30       # L
+
+    def as_dict(self):
+        return asdict(self)
+
+
+# The fixture shapes of SURVEY.md section 8c.
+G1_ODD = Shape(n_words=97, word_embed_size=60, num_attention_heads=10, query_vector_dim=32,
+               batch_size=3, history_len=7, n_candidates=3, n_words_title=9)
+G2_MIND = Shape(n_words=2000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                batch_size=4, history_len=50, n_candidates=5, n_words_title=30)
+BENCH = Shape()
+
+
+def param_names(with_output_proj: bool = False):
+    """The 19 nrms_v0 parameter names, in the flat-buffer order used by the HIP path."""
+    names = ["news_encoder.word_embedding.0.weight"]
+    for enc in ENCODERS:
+        a = enc + ".multihead_self_attention."
+        names += [a + "W_Q.weight", a + "W_K.weight", a + "W_V.weight",
+                  a + "W_Q.bias", a + "W_K.bias", a + "W_V.bias"]
+        if with_output_proj:
+            names += [a + "W_O.weight", a + "W_O.bias"]
+        b = enc + ".additive_attention."
+        names += [b + "linear.weight", b + "linear.bias", b + "attention_query_vector"]
+    return names
+
+
+def param_shapes(shape: Shape, with_output_proj: bool = False):
+    V, d, q = shape.n_words, shape.word_embed_size, shape.query_vector_dim
+    out = {"news_encoder.word_embedding.0.weight": (V, d)}
+    for enc in ENCODERS:
+        a = enc + ".multihead_self_attention."
+        for w in ("W_Q", "W_K", "W_V"):
+            out[a + w + ".weight"] = (d, d)
+            out[a + w + ".bias"] = (d,)
+        if with_output_proj:
+            out[a + "W_O.weight"] = (d, d)
+            out[a + "W_O.bias"] = (d,)
+        b = enc + ".additive_attention."
+        out[b + "linear.weight"] = (q, d)
+        out[b + "linear.bias"] = (q,)
+        out[b + "attention_query_vector"] = (q,)
+    return {n: out[n] for n in param_names(with_output_proj)}
+
+
+def make_params(shape: Shape, seed: int = 0, pad_row_zero: bool = True,
+                with_output_proj: bool = False, weight_gain: float = 1.0):
+    """float32 parameters with the reference's init distributions.
+
+    Table ~ N(0, 0.4^2) (GloVe-like scale); Linear weights xavier-uniform
+    (nrms_v0.py:41-44); biases U(+-1/sqrt(fan_in)) (torch Linear default);
+    query vector U(-0.1, 0.1) (nrms_v0.py:92-93).
+    ``pad_row_zero=False`` leaves a non-zero row 0 to exercise the
+    "row 0 is used as stored but never receives gradient" semantics of
+    ``padding_idx=0`` with ``from_pretrained`` (nrms_v0.py:134-136).
+    """
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in param_shapes(shape, with_output_proj).items():
+        if name.endswith("word_embedding.0.weight"):
+            t = rng.normal(0.0, 0.4, size=shp)
+            if pad_row_zero:
+                t[0] = 0.0
+        elif name.endswith("attention_query_vector"):
+            t = rng.uniform(-0.1, 0.1, size=shp)
+        elif name.endswith(".weight"):
+            fan_out, fan_in = shp
+            bound = weight_gain * np.sqrt(6.0 / (fan_in + fan_out))
+            t = rng.uniform(-bound, bound, size=shp)
+        else:  # Linear bias
+            fan_in = shape.word_embed_size
+            bound = 1.0 / np.sqrt(fan_in)
+            t = rng.uniform(-bound, bound, size=shp)
+        out[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return out
+
+
+def make_batch(shape: Shape, seed: int = 1, ragged: bool = True, min_title: int = 5,
+               empty_history_user: bool = False, all_pad_title: bool = False,
+               mask_some_candidates: bool = False, batch_size: int | None = None):
+    """A MIND-shaped batch dict of numpy arrays (keys and dtypes of data_handler.py:236-250).
+
+    ragged: per-title length in [min_title, L] with the tail zeroed, per-user
+    history length in [1, H] with trailing slots all zero (left-aligned history,
+    data_handler.py:206-215).  Only the three keys the NRMS path reads
+    (nrms_v0.py:248,250,272) plus ``browsed_mask``/``browsed_lens`` are produced.
+    """
+    B = shape.batch_size if batch_size is None else batch_size
+    H, C, L, V = shape.history_len, shape.n_candidates, shape.n_words_title, shape.n_words
+    rng = np.random.default_rng(seed)
+    bt = rng.integers(1, V, size=(B, H, L), dtype=np.int64)
+    ct = rng.integers(1, V, size=(B, C, L), dtype=np.int64)
+    hist_len = np.full((B,), H, dtype=np.int64)
+    if ragged:
+        lo = min(min_title, L)
+        tl_b = rng.integers(lo, L + 1, size=(B, H))
+        tl_c = rng.integers(lo, L + 1, size=(B, C))
+        pos = np.arange(L)
+        bt = np.where(pos[None, None, :] < tl_b[..., None], bt, 0)
+        ct = np.where(pos[None, None, :] < tl_c[..., None], ct, 0)
+        hist_len = rng.integers(max(1, min(5, H)), H + 1, size=(B,))
+    if empty_history_user and B > 1:
+        hist_len[1] = 0
+    slot = np.arange(H)
+    bmask = (slot[None, :] < hist_len[:, None])
+    bt = np.where(bmask[..., None], bt, 0)
+    if all_pad_title:
+        bt[0, 0, :] = 0          # a real (unmasked) history slot whose title is all padding
+        ct[-1, -1, :] = 0
+    cmask = np.ones((B, C), dtype=np.uint8)
+    if mask_some_candidates:
+        cmask[0, C - 1] = 0
+        if B > 2:
+            cmask[2, 1:] = 0     # a user with only the positive left
+    return {
+        "browsed_lens": hist_len.astype(np.int64),
+        "browsed_titles": np.ascontiguousarray(bt, dtype=np.int64),
+        "browsed_mask": bmask.astype(np.uint8),
+        "candidate_titles": np.ascontiguousarray(ct, dtype=np.int64),
+        "candidate_mask": cmask,
+    }
+
+
+def make_eval_impressions(n_imp: int, max_cand: int, seed: int = 7, min_cand: int = 2):
+    """Padded impressions for the AUC path (train_eval.py:219-273): scores [n_imp, max_cand]
+    with padded slots at -1e9 (nrms_v0.py:274) and ragged 0/1 label lists, each with at
+    least one positive and one negative so roc_auc_score is defined."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(min_cand, max_cand + 1, size=(n_imp,))
+    scores = np.full((n_imp, max_cand), -1e9, dtype=np.float32)
+    labels = []
+    for i, n in enumerate(lens):
+        s = rng.normal(0, 0.06, size=(n,)).astype(np.float32)
+        if n >= 6:                       # inject ties: the rank statistic must average them
+            s[3] = s[1]
+            s[5] = s[1]
+        y = (rng.random(n) < 0.2).astype(np.int64)
+        y[rng.integers(0, n)] = 1
+        zeros = np.flatnonzero(y == 0)
+        if zeros.size == 0:
+            y[(int(np.argmax(y)) + 1) % n] = 0
+        scores[i, :n] = s
+        labels.append(y)
+    return scores, labels
