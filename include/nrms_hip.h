@@ -1,0 +1,146 @@
+/*
+ * nrms_hip.h -- C ABI of libnrms_hip.so: the MI355X (gfx950) NRMS train/eval hot path.
+ *
+ * This is the drop-in boundary beneath the reference's Python plugin API
+ * (model/__init__.py:22-23 `import_module('model.'+name).Model(config)`, called as
+ * `outputs = model(datas)` at train_eval.py:111,242,323).  The reference has no native
+ * layer; every entry point below names the reference lines whose ATen op sequence it
+ * replaces (paths relative to /root/reference/MIND_2020/).
+ *
+ * Conventions
+ *   - plain C: POD structs, raw DEVICE pointers, sizes; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the default stream).
+ *   - the library allocates nothing and owns nothing: activations, gradients and workspace
+ *     are caller buffers; workspace sizes come from the *_workspace_bytes queries.
+ *   - every call is asynchronous on `stream`, re-entrant across streams, and returns
+ *     0 on success or a negative NRMS_E* code; nrms_last_error() gives the (thread-local) text.
+ *   - all matrices are row-major and dense; fp32 unless stated.  M = n_seq * seq_len.
+ *   - gradients are ACCUMULATED (+=) into the caller's buffers (zero them per step, as
+ *     `model.zero_grad()` does at train_eval.py:115).
+ */
+#ifndef NRMS_HIP_H
+#define NRMS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRMS_OK            0
+#define NRMS_EINVAL       -1   /* bad dims / null pointer / unsupported shape */
+#define NRMS_ELAUNCH      -2   /* HIP launch or runtime error */
+#define NRMS_EWORKSPACE   -3   /* workspace too small */
+
+#define NRMS_PRECISION_FP32 0  /* f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32): exact fp32 */
+
+/* One self-attention + additive-pooling encoder pass over n_seq sequences of seq_len rows.
+ * vocab > 0  : news encoder -- input is `ids` [n_seq, seq_len] int64, rows gathered from
+ *              `table` (NewsEncoder.forward, model/nrms_v0.py:154-176).
+ * vocab == 0 : user encoder -- input is `x` [n_seq, seq_len, d_model]
+ *              (UserEncoder.forward, model/nrms_v0.py:188-199). */
+typedef struct nrms_encoder_desc {
+    int32_t  n_seq;        /* titles (B*(H+C)) or users (B) */
+    int32_t  seq_len;      /* L or H, 1..64 */
+    int32_t  d_model;      /* config.word_embed_size; multiple of 4; = n_heads * d_k */
+    int32_t  n_heads;      /* config.num_attention_heads; d_k = d_model / n_heads even, <= 64 */
+    int32_t  q_dim;        /* config.query_vector_dim, multiple of 4, <= 256 */
+    int32_t  vocab;        /* rows of `table`, or 0 */
+    float    p_drop;       /* config.dropout when training, 0 in eval: both dropout sites of the
+                              news encoder (nrms_v0.py:137 and :171-173).  Must be 0 if vocab==0. */
+    int32_t  precision;    /* NRMS_PRECISION_* */
+    uint64_t seed;         /* counter-based RNG key for the dropout masks (per step) */
+} nrms_encoder_desc;
+
+/* Parameters, in the reference's own tensor layout ([out,in] Linear weights).
+ * w_qkv is W_Q.weight, W_K.weight, W_V.weight stacked on dim 0 (nrms_v0.py:35-37). */
+typedef struct nrms_encoder_weights {
+    const float* table;    /* [vocab, d]   news_encoder.word_embedding.0.weight, or NULL */
+    const float* w_qkv;    /* [3d, d] */
+    const float* b_qkv;    /* [3d] */
+    const float* w_add;    /* [q, d]       additive_attention.linear.weight (nrms_v0.py:91) */
+    const float* b_add;    /* [q] */
+    const float* q_vec;    /* [q]          additive_attention.attention_query_vector (:92-93) */
+} nrms_encoder_weights;
+
+typedef struct nrms_encoder_grads {   /* same shapes as the weights; accumulated */
+    float* table;          /* dense [vocab, d]; row 0 never written (padding_idx=0, nrms_v0.py:136) */
+    float* w_qkv;
+    float* b_qkv;
+    float* w_add;
+    float* b_add;
+    float* q_vec;
+} nrms_encoder_grads;
+
+/* Activations the forward saves for the backward (caller-owned).  In eval only `qkv`,
+ * `ctx` are required scratch; `t` and `w` may then be NULL. */
+typedef struct nrms_encoder_acts {
+    float* qkv;            /* [M, 3d]  Q|K|V projections incl. bias */
+    float* ctx;            /* [M, d]   head-concatenated attention output AFTER dropout */
+    float* t;              /* [M, q]   tanh(linear(ctx))            (nrms_v0.py:108) */
+    float* w;              /* [M]      additive-attention softmax weights (nrms_v0.py:110-112) */
+} nrms_encoder_acts;
+
+/* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V
+ * -> dropout -> tanh(linear)·q -> softmax over the sequence -> weighted sum.
+ * Replaces model/nrms_v0.py:13-23,46-76,100-126,154-176,188-199.
+ * out: [n_seq, d].  Exactly one of ids / x is used (by desc->vocab). */
+int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w,
+                     const int64_t* ids, const float* x,
+                     const nrms_encoder_acts* acts, float* out, void* stream);
+
+/* Backward of the above (autograd through the same lines; `loss.backward()` train_eval.py:126).
+ * dout: [n_seq, d].  grads: accumulated.  dx: [M, d] gradient w.r.t. `x` (user encoder), or
+ * NULL for the news encoder, whose input gradient is scatter-added into grads->table
+ * (the dense embedding gradient the reference builds 55x per step). */
+size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc);
+int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w,
+                     const int64_t* ids, const float* x,
+                     const nrms_encoder_acts* acts, const float* dout,
+                     const nrms_encoder_grads* grads, float* dx,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Click scores: bmm(cand [B,C,d], user [B,d,1]) then masked_fill(mask==0, -1e9)
+ * (DotProductClickPredictor, nrms_v0.py:205-216; mask nrms_v0.py:272-274).  mask may be NULL. */
+int nrms_click_score_fwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,
+                         const uint8_t* mask, float* scores, void* stream);
+/* dscores [B,C] -> dcand [B,C,d], duser [B,d] (masked slots receive no gradient). */
+int nrms_click_score_bwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,
+                         const uint8_t* mask, const float* dscores, float* dcand, float* duser,
+                         void* stream);
+
+/* nn.CrossEntropyLoss with every label 0 (train_eval.py:63,116-117):
+ * loss_sum[0] += sum_b -log_softmax(scores[b])[0]   (caller divides by the global batch),
+ * dscores = (softmax(scores) - onehot0) * grad_scale (grad_scale = 1/B_global).
+ * dscores may be NULL (loss only). */
+int nrms_ce_loss_fwd_bwd(int32_t B, int32_t C, const float* scores, float* loss_sum,
+                         float* dscores, float grad_scale, void* stream);
+
+/* torch.optim.Adam defaults (train_eval.py:48,127): one fused pass over a flat fp32 buffer.
+ * g is multiplied by grad_scale first (1/world_size after a summing all-reduce).
+ * step is 1-based. */
+int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                   void* stream);
+
+/* The keep mask (1 = kept) the encoder kernels apply at a dropout site, for n_rows x d
+ * elements: site 0 = embedding dropout (nrms_v0.py:137), site 1 = context dropout (:171-173).
+ * Lets a test replay a training step through the oracle with identical masks. */
+int nrms_dropout_keep_mask(uint64_t seed, int32_t site, int64_t n_rows, int32_t d, float p_drop,
+                           uint8_t* keep, void* stream);
+
+/* Per-kernel device timing (HIP events on the launch stream), for bench.py's roofline leg.
+ * nrms_timing_read synchronises the recorded events; returns 0 and the accumulated
+ * milliseconds / launch count of kernels whose name starts with `prefix`. */
+void nrms_timing_enable(int enable);
+void nrms_timing_reset(void);
+int  nrms_timing_read(const char* prefix, double* total_ms, int64_t* launches);
+
+const char* nrms_last_error(void);
+const char* nrms_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRMS_HIP_H */

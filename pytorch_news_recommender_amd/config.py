@@ -1,0 +1,52 @@
+"""Attribute-bag configuration with the reference's field names and defaults
+(/root/reference/MIND_2020/config.py:5-89).  Only fields the NRMS hot path, its data feed and
+its train/eval loop read are kept; ``__nrms__()`` adds the model hyper-parameters exactly as
+the reference's entry scripts expect to call it (run_v0.py:50)."""
+import torch
+
+
+class Config(object):
+    def __init__(self, model_name='NRMS', dataset='../MIND'):
+        self.model_name = model_name
+        self.data_path = './data_processed/'
+        self.train_path = dataset + '/train/'
+        self.dev_path = dataset + '/dev/'
+        self.test_path = dataset + '/test/'
+        self.small_train_path = dataset + '/small_train/'
+        self.small_dev_path = dataset + '/small_dev/'
+
+        self.word_embedding_pretrained = 'all_word_embedding_v3.npz'
+        self.mode = 'large'                      # 'large' / 'demo' / 'synthetic'
+
+        self.save_path = './save_model/'
+        self.log_path = './logs/' + self.model_name
+        self.train_data = 'train_datas.pkl'
+        self.dev_data = 'dev_datas.pkl'
+        self.test_data = 'test_datas.pkl'
+
+        self.n_words_title = 20                  # title length L (config.py:30)
+        self.n_words_abst = 40
+        self.history_len = 50                    # H
+        self.sample_size = 5                     # negatives per positive: C = sample_size + 1 in training
+        self.max_candidate_size = 300            # C in evaluation
+
+        self.save_flag = True
+        self.random_seed = 1998
+        self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+
+        self.n_words = 45800
+        self.word_embed_size = 300
+        self.num_epochs = 5
+        self.eval_step = 5000
+        self.batch_size = 512
+        self.learning_rate = 1e-3
+        self.dropout = 0.2
+        self.require_improvement = 10000
+        self.warm_up_steps = 500
+        self.warm_up = False
+
+    def __nrms__(self):
+        self.query_vector_dim = 200
+        self.title_heads_num = 6
+        self.num_attention_heads = 10
+        self.user_heads_num = 8

@@ -1,0 +1,254 @@
+// C ABI of libnrms_hip.so (declared in include/nrms_hip.h): argument validation, the kernel
+// sequences of one encoder forward / backward, error text and optional event timing.
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "gemm.h"
+
+namespace nrms {
+
+int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
+                     const float* dctx, float* dqkv, hipStream_t stream);
+int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
+                       const float* q_vec, float* T, float* wout, float* out, hipStream_t stream);
+int addattn_bwd_rows_waves(int n_seq);
+int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w,
+                            const float* T, float* ds, float* dq_partial, float* dq, hipStream_t stream);
+
+// ---- error text -----------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return NRMS_ELAUNCH;
+    }
+    return NRMS_OK;
+}
+
+// ---- event timing ---------------------------------------------------------------------
+struct TimedLaunch { std::string name; hipEvent_t start, stop; };
+static std::mutex g_tmu;
+static bool g_timing = false;
+static std::vector<TimedLaunch> g_launches;
+
+TimingScope::TimingScope(const char* name, hipStream_t s) : active(false), slot(-1), stream(s) {
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    TimedLaunch t;
+    t.name = name;
+    if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return;
+    hipEventRecord(t.start, s);
+    g_launches.push_back(t);
+    slot = (int)g_launches.size() - 1;
+    active = true;
+}
+
+TimingScope::~TimingScope() {
+    if (!active) return;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    hipEventRecord(g_launches[slot].stop, stream);
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- encoder --------------------------------------------------------------------------
+static int validate_desc(const nrms_encoder_desc* d, const char* who) {
+    NRMS_REQUIRE(d != nullptr, "%s: null desc", who);
+    NRMS_REQUIRE(d->n_seq >= 0, "%s: n_seq=%d", who, d->n_seq);
+    NRMS_REQUIRE(d->seq_len >= 1 && d->seq_len <= 64, "%s: seq_len=%d outside 1..64", who, d->seq_len);
+    NRMS_REQUIRE(d->d_model > 0 && (d->d_model & 3) == 0, "%s: d_model=%d must be a positive multiple of 4", who,
+                 d->d_model);
+    NRMS_REQUIRE(d->n_heads > 0 && d->d_model % d->n_heads == 0, "%s: d_model %% n_heads != 0", who);
+    const int dk = d->d_model / d->n_heads;
+    NRMS_REQUIRE(dk <= 64 && (dk & 1) == 0, "%s: d_k=%d must be even and <= 64", who, dk);
+    NRMS_REQUIRE(d->q_dim > 0 && (d->q_dim & 3) == 0 && d->q_dim <= 256, "%s: q_dim=%d must be a multiple of 4 <= 256",
+                 who, d->q_dim);
+    NRMS_REQUIRE(d->vocab >= 0, "%s: vocab=%d", who, d->vocab);
+    NRMS_REQUIRE(d->p_drop >= 0.f && d->p_drop < 1.f, "%s: p_drop=%f", who, (double)d->p_drop);
+    NRMS_REQUIRE(d->vocab > 0 || d->p_drop == 0.f, "%s: dropout is only defined for the news encoder", who);
+    NRMS_REQUIRE(d->precision == NRMS_PRECISION_FP32, "%s: unsupported precision %d", who, d->precision);
+    NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
+    return NRMS_OK;
+}
+
+struct BwdWorkspace {
+    size_t dctx, dqkv, ds, wqkv_t, wadd_t, tn_partial, dq_partial, total;   // byte offsets
+};
+
+static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
+    const size_t M = (size_t)d->n_seq * d->seq_len, dm = d->d_model, q = d->q_dim;
+    BwdWorkspace w;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
+    w.dctx = take(M * dm);
+    w.dqkv = take(M * 3 * dm);
+    w.ds = take(M);
+    w.wqkv_t = take(3 * dm * dm);
+    w.wadd_t = take(q * dm);
+    const size_t p1 = gemm_tn_workspace_floats((int)M, (int)(3 * dm), (int)dm, nullptr);
+    const size_t p2 = gemm_tn_workspace_floats((int)M, (int)q, (int)dm, nullptr);
+    w.tn_partial = take(p1 > p2 ? p1 : p2);
+    w.dq_partial = take((size_t)addattn_bwd_rows_waves(d->n_seq) * q);
+    w.total = off;
+    return w;
+}
+
+}  // namespace nrms
+
+using namespace nrms;
+
+extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
+                                const float* x, const nrms_encoder_acts* acts, float* out, void* stream) {
+    int rc = validate_desc(desc, "encoder_fwd");
+    if (rc) return rc;
+    NRMS_REQUIRE(w && acts && out, "encoder_fwd: null argument");
+    NRMS_REQUIRE(w->w_qkv && w->b_qkv && w->w_add && w->b_add && w->q_vec, "encoder_fwd: null weight");
+    NRMS_REQUIRE(acts->qkv && acts->ctx, "encoder_fwd: acts.qkv / acts.ctx are required");
+    const bool gather = desc->vocab > 0;
+    NRMS_REQUIRE(gather ? (ids != nullptr && w->table != nullptr) : (x != nullptr),
+                 "encoder_fwd: %s input missing", gather ? "ids/table" : "x");
+    if (desc->n_seq == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int S = desc->seq_len, d = desc->d_model, q = desc->q_dim, M = desc->n_seq * S;
+    const Dropout drop = make_dropout(desc->seed, desc->p_drop);
+
+    NTArgs g{};
+    g.M = M; g.N = 3 * d; g.K = d; g.rows_per_tile = NT_BM;
+    g.A = x; g.lda = d; g.ids = ids; g.table = w->table;
+    g.W = w->w_qkv; g.bias = w->b_qkv; g.C = acts->qkv; g.ldc = 3 * d; g.drop = drop;
+    rc = launch_gemm_nt(gather ? A_GATHER : A_PLAIN, E_STORE, g, s, "qkv_proj_fwd");
+    if (rc) return rc;
+    rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, acts->ctx, drop, nullptr, nullptr, s);
+    if (rc) return rc;
+    return launch_addattn_fwd(desc->n_seq, S, d, q, acts->ctx, w->w_add, w->b_add, w->q_vec, acts->t, acts->w, out, s);
+}
+
+extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc) {
+    if (validate_desc(desc, "encoder_bwd_workspace_bytes")) return 0;
+    return bwd_layout(desc).total;
+}
+
+extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
+                                const float* x, const nrms_encoder_acts* acts, const float* dout,
+                                const nrms_encoder_grads* grads, float* dx, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    int rc = validate_desc(desc, "encoder_bwd");
+    if (rc) return rc;
+    NRMS_REQUIRE(w && acts && dout && grads && workspace, "encoder_bwd: null argument");
+    NRMS_REQUIRE(acts->qkv && acts->ctx && acts->t && acts->w, "encoder_bwd: all saved activations are required");
+    NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec,
+                 "encoder_bwd: null gradient buffer");
+    const bool gather = desc->vocab > 0;
+    NRMS_REQUIRE(gather ? (ids != nullptr && w->table != nullptr && grads->table != nullptr) : (x != nullptr && dx != nullptr),
+                 "encoder_bwd: %s missing", gather ? "ids/table/grads.table" : "x/dx");
+    const BwdWorkspace L = bwd_layout(desc);
+    if (workspace_bytes < L.total) {
+        set_error("encoder_bwd: workspace %zu < required %zu bytes", workspace_bytes, L.total);
+        return NRMS_EWORKSPACE;
+    }
+    NRMS_REQUIRE(((uintptr_t)workspace & 255) == 0, "encoder_bwd: workspace must be 256-byte aligned");
+    if (desc->n_seq == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int S = desc->seq_len, d = desc->d_model, q = desc->q_dim, M = desc->n_seq * S;
+    const Dropout drop = make_dropout(desc->seed, desc->p_drop);
+    char* base = (char*)workspace;
+    float* dctx = (float*)(base + L.dctx);
+    float* dqkv = (float*)(base + L.dqkv);
+    float* ds = (float*)(base + L.ds);
+    float* wqkv_t = (float*)(base + L.wqkv_t);
+    float* wadd_t = (float*)(base + L.wadd_t);
+    float* tn_partial = (float*)(base + L.tn_partial);
+    float* dq_partial = (float*)(base + L.dq_partial);
+
+    // 1. pooling rows: ds, d(q_vec)
+    rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec, s);
+    if (rc) return rc;
+    // 2. d(ctx) = dZ Wa + w_s dout, through the context dropout mask
+    rc = launch_transpose(w->w_add, wadd_t, q, d, s);
+    if (rc) return rc;
+    {
+        NTArgs g{};
+        g.M = M; g.N = d; g.K = q; g.rows_per_tile = NT_BM;
+        g.ds = ds; g.qv = w->q_vec; g.T = acts->t;
+        g.W = wadd_t; g.C = dctx; g.ldc = d;
+        g.wrow = acts->w; g.dout = dout; g.S = S; g.drop = drop;
+        rc = launch_gemm_nt(A_DZ, E_DCTX, g, s, "dctx_bwd");
+        if (rc) return rc;
+    }
+    // 3. d(w_add), d(b_add) = dZ^T [ctx | 1]
+    {
+        TNArgs t{};
+        t.M = M; t.N = q; t.K = d; t.amode = A_DZ; t.bmode = A_PLAIN;
+        t.ds = ds; t.qv = w->q_vec; t.T = acts->t; t.B = acts->ctx; t.ldb = d;
+        t.dW = grads->w_add; t.dbias = grads->b_add; t.partial = tn_partial;
+        rc = launch_gemm_tn(t, s, "dwadd_bwd");
+        if (rc) return rc;
+    }
+    // 4. attention backward
+    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, drop, dctx, dqkv, s);
+    if (rc) return rc;
+    // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]
+    {
+        TNArgs t{};
+        t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN; t.bmode = gather ? A_GATHER : A_PLAIN;
+        t.A = dqkv; t.lda = 3 * d; t.B = x; t.ldb = d; t.ids = ids; t.table = w->table; t.drop = drop;
+        t.dW = grads->w_qkv; t.dbias = grads->b_qkv; t.partial = tn_partial;
+        rc = launch_gemm_tn(t, s, "dwqkv_bwd");
+        if (rc) return rc;
+    }
+    // 6. dX = dQKV Wqkv: plain store (user encoder) or scatter-add into the embedding gradient
+    rc = launch_transpose(w->w_qkv, wqkv_t, 3 * d, d, s);
+    if (rc) return rc;
+    {
+        NTArgs g{};
+        g.M = M; g.N = d; g.K = 3 * d; g.rows_per_tile = NT_BM;
+        g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t; g.ids = ids; g.drop = drop;
+        if (gather) { g.C = grads->table; g.ldc = d; }
+        else { g.C = dx; g.ldc = d; }
+        rc = launch_gemm_nt(A_PLAIN, gather ? E_SCATTER : E_STORE, g, s, gather ? "dx_scatter_bwd" : "dx_bwd");
+    }
+    return rc;
+}
+
+extern "C" void nrms_timing_enable(int enable) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_timing = enable != 0;
+}
+
+extern "C" void nrms_timing_reset(void) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (auto& t : g_launches) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    g_launches.clear();
+}
+
+extern "C" int nrms_timing_read(const char* prefix, double* total_ms, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    double tot = 0.0;
+    int64_t n = 0;
+    const std::string p = prefix ? prefix : "";
+    for (auto& t : g_launches) {
+        if (t.name.compare(0, p.size(), p) != 0) continue;
+        if (hipEventSynchronize(t.stop) != hipSuccess) { set_error("timing_read: event sync failed"); return NRMS_ELAUNCH; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) != hipSuccess) { set_error("timing_read: elapsed failed"); return NRMS_ELAUNCH; }
+        tot += ms;
+        ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return NRMS_OK;
+}
+
+extern "C" const char* nrms_last_error(void) { return g_err; }
+extern "C" const char* nrms_version(void) { return "nrms_hip 0.1 (gfx950, fp32 MFMA)"; }

@@ -1,0 +1,366 @@
+// Additive-attention pooling (AdditiveAttention, /root/reference/MIND_2020/model/nrms_v0.py:100-126),
+// click scores (:205-216,:272-274), cross-entropy with label 0 (train_eval.py:63,116-117),
+// fused Adam (train_eval.py:48,127) and the dropout-mask export used by the parity tests.
+#include "gemm.h"
+
+namespace nrms {
+
+// =======================================================================================
+// Forward: one workgroup owns `spb` whole sequences (rows_per_tile = spb*S <= 128):
+//   T = tanh(C Wa^T + ba) on the MFMA, s = T.q reduced across the tile's columns in-register,
+//   w = softmax_S(s), out = sum_s w_s C_s.  T and w are saved for the backward.
+// =======================================================================================
+struct AddFwdArgs {
+    NTArgs g;              // A = ctx [M,d], W = w_add [q,d], bias = b_add, N = q, K = d
+    const float* qv;       // [q]
+    float* T;              // [M,q] or null
+    float* wout;           // [M]   or null
+    float* out;            // [n_seq, d]
+    int S, d;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LS];
+    __shared__ __attribute__((aligned(16))) float Bs[NT * 16 * NT_LS];
+    __shared__ float sc[NT_BM];
+
+    const NTArgs& g = a.g;
+    const int row0 = blockIdx.x * g.rows_per_tile;
+    const int rows_valid = min(g.rows_per_tile, g.M - row0);
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_nt_mainloop<NT, A_PLAIN>(g, row0, rows_valid, 0, acc, As, Bs);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int rl = 32 * wave + 16 * mt + 4 * kq + reg;
+            const long grow = (long)row0 + rl;
+            float part = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = 16 * nt + r16;
+                if (n < g.N) {
+                    const float t = tanhf(acc[mt][nt][reg] + g.bias[n]);
+                    part += t * a.qv[n];
+                    if (a.T != nullptr && rl < rows_valid) a.T[grow * g.N + n] = t;
+                }
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 8, 64);
+            if (r16 == 0) sc[rl] = part;
+        }
+    __syncthreads();
+    const int spb = rows_valid / a.S;
+    if (tid < spb) {
+        float* s = sc + tid * a.S;
+        float mx = -1e30f;
+        for (int i = 0; i < a.S; ++i) mx = fmaxf(mx, s[i]);
+        float sum = 0.f;
+        for (int i = 0; i < a.S; ++i) { const float e = expf(s[i] - mx); s[i] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int i = 0; i < a.S; ++i) {
+            s[i] *= inv;
+            if (a.wout != nullptr) a.wout[(long)row0 + tid * a.S + i] = s[i];
+        }
+    }
+    __syncthreads();
+    const long seq0 = row0 / a.S;
+    for (int idx = tid; idx < spb * a.d; idx += 256) {
+        const int sq = idx / a.d, c = idx - sq * a.d;
+        const float* crow = g.A + ((long)row0 + sq * a.S) * g.lda + c;
+        const float* w = sc + sq * a.S;
+        float o = 0.f;
+        for (int i = 0; i < a.S; ++i) o += w[i] * crow[(long)i * g.lda];
+        a.out[(seq0 + sq) * a.d + c] = o;
+    }
+}
+
+template <int NT>
+static int launch_addfwd_inst(const AddFwdArgs& a, hipStream_t stream) {
+    TimingScope ts("addattn_fwd", stream);
+    hipLaunchKernelGGL((addattn_fwd_kernel<NT>), dim3(cdiv(a.g.M, a.g.rows_per_tile)), dim3(256), 0, stream, a);
+    return check_launch("addattn_fwd");
+}
+
+int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
+                       const float* q_vec, float* T, float* wout, float* out, hipStream_t stream) {
+    if (n_seq <= 0) return NRMS_OK;
+    AddFwdArgs a{};
+    a.g.M = n_seq * S; a.g.N = q; a.g.K = d;
+    a.g.rows_per_tile = (NT_BM / S) * S;
+    a.g.A = ctx; a.g.lda = d; a.g.W = w_add; a.g.bias = b_add;
+    a.qv = q_vec; a.T = T; a.wout = wout; a.out = out; a.S = S; a.d = d;
+    if (q <= 32) return launch_addfwd_inst<2>(a, stream);
+    if (q <= 64) return launch_addfwd_inst<4>(a, stream);
+    if (q <= 128) return launch_addfwd_inst<8>(a, stream);
+    if (q <= 208) return launch_addfwd_inst<13>(a, stream);
+    if (q <= 256) return launch_addfwd_inst<16>(a, stream);
+    set_error("addattn_fwd: q_dim=%d > 256 unsupported", q);
+    return NRMS_EINVAL;
+}
+
+// =======================================================================================
+// Backward, row part: one wave per sequence.
+//   dw_s = C_s . dout ; ds_s = w_s (dw_s - sum_t w_t dw_t) ; dq[n] += sum_s ds_s T[s][n]
+// ds feeds the dZ loaders of the two GEMMs; dq goes to a per-wave partial row (deterministic
+// two-stage sum).
+// =======================================================================================
+constexpr int ROWS_WPB = 4;
+constexpr int ROWS_MAXQ = 256;
+
+__global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
+    int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w, const float* T, float* ds,
+    float* dq_partial) {
+    __shared__ float dsl[ROWS_WPB][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long gw = (long)blockIdx.x * ROWS_WPB + wave, nw = (long)gridDim.x * ROWS_WPB;
+    float dq[ROWS_MAXQ / 64] = {0.f, 0.f, 0.f, 0.f};
+    for (long seq = gw; seq < n_seq; seq += nw) {
+        const float* c = ctx + seq * S * d;
+        const float* g = dout + seq * d;
+        float my_dw = 0.f;                 // lane s holds dw_s
+        for (int s = 0; s < S; ++s) {
+            float p = 0.f;
+            for (int k = lane * 4; k < d; k += 256) {
+                const f32x4 cv = *reinterpret_cast<const f32x4*>(c + (long)s * d + k);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + k);
+                p += cv[0] * gv[0] + cv[1] * gv[1] + cv[2] * gv[2] + cv[3] * gv[3];
+            }
+            p = wave_sum(p);
+            if (lane == s) my_dw = p;
+        }
+        const float my_w = lane < S ? w[seq * S + lane] : 0.f;
+        const float dot = wave_sum(my_w * my_dw);
+        const float my_ds = my_w * (my_dw - dot);
+        if (lane < S) ds[seq * S + lane] = my_ds;
+        dsl[wave][lane] = my_ds;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float* t = T + seq * S * q;
+        for (int s = 0; s < S; ++s) {
+            const float dsv = dsl[wave][s];
+#pragma unroll
+            for (int j = 0; j < ROWS_MAXQ / 64; ++j) {
+                const int n = lane + 64 * j;
+                if (n < q) dq[j] += dsv * t[(long)s * q + n];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS_MAXQ / 64; ++j) {
+        const int n = lane + 64 * j;
+        if (n < q) dq_partial[gw * q + n] = dq[j];
+    }
+}
+
+__global__ void colsum_add_kernel(const float* partial, int rows, int cols, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += partial[(long)r * cols + c];
+    out[c] += s;
+}
+
+int addattn_bwd_rows_waves(int n_seq) {
+    int blocks = cdiv(n_seq, ROWS_WPB);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return blocks * ROWS_WPB;
+}
+
+int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w,
+                            const float* T, float* ds, float* dq_partial, float* dq, hipStream_t stream) {
+    if (n_seq <= 0) return NRMS_OK;
+    const int waves = addattn_bwd_rows_waves(n_seq);
+    {
+        TimingScope ts("addattn_bwd_rows", stream);
+        hipLaunchKernelGGL(addattn_bwd_rows_kernel, dim3(waves / ROWS_WPB), dim3(64 * ROWS_WPB), 0, stream, n_seq, S,
+                           d, q, ctx, dout, w, T, ds, dq_partial);
+        int rc = check_launch("addattn_bwd_rows");
+        if (rc) return rc;
+    }
+    TimingScope ts("colsum_add", stream);
+    hipLaunchKernelGGL(colsum_add_kernel, dim3(cdiv(q, 64)), dim3(64), 0, stream, dq_partial, waves, q, dq);
+    return check_launch("colsum_add");
+}
+
+// =======================================================================================
+// Click scores, CE loss, Adam, dropout mask export
+// =======================================================================================
+__global__ void click_fwd_kernel(int B, int C, int d, const float* cand, const float* user, const uint8_t* mask,
+                                 float* scores) {
+    const int lane = threadIdx.x & 63;
+    const long u = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (u >= (long)B * C) return;
+    const long b = u / C;
+    const float* cv = cand + u * d;
+    const float* uv = user + b * d;
+    float p = 0.f;
+    for (int k = lane; k < d; k += 64) p += cv[k] * uv[k];
+    p = wave_sum(p);
+    if (lane == 0) scores[u] = (mask != nullptr && mask[u] == 0) ? -1e9f : p;
+}
+
+__global__ void click_bwd_kernel(int B, int C, int d, const float* cand, const float* user, const uint8_t* mask,
+                                 const float* dscores, float* dcand, float* duser) {
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float uv = user[(long)b * d + k];
+        float du = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const long u = (long)b * C + c;
+            const float g = (mask != nullptr && mask[u] == 0) ? 0.f : dscores[u];
+            dcand[u * d + k] = g * uv;
+            du += g * cand[u * d + k];
+        }
+        duser[(long)b * d + k] = du;
+    }
+}
+
+__global__ void ce_loss_kernel(int B, int C, const float* scores, float* loss_sum, float* dscores, float gscale) {
+    __shared__ float red[256];
+    float local = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* s = scores + (long)b * C;
+        float mx = -3.0e38f;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, s[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(s[c] - mx);
+        const float lse = mx + logf(sum);
+        local += lse - s[0];
+        if (dscores != nullptr) {
+            const float inv = 1.0f / sum;
+            for (int c = 0; c < C; ++c) {
+                const float p = expf(s[c] - mx) * inv;
+                dscores[(long)b * C + c] = (p - (c == 0 ? 1.0f : 0.0f)) * gscale;
+            }
+        }
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_sum[0] += red[0];
+}
+
+__global__ void adam_kernel(size_t n4, size_t n, float* p, const float* g, float* m, float* v, float step_size,
+                            float b1, float b2, float inv_sqrt_bc2, float eps, float gscale) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * gscale;
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mv[e] = b1 * mv[e] + (1.0f - b1) * gv[e];
+            vv[e] = b2 * vv[e] + (1.0f - b2) * gv[e] * gv[e];
+            const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+            pv[e] -= step_size * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    const size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float gv = g[t] * gscale;
+        const float mv = b1 * m[t] + (1.0f - b1) * gv;
+        const float vv = b2 * v[t] + (1.0f - b2) * gv * gv;
+        m[t] = mv; v[t] = vv;
+        p[t] -= step_size * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+    }
+}
+
+__global__ void keep_mask_kernel(uint64_t seed, uint32_t site, long groups, uint32_t thresh, uint8_t* keep) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups) return;
+    uint32_t r[4];
+    philox4x32_7(seed, (uint64_t)i, site, r);
+    uchar4 k;
+    k.x = r[0] >= thresh; k.y = r[1] >= thresh; k.z = r[2] >= thresh; k.w = r[3] >= thresh;
+    reinterpret_cast<uchar4*>(keep)[i] = k;
+}
+
+}  // namespace nrms
+
+using namespace nrms;
+
+extern "C" int nrms_click_score_fwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,
+                                    const uint8_t* mask, float* scores, void* stream) {
+    NRMS_REQUIRE(B >= 0 && C > 0 && d > 0 && cand && user && scores, "click_score_fwd: bad arguments");
+    if (B == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    TimingScope ts("click_fwd", s);
+    hipLaunchKernelGGL(click_fwd_kernel, dim3(cdiv((long)B * C, 4)), dim3(256), 0, s, B, C, d, cand, user, mask, scores);
+    return check_launch("click_fwd");
+}
+
+extern "C" int nrms_click_score_bwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,
+                                    const uint8_t* mask, const float* dscores, float* dcand, float* duser,
+                                    void* stream) {
+    NRMS_REQUIRE(B >= 0 && C > 0 && d > 0 && cand && user && dscores && dcand && duser, "click_score_bwd: bad arguments");
+    if (B == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    TimingScope ts("click_bwd", s);
+    hipLaunchKernelGGL(click_bwd_kernel, dim3(B), dim3(128), 0, s, B, C, d, cand, user, mask, dscores, dcand, duser);
+    return check_launch("click_bwd");
+}
+
+extern "C" int nrms_ce_loss_fwd_bwd(int32_t B, int32_t C, const float* scores, float* loss_sum, float* dscores,
+                                    float grad_scale, void* stream) {
+    NRMS_REQUIRE(B >= 0 && C > 0 && scores && loss_sum, "ce_loss: bad arguments");
+    if (B == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    TimingScope ts("ce_loss", s);
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, s, B, C, scores, loss_sum, dscores, grad_scale);
+    return check_launch("ce_loss");
+}
+
+extern "C" int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                              float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+    NRMS_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad arguments");
+    NRMS_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+                 "adam_step: buffers must be 16-byte aligned");
+    if (n == 0) return NRMS_OK;
+    // torch.optim.Adam: step_size = lr / (1 - b1^t); denom = sqrt(v)/sqrt(1 - b2^t) + eps
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    TimingScope ts("adam", s);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, n4, n, param, grad, exp_avg, exp_avg_sq, step_size,
+                       beta1, beta2, inv_sqrt_bc2, eps, grad_scale);
+    return check_launch("adam");
+}
+
+extern "C" int nrms_dropout_keep_mask(uint64_t seed, int32_t site, int64_t n_rows, int32_t d, float p_drop,
+                                      uint8_t* keep, void* stream) {
+    NRMS_REQUIRE(keep && n_rows >= 0 && d > 0 && (d & 3) == 0 && site >= 0, "dropout_keep_mask: bad arguments");
+    const long groups = (long)n_rows * d / 4;
+    if (groups == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(keep_mask_kernel, dim3(cdiv(groups, 256)), dim3(256), 0, s, seed, (uint32_t)site, groups,
+                       drop_threshold(p_drop), keep);
+    return check_launch("keep_mask");
+}

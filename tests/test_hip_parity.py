@@ -1,0 +1,221 @@
+"""Parity of the HIP path (through the drop-in Model and the C ABI) against the golden fixtures
+generated from the imported reference, and against the oracle on seeded inputs.
+
+Tolerances (fp32 MFMA path): scores / vectors 1e-5 absolute (north_star asks 1e-4), gradients
+rtol 1e-3 + atol 2e-6 (fp32, different summation order; embedding-gradient rows are float
+atomic sums)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_news_recommender_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-5
+GRAD_RTOL, GRAD_ATOL = 1e-3, 2e-6
+
+
+def make_model(shape, params, dropout=0.0, device="cuda"):
+    from pytorch_news_recommender_amd.config import Config
+    from pytorch_news_recommender_amd.model.nrms_hip import Model
+    cfg = Config("nrms_hip")
+    cfg.__nrms__()
+    cfg.word_embed_size = shape.word_embed_size
+    cfg.num_attention_heads = shape.num_attention_heads
+    cfg.query_vector_dim = shape.query_vector_dim
+    cfg.dropout = dropout
+    m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    return m.to(device)
+
+
+def tbatch(batch):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
+
+
+def fwd_bwd(model, batch):
+    model.zero_grad()
+    scores = model(tbatch(batch))
+    loss = torch.nn.CrossEntropyLoss()(scores, torch.zeros(len(scores), dtype=torch.long, device=scores.device))
+    loss.backward()
+    grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
+    return scores.detach().cpu().numpy(), float(loss), grads
+
+
+def assert_params_close(got, want, name):
+    """Parameters after a few Adam steps.  Adam's update lr*m/(sqrt(v)+eps) is ill-conditioned
+    where |g| ~ eps=1e-8 (d(update)/dg ~ lr/eps there), so a handful of elements may move by a
+    fraction of one lr step on fp32 summation-order noise; the bulk must agree tightly."""
+    diff = np.abs(got - want)
+    # e.g. d(b_add) = sum_s ds_s q (1-T_s^2) with sum_s ds_s == 0: a cancelling sum whose fp32
+    # relative noise (~1e-2, also between the torch-CPU oracle and the reference: 5e-6 after 3 steps)
+    # Adam turns into ~1e-2 of a step.  So: bulk within 5% of one lr step, nothing beyond 30%.
+    assert np.median(diff) < 5e-5, (name, float(np.median(diff)))
+    assert diff.max() < 3e-4, (name, float(diff.max()))
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_library_loaded_and_native():
+    from pytorch_news_recommender_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.nrms_version()
+    assert os.path.basename(_lib.LIB_PATH) == "libnrms_hip.so"
+
+
+def test_g1_odd_golden(golden_dir):
+    g = load(golden_dir, "g1_odd.npz")
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=11, pad_row_zero=False)
+    batch = synth.make_batch(shape, seed=12, ragged=True, min_title=1, empty_history_user=True,
+                             all_pad_title=True, mask_some_candidates=True)
+    model = make_model(shape, params)
+    model.train()                      # dropout=0: train mode == eval mode numerically
+    scores, loss, grads = fwd_bwd(model, batch)
+    np.testing.assert_allclose(scores, g["scores"], rtol=0, atol=SCORE_TOL)
+    assert abs(loss - float(g["loss"])) < SCORE_TOL
+    assert (scores[batch["candidate_mask"] == 0] == np.float32(-1e9)).all()
+    for n in synth.param_names():
+        np.testing.assert_allclose(grads[n], g["grad/" + n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+    assert not grads["news_encoder.word_embedding.0.weight"][0].any()     # padding_idx = 0
+    # helper API (nrms_v0.py:278-312)
+    model.eval()
+    B, H, L = batch["browsed_titles"].shape
+    with torch.no_grad():
+        hist = model.get_news_vector(torch.from_numpy(batch["browsed_titles"]).reshape(B * H, L)).view(B, H, -1)
+        user = model.get_user_vector(hist)
+        pred = model.get_prediction(torch.from_numpy(g["cand"][0]), torch.from_numpy(g["user"][0]))
+    np.testing.assert_allclose(hist.cpu().numpy(), g["hist"], atol=SCORE_TOL)
+    np.testing.assert_allclose(user.cpu().numpy(), g["user"], atol=SCORE_TOL)
+    np.testing.assert_allclose(pred.cpu().numpy(), g["cand"][0] @ g["user"][0], atol=SCORE_TOL)
+
+
+def test_g2_mind_golden(golden_dir):
+    g = load(golden_dir, "g2_mind.npz")
+    shape = synth.G2_MIND
+    params = synth.make_params(shape, seed=21)
+    batch = synth.make_batch(shape, seed=22, ragged=True)
+    model = make_model(shape, params)
+    scores, loss, grads = fwd_bwd(model, batch)
+    np.testing.assert_allclose(scores, g["scores"], rtol=0, atol=SCORE_TOL)
+    assert abs(loss - float(g["loss"])) < SCORE_TOL
+    emb = "news_encoder.word_embedding.0.weight"
+    for n in synth.param_names():
+        if n == emb:
+            np.testing.assert_allclose(grads[n][g["rows"]], g["grad_rows/" + n], rtol=GRAD_RTOL, atol=GRAD_ATOL)
+            np.testing.assert_allclose(grads[n].sum(axis=1), g["grad_rowsum/" + n], rtol=1e-3, atol=2e-5)
+        else:
+            np.testing.assert_allclose(grads[n], g["grad/" + n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+    # eval forward (no autograd) gives the same scores
+    model.eval()
+    with torch.no_grad():
+        s2 = model(tbatch(batch)).cpu().numpy()
+    np.testing.assert_allclose(s2, g["scores"], rtol=0, atol=SCORE_TOL)
+
+
+def test_train_mode_dropout_replayed_through_oracle():
+    """Dropout on: export the kernels' keep masks, replay them in the oracle, demand parity of
+    scores and every gradient.  Proves forward and backward use the same mask at both sites."""
+    from oracle import nrms_oracle as orc
+    shape = synth.Shape(n_words=500, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
+                        batch_size=6, history_len=9, n_candidates=4, n_words_title=12)
+    params = synth.make_params(shape, seed=5)
+    batch = synth.make_batch(shape, seed=6, ragged=True, min_title=2)
+    model = make_model(shape, params, dropout=0.2)
+    model.train()
+    scores, loss, grads = fwd_bwd(model, batch)
+    sv = model.engine._saved
+    n_titles = shape.batch_size * (shape.history_len + shape.n_candidates)
+    L, d = shape.n_words_title, shape.word_embed_size
+    keep = {}
+    for site, name in ((0, "embed"), (1, "ctx")):
+        k = model.engine.dropout_keep_mask(sv["seed"], site, n_titles * L, 0.2)
+        keep[name] = k.cpu().view(n_titles, L, d)
+    frac = float(keep["embed"].float().mean())
+    assert 0.77 < frac < 0.83, frac
+    assert not torch.equal(keep["embed"], keep["ctx"])
+    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads, p_drop=0.2, keep=keep)
+    np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
+    assert abs(loss - o_loss) < SCORE_TOL
+    for n in synth.param_names():
+        np.testing.assert_allclose(grads[n], o_grads[n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+    # a second step draws a different mask
+    s2, _, _ = fwd_bwd(model, batch)
+    assert np.abs(s2 - scores).max() > 1e-6
+
+
+def test_g5_fused_train_steps(golden_dir):
+    """Model.train_step (HIP fwd + CE + bwd + fused Adam) x3 against the reference model stepped
+    by torch.optim.Adam (fixture g5)."""
+    g = load(golden_dir, "g5_adam.npz")
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=51)
+    model = make_model(shape, params)
+    model.train()
+    model.config.learning_rate = 1e-3
+    losses = []
+    for t in range(3):
+        batch = synth.make_batch(shape, seed=52 + t, ragged=True, min_title=1)
+        ls = model.train_step(tbatch(batch))
+        losses.append(float(ls) / shape.batch_size)
+    np.testing.assert_allclose(losses, g["losses"], atol=SCORE_TOL)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for n in synth.param_names():
+        if n.endswith("W_K.bias"):       # analytically zero gradient: Adam amplifies rounding noise
+            assert np.abs(sd[n] - params[n]).max() <= 3.1e-3
+            continue
+        assert_params_close(sd[n], g["param/" + n], n)
+
+
+def test_autograd_path_with_torch_adam_matches_fused(golden_dir):
+    """The drop-in loop of train_eval.py:111-127 (model(batch) -> CE -> backward -> torch Adam)."""
+    g = load(golden_dir, "g5_adam.npz")
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=51)
+    model = make_model(shape, params)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    losses = []
+    for t in range(3):
+        batch = synth.make_batch(shape, seed=52 + t, ragged=True, min_title=1)
+        out = model(tbatch(batch))
+        model.zero_grad()
+        loss = crit(out, torch.zeros(len(out), dtype=torch.long, device=out.device))
+        losses.append(loss.item())
+        loss.backward()
+        opt.step()
+    np.testing.assert_allclose(losses, g["losses"], atol=SCORE_TOL)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for n in synth.param_names():
+        if n.endswith("W_K.bias"):
+            continue
+        assert_params_close(sd[n], g["param/" + n], n)
+
+
+@pytest.mark.parametrize("shape", [
+    synth.Shape(n_words=300, word_embed_size=64, num_attention_heads=2, query_vector_dim=64,
+                batch_size=5, history_len=33, n_candidates=2, n_words_title=33),     # S > 32, d_k = 32
+    synth.Shape(n_words=300, word_embed_size=300, num_attention_heads=6, query_vector_dim=200,
+                batch_size=3, history_len=64, n_candidates=3, n_words_title=20),     # v1 heads: d_k = 50, H = 64
+    synth.Shape(n_words=64, word_embed_size=8, num_attention_heads=2, query_vector_dim=4,
+                batch_size=1, history_len=1, n_candidates=1, n_words_title=1),       # minimum sizes
+    synth.Shape(n_words=1000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                batch_size=16, history_len=50, n_candidates=5, n_words_title=30),    # bench shape, small batch
+])
+def test_shape_sweep_against_oracle(shape):
+    from oracle import nrms_oracle as orc
+    params = synth.make_params(shape, seed=101)
+    batch = synth.make_batch(shape, seed=102, ragged=True, min_title=1, mask_some_candidates=shape.n_candidates > 1)
+    model = make_model(shape, params)
+    scores, loss, grads = fwd_bwd(model, batch)
+    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads)
+    np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
+    assert abs(loss - o_loss) < SCORE_TOL
+    for n in synth.param_names():
+        np.testing.assert_allclose(grads[n], o_grads[n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
