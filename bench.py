@@ -102,11 +102,12 @@ def main():
     ap.add_argument("--cpu-sample-users", type=int, default=64)
     args = ap.parse_args()
 
-    rank, local_rank, world = parallel.init_process_group()
+    rank, local_rank, world = parallel.init_process_group(os.environ.get("NRMS_DIST_BACKEND"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)   # identity on a full node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     shape = synth.BENCH
     B = args.users_per_gpu

@@ -31,7 +31,7 @@ def init_process_group(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -59,14 +59,25 @@ class GradAllReduce:
 
     def __call__(self, flat_grad: torch.Tensor):
         if self.world > 1:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if flat_grad.is_cuda and dist.get_backend(self.group) == "gloo":
+                # test rigs only (several ranks sharing one GPU): stage through the host
+                host = flat_grad.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                flat_grad.copy_(host)
+            else:
+                dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return flat_grad
 
 
 def broadcast_parameters(flat: torch.Tensor, src: int = 0):
     """Replicas start identical (rank `src`'s values)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(flat, src=src)
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            host = flat.cpu()
+            dist.broadcast(host, src=src)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=src)
     return flat
 
 

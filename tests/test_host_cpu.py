@@ -1,0 +1,162 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/nrms_hip.h declares
+(no compute call without a GPU), the flat parameter layout, the drop-in Model's names /
+state_dict / loud failure without a GPU, and the synthetic batch layout."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_news_recommender_amd import _lib, synth
+from pytorch_news_recommender_amd.config import Config
+from pytorch_news_recommender_amd.engine import FlatLayout, ModelDims
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "nrms_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nrms_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 12
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signatures and the header disagree"
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -m pytorch_news_recommender_amd.build"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    bound = _lib.load()
+    assert b"gfx950" in bound.nrms_version()
+    assert bound.nrms_last_error() is not None
+
+
+def test_struct_layouts_match_header():
+    # field order / widths of the POD structs (x86-64 SysV): desc = 8 x 4 bytes + u64
+    assert ctypes.sizeof(_lib.EncoderDesc) == 40
+    assert _lib.EncoderDesc.seed.offset == 32
+    assert ctypes.sizeof(_lib.EncoderWeights) == 48 and ctypes.sizeof(_lib.EncoderGrads) == 48
+    assert ctypes.sizeof(_lib.EncoderActs) == 32
+
+
+def test_argument_validation_without_gpu():
+    """Validation runs before any HIP call, so bad descriptors are reported on a CPU-only host."""
+    lib = _lib.load()
+    bad = _lib.EncoderDesc(n_seq=1, seq_len=65, d_model=300, n_heads=10, q_dim=200, vocab=0, p_drop=0.0,
+                           precision=0, seed=0)
+    assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"seq_len" in lib.nrms_last_error()
+    ok = _lib.EncoderDesc(n_seq=28160, seq_len=30, d_model=300, n_heads=10, q_dim=200, vocab=45800, p_drop=0.2,
+                          precision=0, seed=1)
+    need = lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(ok))
+    M = 28160 * 30
+    assert need >= 4 * (M * 300 + M * 900 + M)           # dctx + dqkv + ds at least
+    w = _lib.EncoderWeights()
+    acts = _lib.EncoderActs()
+    rc = lib.nrms_encoder_fwd(ctypes.byref(ok), ctypes.byref(w), None, None, ctypes.byref(acts), None, None)
+    assert rc == -1 and b"null" in lib.nrms_last_error()
+    odd = _lib.EncoderDesc(n_seq=1, seq_len=5, d_model=30, n_heads=10, q_dim=200, vocab=0, p_drop=0.0,
+                           precision=0, seed=0)
+    assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(odd)) == 0      # d_model % 4 != 0
+    with pytest.raises(_lib.NrmsError):
+        _lib.check(-1, "unit test")
+
+
+def test_flat_layout_adjacency_and_names():
+    dims = ModelDims(n_words=45800, word_embed_size=300, num_attention_heads=10, query_vector_dim=200)
+    lay = FlatLayout(dims)
+    assert lay.total == 14402600
+    assert list(lay.entries) == synth.param_names()
+    assert len(lay.entries) == 19
+    for off, shp, n in lay.entries.values():
+        assert off % 4 == 0 and n == int(np.prod(shp))
+    flat = torch.arange(lay.total, dtype=torch.float32)
+    v = lay.view(flat, "user_encoder.multihead_self_attention.W_K.weight")
+    assert v.shape == (300, 300) and v.data_ptr() == flat.data_ptr() + 4 * lay.entries[
+        "user_encoder.multihead_self_attention.W_K.weight"][0]
+
+
+def make_cfg(shape):
+    cfg = Config("nrms_hip")
+    cfg.__nrms__()
+    cfg.word_embed_size = shape.word_embed_size
+    cfg.num_attention_heads = shape.num_attention_heads
+    cfg.query_vector_dim = shape.query_vector_dim
+    return cfg
+
+
+def test_model_names_state_dict_and_loud_failure_on_cpu(tmp_path):
+    from pytorch_news_recommender_amd.model.nrms_hip import Model
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=3)
+    cfg = make_cfg(shape)
+    # the reference's own construction path: table from config.data_path + npz (nrms_v0.py:134-135)
+    np.savez(tmp_path / "all_word_embedding_v3.npz", embeddings=params["news_encoder.word_embedding.0.weight"])
+    cfg.data_path = str(tmp_path) + "/"
+    m = Model(cfg)
+    assert sorted(m.state_dict()) == sorted(synth.param_names())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    assert m._views_intact()
+    for n, p in m.named_parameters():
+        np.testing.assert_array_equal(p.detach().numpy(), params[n])
+    np.testing.assert_array_equal(m._layout.view(m._flat, "news_encoder.additive_attention.linear.bias").numpy(),
+                                  params["news_encoder.additive_attention.linear.bias"])
+    # module protocol used by train_eval.py: train/eval/parameters/zero_grad/state_dict
+    m.train(); m.eval(); m.zero_grad()
+    assert sum(p.numel() for p in m.parameters()) == m._layout.total
+    batch = {k: torch.from_numpy(v) for k, v in synth.make_batch(shape, seed=4).items()}
+    with pytest.raises(_lib.NrmsError, match="no CPU fallback"):
+        m(batch)                                          # never a silent CPU path
+    with pytest.raises(_lib.NrmsError):
+        m.get_news_vector(batch["browsed_titles"][0])
+
+
+def test_model_dispatch_wrapper():
+    import types
+    from pytorch_news_recommender_amd import model as model_pkg
+    shape = synth.G1_ODD
+    cfg = make_cfg(shape)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "all_word_embedding_v3.npz"),
+                 embeddings=synth.make_params(shape, seed=3)["news_encoder.word_embedding.0.weight"])
+        cfg.data_path = td + "/"
+        args = types.SimpleNamespace(model="NRMS_V0", n_GPUs=1)
+        w = model_pkg.Model(cfg, args)
+    assert sorted(w.state_dict()) == sorted("model." + n for n in synth.param_names())   # ckpt keys, SURVEY 5
+
+
+def test_config_fields_of_the_reference():
+    c = Config("x")
+    c.__nrms__()
+    for f in ("data_path", "word_embedding_pretrained", "word_embed_size", "num_attention_heads",
+              "title_heads_num", "query_vector_dim", "dropout", "history_len", "sample_size",
+              "max_candidate_size", "n_words_title", "batch_size", "learning_rate", "device", "eval_step",
+              "num_epochs", "save_path", "log_path", "warm_up", "warm_up_steps"):
+        assert hasattr(c, f), f
+    assert (c.n_words, c.word_embed_size, c.history_len, c.sample_size, c.dropout, c.learning_rate) == (
+        45800, 300, 50, 5, 0.2, 1e-3)
+    assert (c.query_vector_dim, c.num_attention_heads, c.title_heads_num) == (200, 10, 6)
+
+
+def test_synthetic_batch_layout():
+    shape = synth.G1_ODD
+    b = synth.make_batch(shape, seed=12, ragged=True, min_title=1, empty_history_user=True,
+                         all_pad_title=True, mask_some_candidates=True)
+    B, H, C, L = shape.batch_size, shape.history_len, shape.n_candidates, shape.n_words_title
+    assert b["browsed_titles"].shape == (B, H, L) and b["browsed_titles"].dtype == np.int64
+    assert b["candidate_titles"].shape == (B, C, L) and b["candidate_mask"].dtype == np.uint8
+    assert b["browsed_mask"].dtype == np.uint8
+    # left-aligned history, right-zero-padded titles (data_handler.py:206-215)
+    for u in range(B):
+        n = int(b["browsed_lens"][u])
+        assert not b["browsed_titles"][u, n:].any()
+        assert b["browsed_mask"][u, :n].all() and not b["browsed_mask"][u, n:].any()
+    t = b["candidate_titles"]
+    nz = t != 0
+    assert (np.diff(nz.astype(int), axis=-1) <= 0).all()          # once padded, stays padded
+    assert t.max() < shape.n_words
