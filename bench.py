@@ -43,8 +43,7 @@ def kernel_flops(shape, B):
     return {
         "qkv_proj_fwd": (qkv(Mn), qkv(Mu)),
         "dwqkv_bwd": (qkv(Mn), qkv(Mu)),
-        "dx_scatter_bwd": (qkv(Mn),),
-        "dx_bwd": (qkv(Mu),),
+        "dx_bwd": (qkv(Mn), qkv(Mu)),
         "addattn_fwd": (add(Mn), add(Mu)),
         "dctx_bwd": (add(Mn), add(Mu)),
         "dwadd_bwd": (add(Mn), add(Mu)),
@@ -165,7 +164,8 @@ def main():
             per_step_flop = sum(fl)
             kernels[name] = {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps,
                              "tflops": per_step_flop / (ms / args.steps * 1e-3) / 1e12}
-        for name in ("adam", "tn_reduce", "addattn_bwd_rows", "click", "ce_loss", "transpose", "colsum"):
+        for name in ("gather_dropout", "scatter_dropout", "adam", "tn_reduce", "addattn_bwd_rows", "click", "ce_loss",
+                     "transpose", "colsum"):
             ms, n = eng.timing_read(name)
             if n:
                 kernels[name] = {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps}

@@ -74,8 +74,10 @@ typedef struct nrms_encoder_grads {   /* same shapes as the weights; accumulated
 } nrms_encoder_grads;
 
 /* Activations the forward saves for the backward (caller-owned).  In eval only `qkv`,
- * `ctx` are required scratch; `t` and `w` may then be NULL. */
+ * `ctx` (and `x` for the news encoder) are required scratch; `t` and `w` may then be NULL. */
 typedef struct nrms_encoder_acts {
+    float* x;              /* [M, d]   news encoder only: gathered word embeddings AFTER dropout
+                                       (the user encoder's input is the caller's `x`); may be NULL if vocab==0 */
     float* qkv;            /* [M, 3d]  Q|K|V projections incl. bias */
     float* ctx;            /* [M, d]   head-concatenated attention output AFTER dropout */
     float* t;              /* [M, q]   tanh(linear(ctx))            (nrms_v0.py:108) */

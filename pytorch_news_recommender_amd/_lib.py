@@ -35,7 +35,7 @@ class EncoderGrads(C.Structure):
 
 
 class EncoderActs(C.Structure):
-    _fields_ = [("qkv", C.c_void_p), ("ctx", C.c_void_p), ("t", C.c_void_p), ("w", C.c_void_p)]
+    _fields_ = [("x", C.c_void_p), ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("t", C.c_void_p), ("w", C.c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/nrms_hip.h declares.

@@ -20,7 +20,8 @@ struct AttnArgs {
     const float* qkv;       // [M, 3d]
     float* ctx;             // fwd out [M, d]
     Dropout drop;           // fwd: site 1 on ctx
-    const float* dctx;      // bwd in  [M, d] (gradient w.r.t. the pre-dropout context)
+    const float* dctx;      // bwd in  [M, d] gradient w.r.t. the POST-dropout context; the mask (site 1,
+                            // same Philox counters as the forward) is applied while it is loaded
     float* dqkv;            // bwd out [M, 3d]
 };
 
@@ -44,6 +45,74 @@ __device__ __forceinline__ void stage_in(float* dst, int RS, const float* src, l
         }
     }
 }
+
+// same, for the context gradient: applies the context-dropout mask (site 1) of the forward while
+// loading, element index = base_elem + r*ld + c (ld = d for the [M, d] gradient)
+template <int ND>
+__device__ __forceinline__ void stage_in_drop(float* dst, int RS, const float* src, long ld, int S, int dk, int lane,
+                                              const Dropout& drop, uint64_t base_elem) {
+    constexpr int LPR = 16 * ND, RPI = 64 / LPR;
+    const int c2 = lane % LPR, rsub = lane / LPR;
+    if (2 * c2 < dk) {
+        for (int r = rsub; r < S; r += RPI) {
+            float2 v = *reinterpret_cast<const float2*>(src + r * ld + 2 * c2);
+            if (drop.thresh != 0u) {
+                uint32_t rnd[4];
+                const uint64_t e = base_elem + (uint64_t)r * ld + 2 * c2;
+                philox4x32_7(drop.seed, e >> 2, 1u, rnd);
+                const int q = (int)(e & 3);          // 0 or 2
+                v.x = (q == 0 ? rnd[0] : rnd[2]) >= drop.thresh ? v.x * drop.inv_keep : 0.f;
+                v.y = (q == 0 ? rnd[1] : rnd[3]) >= drop.thresh ? v.y * drop.inv_keep : 0.f;
+            }
+            *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = v;
+        }
+    }
+}
+
+// Register prefetch of one [S x d_k] operand of the NEXT unit (global -> VGPR), written to LDS
+// after the current unit's compute: keeps HBM requests in flight while the wave is on the MFMAs.
+template <int NS, int ND>
+struct Prefetch {
+    static constexpr int LPR = 16 * ND, RPI = 64 / LPR, IT = 32 * NS / RPI;
+    float2 v[IT];
+    __device__ __forceinline__ void load(const float* src, long ld, int S, int dk, int lane) {
+        const int c2 = lane % LPR, rsub = lane / LPR;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int r = rsub + it * RPI;
+            v[it] = (2 * c2 < dk && r < S) ? *reinterpret_cast<const float2*>(src + r * ld + 2 * c2) : float2{0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void store(float* dst, int RS, int S, int dk, int lane) const {
+        const int c2 = lane % LPR, rsub = lane / LPR;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int r = rsub + it * RPI;
+            if (2 * c2 < dk && r < S) *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = v[it];
+        }
+    }
+    // store through the context-dropout mask (site 1); element index = base_elem + r*ld + c
+    __device__ __forceinline__ void store_drop(float* dst, int RS, int S, int dk, int lane, long ld, const Dropout& drop,
+                                               uint64_t base_elem) const {
+        const int c2 = lane % LPR, rsub = lane / LPR;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int r = rsub + it * RPI;
+            if (2 * c2 < dk && r < S) {
+                float2 x = v[it];
+                if (drop.thresh != 0u) {
+                    uint32_t rnd[4];
+                    const uint64_t e = base_elem + (uint64_t)r * ld + 2 * c2;
+                    philox4x32_7(drop.seed, e >> 2, 1u, rnd);
+                    const int q = (int)(e & 3);
+                    x.x = (q == 0 ? rnd[0] : rnd[2]) >= drop.thresh ? x.x * drop.inv_keep : 0.f;
+                    x.y = (q == 0 ? rnd[1] : rnd[3]) >= drop.thresh ? x.y * drop.inv_keep : 0.f;
+                }
+                *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = x;
+            }
+        }
+    }
+};
 
 // S^T (or dP^T) tiles: out[jt][it] += sum_d A[j][d] B[i][d]
 template <int NS, int ND>
@@ -188,14 +257,30 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 
     const long total = (long)a.n_seq * a.h;
     const long ld = 3L * a.d;
-    for (long u = (long)blockIdx.x * WPB + wave; u < total; u += (long)gridDim.x * WPB) {
+    const long ustride = (long)gridDim.x * WPB;
+    Prefetch<NS, ND> pq, pk, pv;
+    long u = (long)blockIdx.x * WPB + wave;
+    if (u < total) {
+        const long seq = u / a.h;
+        const float* base = a.qkv + seq * a.S * ld + (int)(u - seq * a.h) * a.dk;
+        pq.load(base, ld, a.S, a.dk, lane);
+        pk.load(base + a.d, ld, a.S, a.dk, lane);
+        pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+    }
+    for (; u < total; u += ustride) {
         const long seq = u / a.h;
         const int head = (int)(u - seq * a.h);
-        const float* base = a.qkv + seq * a.S * ld + head * a.dk;
-        stage_in<ND>(Qs, RS, base, ld, a.S, a.dk, lane);
-        stage_in<ND>(Ks, RS, base + a.d, ld, a.S, a.dk, lane);
-        stage_in<ND>(Vs, RS, base + 2 * a.d, ld, a.S, a.dk, lane);
+        pq.store(Qs, RS, a.S, a.dk, lane);
+        pk.store(Ks, RS, a.S, a.dk, lane);
+        pv.store(Vs, RS, a.S, a.dk, lane);
         wave_sync();
+        if (u + ustride < total) {            // next unit's operands fly while this one computes
+            const long un = u + ustride, sn = un / a.h;
+            const float* base = a.qkv + sn * a.S * ld + (int)(un - sn * a.h) * a.dk;
+            pq.load(base, ld, a.S, a.dk, lane);
+            pk.load(base + a.d, ld, a.S, a.dk, lane);
+            pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+        }
 
         f32x16 st[NS][NS];
         abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
@@ -237,6 +322,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 // 32x32 transpose through a wave-private LDS image each.
 template <int NS, int ND, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
+    constexpr bool PF = NS == 1;      // prefetch across the compute only where registers allow
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1, WF = 4 * SP * RS + SP * TS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -251,15 +337,35 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
 
     const long total = (long)a.n_seq * a.h;
     const long ld = 3L * a.d;
-    for (long u = (long)blockIdx.x * WPB + wave; u < total; u += (long)gridDim.x * WPB) {
+    const long ustride = (long)gridDim.x * WPB;
+    Prefetch<NS, ND> pq, pk, pv, pg;
+    long u = (long)blockIdx.x * WPB + wave;
+    if (u < total) {
         const long seq = u / a.h;
         const int head = (int)(u - seq * a.h);
         const float* base = a.qkv + seq * a.S * ld + head * a.dk;
-        stage_in<ND>(Qs, RS, base, ld, a.S, a.dk, lane);
-        stage_in<ND>(Ks, RS, base + a.d, ld, a.S, a.dk, lane);
-        stage_in<ND>(Vs, RS, base + 2 * a.d, ld, a.S, a.dk, lane);
-        stage_in<ND>(Gs, RS, a.dctx + seq * a.S * a.d + head * a.dk, a.d, a.S, a.dk, lane);
+        pq.load(base, ld, a.S, a.dk, lane);
+        pk.load(base + a.d, ld, a.S, a.dk, lane);
+        pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+        pg.load(a.dctx + seq * a.S * a.d + head * a.dk, a.d, a.S, a.dk, lane);
+    }
+    for (; u < total; u += ustride) {
+        const long seq = u / a.h;
+        const int head = (int)(u - seq * a.h);
+        pq.store(Qs, RS, a.S, a.dk, lane);
+        pk.store(Ks, RS, a.S, a.dk, lane);
+        pv.store(Vs, RS, a.S, a.dk, lane);
+        pg.store_drop(Gs, RS, a.S, a.dk, lane, a.d, a.drop, (uint64_t)(seq * a.S * a.d + head * a.dk));
         wave_sync();
+        if (PF && u + ustride < total) {
+            const long un = u + ustride, sn = un / a.h;
+            const int hn = (int)(un - sn * a.h);
+            const float* base = a.qkv + sn * a.S * ld + hn * a.dk;
+            pq.load(base, ld, a.S, a.dk, lane);
+            pk.load(base + a.d, ld, a.S, a.dk, lane);
+            pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+            pg.load(a.dctx + sn * a.S * a.d + hn * a.dk, a.d, a.S, a.dk, lane);
+        }
 
         f32x16 st[NS][NS], dp[NS][NS];
         abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
@@ -316,6 +422,15 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
             }
         }
         wave_sync();
+        if (!PF && u + ustride < total) {     // big tiles: no registers to spare, load after the compute
+            const long un = u + ustride, sn = un / a.h;
+            const int hn = (int)(un - sn * a.h);
+            const float* base = a.qkv + sn * a.S * ld + hn * a.dk;
+            pq.load(base, ld, a.S, a.dk, lane);
+            pk.load(base + a.d, ld, a.S, a.dk, lane);
+            pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+            pg.load(a.dctx + sn * a.S * a.d + hn * a.dk, a.d, a.S, a.dk, lane);
+        }
     }
 }
 

@@ -123,11 +123,18 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     const int S = desc->seq_len, d = desc->d_model, q = desc->q_dim, M = desc->n_seq * S;
     const Dropout drop = make_dropout(desc->seed, desc->p_drop);
 
+    const float* xin = x;
+    if (gather) {
+        NRMS_REQUIRE(acts->x != nullptr, "encoder_fwd: acts.x (gathered embeddings) is required for the news encoder");
+        rc = launch_gather_dropout((long)M, d, ids, w->table, drop, acts->x, s);
+        if (rc) return rc;
+        xin = acts->x;
+    }
     NTArgs g{};
     g.M = M; g.N = 3 * d; g.K = d; g.rows_per_tile = NT_BM;
-    g.A = x; g.lda = d; g.ids = ids; g.table = w->table;
-    g.W = w->w_qkv; g.bias = w->b_qkv; g.C = acts->qkv; g.ldc = 3 * d; g.drop = drop;
-    rc = launch_gemm_nt(gather ? A_GATHER : A_PLAIN, E_STORE, g, s, "qkv_proj_fwd");
+    g.A = xin; g.lda = d;
+    g.W = w->w_qkv; g.bias = w->b_qkv; g.C = acts->qkv; g.ldc = 3 * d;
+    rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "qkv_proj_fwd");
     if (rc) return rc;
     rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, acts->ctx, drop, nullptr, nullptr, s);
     if (rc) return rc;
@@ -150,8 +157,8 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec,
                  "encoder_bwd: null gradient buffer");
     const bool gather = desc->vocab > 0;
-    NRMS_REQUIRE(gather ? (ids != nullptr && w->table != nullptr && grads->table != nullptr) : (x != nullptr && dx != nullptr),
-                 "encoder_bwd: %s missing", gather ? "ids/table/grads.table" : "x/dx");
+    NRMS_REQUIRE(gather ? (ids != nullptr && acts->x != nullptr && grads->table != nullptr) : (x != nullptr && dx != nullptr),
+                 "encoder_bwd: %s missing", gather ? "ids/acts.x/grads.table" : "x/dx");
     const BwdWorkspace L = bwd_layout(desc);
     if (workspace_bytes < L.total) {
         set_error("encoder_bwd: workspace %zu < required %zu bytes", workspace_bytes, L.total);
@@ -182,14 +189,14 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         g.M = M; g.N = d; g.K = q; g.rows_per_tile = NT_BM;
         g.ds = ds; g.qv = w->q_vec; g.T = acts->t;
         g.W = wadd_t; g.C = dctx; g.ldc = d;
-        g.wrow = acts->w; g.dout = dout; g.S = S; g.drop = drop;
+        g.wrow = acts->w; g.dout = dout; g.S = S;
         rc = launch_gemm_nt(A_DZ, E_DCTX, g, s, "dctx_bwd");
         if (rc) return rc;
     }
     // 3. d(w_add), d(b_add) = dZ^T [ctx | 1]
     {
         TNArgs t{};
-        t.M = M; t.N = q; t.K = d; t.amode = A_DZ; t.bmode = A_PLAIN;
+        t.M = M; t.N = q; t.K = d; t.amode = A_DZ;
         t.ds = ds; t.qv = w->q_vec; t.T = acts->t; t.B = acts->ctx; t.ldb = d;
         t.dW = grads->w_add; t.dbias = grads->b_add; t.partial = tn_partial;
         rc = launch_gemm_tn(t, s, "dwadd_bwd");
@@ -198,26 +205,29 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     // 4. attention backward
     rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, drop, dctx, dqkv, s);
     if (rc) return rc;
-    // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]
+    // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings)
+    const float* xin = gather ? acts->x : x;
     {
         TNArgs t{};
-        t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN; t.bmode = gather ? A_GATHER : A_PLAIN;
-        t.A = dqkv; t.lda = 3 * d; t.B = x; t.ldb = d; t.ids = ids; t.table = w->table; t.drop = drop;
+        t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN;
+        t.A = dqkv; t.lda = 3 * d; t.B = xin; t.ldb = d;
         t.dW = grads->w_qkv; t.dbias = grads->b_qkv; t.partial = tn_partial;
         rc = launch_gemm_tn(t, s, "dwqkv_bwd");
         if (rc) return rc;
     }
-    // 6. dX = dQKV Wqkv: plain store (user encoder) or scatter-add into the embedding gradient
+    // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: dX goes to the (now dead)
+    //    dctx buffer and is scatter-added through the embedding-dropout mask into the table gradient.
     rc = launch_transpose(w->w_qkv, wqkv_t, 3 * d, d, s);
     if (rc) return rc;
     {
         NTArgs g{};
         g.M = M; g.N = d; g.K = 3 * d; g.rows_per_tile = NT_BM;
-        g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t; g.ids = ids; g.drop = drop;
-        if (gather) { g.C = grads->table; g.ldc = d; }
-        else { g.C = dx; g.ldc = d; }
-        rc = launch_gemm_nt(A_PLAIN, gather ? E_SCATTER : E_STORE, g, s, gather ? "dx_scatter_bwd" : "dx_bwd");
+        g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t;
+        g.C = gather ? dctx : dx; g.ldc = d;
+        rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "dx_bwd");
+        if (rc) return rc;
     }
+    if (gather) rc = launch_scatter_dropout((long)M, d, ids, dctx, drop, grads->table, s);
     return rc;
 }
 
@@ -251,4 +261,4 @@ extern "C" int nrms_timing_read(const char* prefix, double* total_ms, int64_t* l
 }
 
 extern "C" const char* nrms_last_error(void) { return g_err; }
-extern "C" const char* nrms_version(void) { return "nrms_hip 0.1 (gfx950, fp32 MFMA)"; }
+extern "C" const char* nrms_version(void) { return "nrms_hip 0.2 (gfx950, fp32 MFMA)"; }

@@ -7,124 +7,142 @@
 //   TN form  dW[N,K] += A'[M,N]^T . B'[M,K]        (weight gradients; K gets an extra "ones"
 //                                                   column so column K of the result is the
 //                                                   bias gradient for free)
-// A' / B' are produced by loaders: plain rows, rows gathered from the embedding table by id
-// (+ dropout), or the additive-attention dZ = ds*q*(1-T^2) formed on the fly.
+// The GEMM waves carry NO gather / RNG work: measured on MI355X, VALU work inside an MFMA wave
+// comes straight out of MFMA time (the Philox-dropout gather loader ran the matrix pipe 58 %
+// busy against 75 % for a plain loader), so embedding gather+dropout and the dropout+scatter of
+// the embedding gradient are separate HBM-bound kernels (embed.hip).  The one fused transform
+// left is the additive-attention dZ = ds*q*(1-T^2) (three VALU ops per element).
 #pragma once
 #include "common.h"
 
 namespace nrms {
 
 constexpr int NT_BM = 128;            // rows per workgroup tile (4 waves x 32)
-constexpr int NT_BK = 32;             // K per LDS stage
-constexpr int NT_LS = NT_BK + 4;      // LDS row stride (floats), keeps float4 alignment
+constexpr int NT_BK = 16;             // K per LDS stage (one 64-byte row segment)
+constexpr int NT_STAGE_A = NT_BM * NT_BK;                 // floats per A stage
 
-enum { A_PLAIN = 0, A_GATHER = 1, A_DZ = 2 };
-enum { E_STORE = 0, E_DCTX = 1, E_SCATTER = 2 };
+enum { A_PLAIN = 0, A_DZ = 2 };
+enum { E_STORE = 0, E_DCTX = 1 };
 
 struct NTArgs {
     int M, N, K;
     int rows_per_tile;        // valid rows per workgroup tile (<= NT_BM)
     const float* A; int lda;  // A_PLAIN
-    const int64_t* ids;       // A_GATHER / E_SCATTER: row ids
-    const float* table;       // A_GATHER: [vocab, K]
     const float* ds;          // A_DZ: [M]
     const float* qv;          // A_DZ: [K]
     const float* T;           // A_DZ: [M, K]
     const float* W;           // [N, K]
     const float* bias;        // [N] or null
-    float* C; int ldc;        // output (E_STORE / E_DCTX) or dense table gradient (E_SCATTER, ldc = N)
+    float* C; int ldc;        // output
     const float* wrow;        // E_DCTX: [M] pooling weights
     const float* dout;        // E_DCTX: [n_seq, N]
     int S;                    // E_DCTX: rows per sequence
-    Dropout drop;             // A_GATHER: site 0 on A;  E_DCTX: site 1 on C;  E_SCATTER: site 0 on C
 };
 
+// LDS image of a K-stage: [rows][4 chunks of 16 B], the chunk index XOR-swizzled per 4-row group
+// so that the ds_read_b128 fragment reads (lane = 16*kq + row, one chunk each) hit 16 distinct
+// 16-byte slots in every hardware lane group {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...
+__device__ __forceinline__ int nt_swz(int row) { return (0x1230 >> (((row >> 2) & 3) * 4)) & 3; }
+
 // ---- NT main loop: acc[mt][nt] covers rows row0 + 32*wave + 16*mt + ..., cols col0 + 16*nt + ...
+// Software pipeline: global loads of stage s+1 are issued before the MFMAs of stage s and written
+// to the other LDS buffer after them; one barrier per stage.
+//   lds: 2 * (NT_BM + 16*NT) * NT_BK floats
 template <int NT, int AMODE>
 __device__ __forceinline__ void gemm_nt_mainloop(const NTArgs& a, int row0, int rows_valid, int col0,
-                                                 f32x4 (&acc)[2][NT], float* As, float* Bs) {
+                                                 f32x4 (&acc)[2][NT], float* lds) {
+    constexpr int STAGE = (NT_BM + 16 * NT) * NT_BK;     // floats per stage (A then B)
+    constexpr int B_F4 = NT * 16 * 4;                    // float4 per B stage
+    constexpr int B_IT = (B_F4 + 255) / 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
 
-    // each thread stages 4 float4 of A per K step: rows (tid>>3) + 32 i, column quad tid&7
-    const int c4 = tid & 7;
-    const float* arow[4];
-    float ascale[4];
-    long agrow[4];
+    // ---- staging assignment: A rows (tid>>2) and (tid>>2)+64, 16-byte chunk tid&3
+    const int chunk = tid & 3;
+    const float* arow[2];
+    float ascale[2];
+    int a_lds[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (tid >> 3) + 32 * i;
-        const bool ok = r < rows_valid;
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 2) + 64 * i;
         const long g = (long)row0 + r;
-        agrow[i] = g;
         arow[i] = nullptr;
         ascale[i] = 0.f;
-        if (ok) {
+        a_lds[i] = (r * 4 + (chunk ^ nt_swz(r))) * 4;
+        if (r < rows_valid) {
             if (AMODE == A_PLAIN) arow[i] = a.A + g * a.lda;
-            else if (AMODE == A_GATHER) arow[i] = a.table + a.ids[g] * (long)a.K;
             else { arow[i] = a.T + g * (long)a.K; ascale[i] = a.ds[g]; }
         }
     }
-    constexpr int B_F4 = NT * 16 * 8;                 // float4 per B stage
-    constexpr int B_IT = (B_F4 + 255) / 256;
-
-    for (int k0 = 0; k0 < a.K; k0 += NT_BK) {
-        const int k = k0 + c4 * 4;
-        const bool kok = k < a.K;
-        f32x4 av[4];
+    const float* brow[B_IT];
+    int b_lds[B_IT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 2;
+        const int n = col0 + r;
+        brow[i] = (idx < B_F4 && n < a.N) ? a.W + (long)n * a.K : nullptr;
+        b_lds[i] = idx < B_F4 ? NT_STAGE_A + (r * 4 + (chunk ^ nt_swz(r))) * 4 : -1;
+    }
+    // fragment read offsets (floats) inside a stage
+    const int fsw = kq ^ nt_swz(r16);
+    const int a_frag0 = ((32 * wave + r16) * 4 + fsw) * 4;
+    const int a_frag1 = ((32 * wave + 16 + r16) * 4 + fsw) * 4;
+    const int b_frag = NT_STAGE_A + (r16 * 4 + fsw) * 4;
+
+    f32x4 av[2], bv[B_IT];
+    auto load_stage = [&](int k0) {
+        const int k = k0 + chunk * 4;
+        const bool kok = k < a.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (arow[i] != nullptr && kok) {
                 v = *reinterpret_cast<const f32x4*>(arow[i] + k);
-                if (AMODE == A_GATHER) {
-                    if (a.drop.thresh != 0u) {
-                        const f32x4 s = dropout_scale4(a.drop.seed, 0u, (uint64_t)(agrow[i] * a.K + k) >> 2,
-                                                       a.drop.thresh, a.drop.inv_keep);
-                        v *= s;
-                    }
-                } else if (AMODE == A_DZ) {
+                if (AMODE == A_DZ) {
                     const f32x4 q = *reinterpret_cast<const f32x4*>(a.qv + k);
                     v = ascale[i] * q * (1.0f - v * v);
                 }
             }
             av[i] = v;
         }
-        f32x4 bv[B_IT];
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int idx = tid + 256 * i;
-            const int n = col0 + (idx >> 3);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < B_F4 && n < a.N && kok) v = *reinterpret_cast<const f32x4*>(a.W + (long)n * a.K + k);
+            if (brow[i] != nullptr && kok) v = *reinterpret_cast<const f32x4*>(brow[i] + k);
             bv[i] = v;
         }
-        __syncthreads();   // previous stage fully consumed
+    };
+    auto store_stage = [&](float* st) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(As + ((tid >> 3) + 32 * i) * NT_LS + c4 * 4) = av[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(st + a_lds[i]) = av[i];
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < B_F4) *reinterpret_cast<f32x4*>(Bs + (idx >> 3) * NT_LS + c4 * 4) = bv[i];
-        }
-        __syncthreads();
+        for (int i = 0; i < B_IT; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<f32x4*>(st + b_lds[i]) = bv[i];
+    };
+
+    const int n_stage = (a.K + NT_BK - 1) / NT_BK;
+    load_stage(0);
+    store_stage(lds);
+    __syncthreads();
+    for (int s = 0; s < n_stage; ++s) {
+        const float* cur = lds + (s & 1) * STAGE;
+        if (s + 1 < n_stage) load_stage((s + 1) * NT_BK);
+        // K permutation: lane quarter kq takes k = 4 kq + e for MFMA e (A and B agree)
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cur + a_frag0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(cur + a_frag1);
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            // K permutation: lane quarter kq takes k = 16 ss + 4 kq + e for MFMA e; A and B agree.
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + (32 * wave + r16) * NT_LS + 16 * ss + 4 * kq);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + (32 * wave + 16 + r16) * NT_LS + 16 * ss + 4 * kq);
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cur + b_frag + nt * 16 * NT_BK);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + (16 * nt + r16) * NT_LS + 16 * ss + 4 * kq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0][nt] = mfma16(a0[e], b[e], acc[0][nt]);
-                    acc[1][nt] = mfma16(a1[e], b[e], acc[1][nt]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                acc[0][nt] = mfma16(a0[e], b[e], acc[0][nt]);
+                acc[1][nt] = mfma16(a1[e], b[e], acc[1][nt]);
             }
         }
+        if (s + 1 < n_stage) store_stage(lds + ((s + 1) & 1) * STAGE);
+        __syncthreads();
     }
 }
 
@@ -134,15 +152,11 @@ int launch_gemm_nt(int amode, int emode, const NTArgs& a, hipStream_t stream, co
 struct TNArgs {
     int M, N, K;              // A' is [M,N]; B' is [M,K] (+ ones column at index K)
     int amode;                // A_PLAIN or A_DZ
-    int bmode;                // A_PLAIN or A_GATHER
     const float* A; int lda;  // A_PLAIN
     const float* ds;          // A_DZ: [M]
     const float* qv;          // A_DZ: [N]
     const float* T;           // A_DZ: [M, N]
-    const float* B; int ldb;  // plain B
-    const int64_t* ids;       // gather B
-    const float* table;       // [vocab, K]
-    Dropout drop;             // site 0 on gathered B
+    const float* B; int ldb;  // [M, K]
     float* dW;                // [N, K] accumulated
     float* dbias;             // [N]    accumulated
     float* partial;           // workspace: [splits][n_pad][k_pad]
@@ -153,5 +167,11 @@ size_t gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int launch_gemm_tn(const TNArgs& a, hipStream_t stream, const char* name);
 
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t stream);
+
+// embed.hip
+int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,
+                          hipStream_t stream);
+int launch_scatter_dropout(long M, int d, const int64_t* ids, const float* dx, const Dropout& drop, float* dtable,
+                           hipStream_t stream);
 
 }  // namespace nrms

@@ -8,12 +8,18 @@ namespace nrms {
 // =======================================================================================
 template <int NT, int AMODE, int EMODE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LS];
-    __shared__ __attribute__((aligned(16))) float Bs[NT * 16 * NT_LS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (NT_BM + 16 * NT) * NT_BK];
 
-    const int row0 = blockIdx.x * a.rows_per_tile;
+    // 1-D grid, XCD-aware: blocks b, b+8, ... share an XCD (round-robin dispatch); the column
+    // tiles of one row tile run back to back there, so the A rows they all stream are fetched
+    // into that L2 once (speed only, never correctness).
+    const int n_ct = (a.N + NT * 16 - 1) / (NT * 16);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int rt = (j / n_ct) * 8 + xcd;
+    const int row0 = rt * a.rows_per_tile;
+    if (row0 >= a.M) return;
     const int rows_valid = min(a.rows_per_tile, a.M - row0);
-    const int col0 = blockIdx.y * (NT * 16);
+    const int col0 = (j % n_ct) * (NT * 16);
 
     f32x4 acc[2][NT];
 #pragma unroll
@@ -21,7 +27,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gemm_nt_mainloop<NT, AMODE>(a, row0, rows_valid, col0, acc, As, Bs);
+    gemm_nt_mainloop<NT, AMODE>(a, row0, rows_valid, col0, acc, lds);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -32,13 +38,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
             const int rl = 32 * wave + 16 * mt + 4 * kq + reg;
             if (rl >= rows_valid) continue;
             const long g = (long)row0 + rl;
-            long dst_row = g;
             float wr = 0.f;
             const float* dout_row = nullptr;
-            if (EMODE == E_SCATTER) {
-                dst_row = a.ids[g];
-                if (dst_row == 0) continue;          // padding_idx = 0: no gradient to the pad row
-            }
             if (EMODE == E_DCTX) {
                 wr = a.wrow[g];
                 dout_row = a.dout + (g / a.S) * (long)a.N;
@@ -50,17 +51,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
                 float v = acc[mt][nt][reg];
                 if (EMODE == E_STORE) {
                     if (a.bias != nullptr) v += a.bias[n];
-                    a.C[dst_row * a.ldc + n] = v;
-                } else if (EMODE == E_DCTX) {
+                } else {
                     v += wr * dout_row[n];
-                    if (a.drop.thresh != 0u)
-                        v *= dropout_scale1(a.drop.seed, 1u, (uint64_t)(g * a.N + n), a.drop.thresh, a.drop.inv_keep);
-                    a.C[g * a.ldc + n] = v;
-                } else {  // E_SCATTER
-                    if (a.drop.thresh != 0u)
-                        v *= dropout_scale1(a.drop.seed, 0u, (uint64_t)(g * a.N + n), a.drop.thresh, a.drop.inv_keep);
-                    atomicAdd(a.C + dst_row * a.ldc + n, v);
                 }
+                a.C[g * a.ldc + n] = v;
             }
         }
     }
@@ -68,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
 
 template <int NT, int AMODE, int EMODE>
 static int launch_nt_inst(const NTArgs& a, hipStream_t stream, const char* name) {
-    dim3 grid(cdiv(a.M, a.rows_per_tile), cdiv(a.N, NT * 16));
+    dim3 grid(cdiv(cdiv(a.M, a.rows_per_tile), 8) * 8 * cdiv(a.N, NT * 16));
     TimingScope ts(name, stream);
     hipLaunchKernelGGL((gemm_nt_kernel<NT, AMODE, EMODE>), grid, dim3(256), 0, stream, a);
     return check_launch(name);
@@ -101,9 +95,7 @@ static int launch_nt_mode(const NTArgs& a, hipStream_t stream, const char* name)
 int launch_gemm_nt(int amode, int emode, const NTArgs& a, hipStream_t stream, const char* name) {
     if (a.M <= 0) return NRMS_OK;
     if ((a.K & 3) != 0) { set_error("%s: K=%d must be a multiple of 4", name, a.K); return NRMS_EINVAL; }
-    if (amode == A_GATHER && emode == E_STORE) return launch_nt_mode<A_GATHER, E_STORE>(a, stream, name);
     if (amode == A_PLAIN && emode == E_STORE) return launch_nt_mode<A_PLAIN, E_STORE>(a, stream, name);
-    if (amode == A_PLAIN && emode == E_SCATTER) return launch_nt_mode<A_PLAIN, E_SCATTER>(a, stream, name);
     if (amode == A_DZ && emode == E_DCTX) return launch_nt_mode<A_DZ, E_DCTX>(a, stream, name);
     set_error("%s: unsupported gemm_nt mode %d/%d", name, amode, emode);
     return NRMS_EINVAL;
@@ -112,11 +104,22 @@ int launch_gemm_nt(int amode, int emode, const NTArgs& a, hipStream_t stream, co
 // =======================================================================================
 // TN: dW[N,K(+1)] = sum_m A'[m,N]^T B'[m,K(+ones)] -- split over M, partial slabs + reduce
 // =======================================================================================
-constexpr int TN_NTN = 10;                  // max 16-col tiles per wave along N  (2 waves)
-constexpr int TN_NTK = 5;                   // max 16-col tiles per wave along K  (2 waves)
+// Workgroup = 8 waves (4 along N x 2 along K), each wave <= 5x5 tiles of 16x16 (100 accumulator
+// registers), so a workgroup owns up to 320 x 160 of the output and walks its slice of M in stages
+// of 32 rows.  Software pipeline as in the NT loop: the global loads of stage s+1 are issued
+// before the MFMAs of stage s and written to the other LDS buffer after them; one barrier per stage.
+constexpr int TN_WN = 4, TN_WK = 2;         // wave grid
+constexpr int TN_NTN = 5;                   // max 16-col tiles per wave along N
+constexpr int TN_NTK = 5;                   // max 16-col tiles per wave along K
 constexpr int TN_MC = 32;                   // rows of M per LDS stage
-constexpr int TN_SA = 2 * TN_NTN * 16 + 4;  // 324: stride % 8 == 4 -> conflict-free b32 column reads
-constexpr int TN_SB = 2 * TN_NTK * 16 + 4;  // 164
+constexpr int TN_AW = TN_WN * TN_NTN * 16;  // 320 staged A' columns (max)
+constexpr int TN_BW = TN_WK * TN_NTK * 16;  // 160 staged B' columns (max)
+constexpr int TN_SA = TN_AW + 4;            // 324: stride % 8 == 4 -> conflict-free b32 column reads
+constexpr int TN_SB = TN_BW + 4;            // 164
+constexpr int TN_STAGE = TN_MC * (TN_SA + TN_SB);          // floats per stage
+constexpr int TN_THREADS = 64 * TN_WN * TN_WK;             // 512
+constexpr int TN_A_IT = (TN_MC * TN_AW / 4) / TN_THREADS;  // 5 float4 per thread
+constexpr int TN_B_IT = (TN_MC * TN_BW / 4 + TN_THREADS - 1) / TN_THREADS;   // 3 (last half-used)
 
 struct TNGeom {
     int n_tiles, k_tiles;     // 16-wide tiles of the padded output
@@ -128,51 +131,70 @@ static TNGeom tn_geom(int N, int K) {
     TNGeom g;
     g.n_tiles = cdiv(N, 16);
     g.k_tiles = cdiv(K + 1, 16);            // + ones column
-    g.n_wg = cdiv(g.n_tiles, 2 * TN_NTN);
-    g.k_wg = cdiv(g.k_tiles, 2 * TN_NTK);
+    g.n_wg = cdiv(g.n_tiles, TN_WN * TN_NTN);
+    g.k_wg = cdiv(g.k_tiles, TN_WK * TN_NTK);
+    // an XCD has 32 CUs and runs whole M-slices (all output tiles of a slice): make the number of
+    // output tiles a divisor of 32 so a single round fills every CU
+    while (g.n_wg * g.k_wg < 32 && (32 % (g.n_wg * g.k_wg)) != 0 && g.n_wg < g.n_tiles) ++g.n_wg;
     g.n_tpw = cdiv(g.n_tiles, g.n_wg);
     g.k_tpw = cdiv(g.k_tiles, g.k_wg);
     return g;
 }
 
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs a, TNGeom g) {
-    __shared__ __attribute__((aligned(16))) float As[TN_MC * TN_SA];
-    __shared__ __attribute__((aligned(16))) float Bs[TN_MC * TN_SB];
+template <int AMODE>
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
 
-    const int nt0 = blockIdx.x * g.n_tpw;                       // first n tile of this WG
-    const int nt_cnt = min(g.n_tpw, g.n_tiles - nt0);
-    const int kt0 = blockIdx.y * g.k_tpw;
-    const int kt_cnt = min(g.k_tpw, g.k_tiles - kt0);
-    const int n_half = (nt_cnt + 1) >> 1, k_half = (kt_cnt + 1) >> 1;
-    const int my_nt0 = wn * n_half, my_ntn = wn == 0 ? n_half : nt_cnt - n_half;
-    const int my_kt0 = wk * k_half, my_ktn = wk == 0 ? k_half : kt_cnt - k_half;
+    // XCD-aware decomposition of the 1-D grid: blocks b and b+8 share an XCD, so give every XCD
+    // whole M-slices: the n_wg*k_wg output-tile workgroups that stream the SAME rows of A' and B'
+    // sit on one L2 (speed only, not correctness).
+    const int out_wgs = g.n_wg * g.k_wg;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % out_wgs;
+    const int split = (j / out_wgs) * 8 + xcd;
+    if (split >= a.splits) return;
+    const int bx = tile % g.n_wg, by = tile / g.n_wg;
+    const int nt0 = bx * g.n_tpw;                               // first n tile of this WG
+    const int nt_cnt = max(0, min(g.n_tpw, g.n_tiles - nt0));
+    const int kt0 = by * g.k_tpw;
+    const int kt_cnt = max(0, min(g.k_tpw, g.k_tiles - kt0));
+    const int n_q = (nt_cnt + TN_WN - 1) / TN_WN, k_h = (kt_cnt + TN_WK - 1) / TN_WK;
+    const int my_nt0 = wn * n_q, my_ntn = max(0, min(n_q, nt_cnt - my_nt0));
+    const int my_kt0 = wk * k_h, my_ktn = max(0, min(k_h, kt_cnt - my_kt0));
 
     const int n_cols = nt_cnt * 16, k_cols = kt_cnt * 16;       // staged widths
     const int ncol0 = nt0 * 16, kcol0 = kt0 * 16;
-    const int m_begin = blockIdx.z * a.rows_per_split;
+    const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
 
-    f32x4 acc[TN_NTN][TN_NTK];
+    // ---- fixed staging slots of this thread
+    int a_r[TN_A_IT], a_c[TN_A_IT], b_r[TN_B_IT], b_c[TN_B_IT];
 #pragma unroll
-    for (int i = 0; i < TN_NTN; ++i)
+    for (int i = 0; i < TN_A_IT; ++i) {
+        const int sl = tid + TN_THREADS * i;
+        a_r[i] = sl / (TN_AW / 4);
+        a_c[i] = (sl - a_r[i] * (TN_AW / 4)) * 4;
+    }
 #pragma unroll
-        for (int j = 0; j < TN_NTK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TN_B_IT; ++i) {
+        const int sl = tid + TN_THREADS * i;
+        b_r[i] = sl / (TN_BW / 4);
+        b_c[i] = (sl - b_r[i] * (TN_BW / 4)) * 4;
+        if (b_r[i] >= TN_MC) { b_r[i] = 0; b_c[i] = TN_BW; }     // unused slot
+    }
 
-    const int a_f4_per_row = n_cols >> 2, b_f4_per_row = k_cols >> 2;
-    for (int m0 = m_begin; m0 < m_end; m0 += TN_MC) {
-        __syncthreads();
-        // ---- stage A' chunk [32][n_cols]
-        for (int idx = tid; idx < TN_MC * a_f4_per_row; idx += 256) {
-            const int r = idx / a_f4_per_row, c = (idx - r * a_f4_per_row) * 4;
-            const long m = (long)m0 + r;
-            const int n = ncol0 + c;
+    f32x4 av[TN_A_IT], bv[TN_B_IT];
+    auto load_stage = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < TN_A_IT; ++i) {
+            const long m = (long)m0 + a_r[i];
+            const int n = ncol0 + a_c[i];
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && n < a.N) {
+            if (m < m_end && a_c[i] < n_cols && n < a.N) {
                 if (AMODE == A_PLAIN) {
                     v = *reinterpret_cast<const f32x4*>(a.A + m * a.lda + n);
                 } else {
@@ -181,32 +203,46 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs a, TNGeom g) {
                     v = a.ds[m] * q * (1.0f - t * t);
                 }
             }
-            *reinterpret_cast<f32x4*>(As + r * TN_SA + c) = v;
+            av[i] = v;
         }
-        // ---- stage B' chunk [32][k_cols] (column K = 1.0 -> bias gradient)
-        for (int idx = tid; idx < TN_MC * b_f4_per_row; idx += 256) {
-            const int r = idx / b_f4_per_row, c = (idx - r * b_f4_per_row) * 4;
-            const long m = (long)m0 + r;
-            const int k = kcol0 + c;
+#pragma unroll
+        for (int i = 0; i < TN_B_IT; ++i) {
+            const long m = (long)m0 + b_r[i];
+            const int k = kcol0 + b_c[i];
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end) {
-                if (k < a.K) {
-                    if (BMODE == A_PLAIN) {
-                        v = *reinterpret_cast<const f32x4*>(a.B + m * a.ldb + k);
-                    } else {
-                        v = *reinterpret_cast<const f32x4*>(a.table + a.ids[m] * (long)a.K + k);
-                        if (a.drop.thresh != 0u)
-                            v *= dropout_scale4(a.drop.seed, 0u, (uint64_t)(m * a.K + k) >> 2, a.drop.thresh,
-                                                a.drop.inv_keep);
-                    }
-                } else if (k == a.K) {
-                    v[0] = 1.0f;
-                }
+            if (m < m_end && b_c[i] < k_cols) {
+                if (k < a.K) v = *reinterpret_cast<const f32x4*>(a.B + m * a.ldb + k);
+                else if (k == a.K) v[0] = 1.0f;                    // ones column -> bias gradient
             }
-            *reinterpret_cast<f32x4*>(Bs + r * TN_SB + c) = v;
+            bv[i] = v;
         }
-        __syncthreads();
-        // ---- 32 rows of M = 2 sub-chunks x 4 MFMA k-steps (m = 16 sub + 4 kq + e)
+    };
+    auto store_stage = [&](float* st) {
+#pragma unroll
+        for (int i = 0; i < TN_A_IT; ++i)
+            *reinterpret_cast<f32x4*>(st + a_r[i] * TN_SA + a_c[i]) = av[i];
+#pragma unroll
+        for (int i = 0; i < TN_B_IT; ++i)
+            if (b_c[i] < TN_BW) *reinterpret_cast<f32x4*>(st + TN_MC * TN_SA + b_r[i] * TN_SB + b_c[i]) = bv[i];
+    };
+
+    f32x4 acc[TN_NTN][TN_NTK];
+#pragma unroll
+    for (int i = 0; i < TN_NTN; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN_NTK; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int n_stage = (m_end - m_begin + TN_MC - 1) / TN_MC;
+    if (n_stage > 0) {
+        load_stage(m_begin);
+        store_stage(lds);
+    }
+    __syncthreads();
+    for (int s = 0; s < n_stage; ++s) {
+        const float* As = lds + (s & 1) * TN_STAGE;
+        const float* Bs = As + TN_MC * TN_SA;
+        if (s + 1 < n_stage) load_stage(m_begin + (s + 1) * TN_MC);
+        // 32 rows of M = 2 sub-chunks x 4 MFMA k-steps (m = 16 sub + 4 kq + e)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -214,34 +250,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs a, TNGeom g) {
                 const int mrow = 16 * sub + 4 * kq + e;
                 float bf[TN_NTK];
 #pragma unroll
-                for (int j = 0; j < TN_NTK; ++j)
-                    bf[j] = j < my_ktn ? Bs[mrow * TN_SB + (my_kt0 + j) * 16 + r16] : 0.f;
+                for (int jj = 0; jj < TN_NTK; ++jj)
+                    bf[jj] = jj < my_ktn ? Bs[mrow * TN_SB + (my_kt0 + jj) * 16 + r16] : 0.f;
 #pragma unroll
                 for (int i = 0; i < TN_NTN; ++i) {
                     if (i < my_ntn) {
                         const float af = As[mrow * TN_SA + (my_nt0 + i) * 16 + r16];
 #pragma unroll
-                        for (int j = 0; j < TN_NTK; ++j)
-                            if (j < my_ktn) acc[i][j] = mfma16(af, bf[j], acc[i][j]);
+                        for (int jj = 0; jj < TN_NTK; ++jj)
+                            if (jj < my_ktn) acc[i][jj] = mfma16(af, bf[jj], acc[i][jj]);
                     }
                 }
             }
         }
+        if (s + 1 < n_stage) store_stage(lds + ((s + 1) & 1) * TN_STAGE);
+        __syncthreads();
     }
     // ---- partial slab: [split][n_pad][k_pad]
     const long n_pad = (long)g.n_tiles * 16, k_pad = (long)g.k_tiles * 16;
-    float* slab = a.partial + (long)blockIdx.z * n_pad * k_pad;
+    float* slab = a.partial + (long)split * n_pad * k_pad;
 #pragma unroll
     for (int i = 0; i < TN_NTN; ++i) {
         if (i >= my_ntn) continue;
 #pragma unroll
-        for (int j = 0; j < TN_NTK; ++j) {
-            if (j >= my_ktn) continue;
+        for (int jj = 0; jj < TN_NTK; ++jj) {
+            if (jj >= my_ktn) continue;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const long n = ncol0 + (my_nt0 + i) * 16 + 4 * kq + reg;
-                const long k = kcol0 + (my_kt0 + j) * 16 + r16;
-                slab[n * k_pad + k] = acc[i][j][reg];
+                const long k = kcol0 + (my_kt0 + jj) * 16 + r16;
+                slab[n * k_pad + k] = acc[i][jj][reg];
             }
         }
     }
@@ -260,9 +298,10 @@ __global__ void tn_reduce_kernel(const float* partial, int splits, int N, int K,
 }
 
 static int tn_splits(int M, const TNGeom& g) {
+    // one 8-wave workgroup per CU, one round: each of the 8 XCDs (32 CUs) runs 32/out_wgs slices
     const int out_wgs = g.n_wg * g.k_wg;
-    int splits = cdiv(768, out_wgs);                 // ~3 workgroups per CU in flight
-    const int max_splits = cdiv(M, 4 * TN_MC);       // at least 128 rows per split
+    int splits = 8 * (out_wgs <= 32 ? 32 / out_wgs : 1);
+    const int max_splits = cdiv(M, 8 * TN_MC);       // at least 256 rows per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     return splits;
@@ -283,16 +322,17 @@ int launch_gemm_tn(const TNArgs& a_in, hipStream_t stream, const char* name) {
     a.splits = tn_splits(a.M, g);
     a.rows_per_split = cdiv(cdiv(a.M, a.splits), TN_MC) * TN_MC;
     a.splits = cdiv(a.M, a.rows_per_split);
-    dim3 grid(g.n_wg, g.k_wg, a.splits);
+    dim3 grid(cdiv(a.splits, 8) * 8 * g.n_wg * g.k_wg);
+    constexpr size_t lds_bytes = 2 * TN_STAGE * sizeof(float);
     {
+        const void* fn = a.amode == A_PLAIN ? (const void*)gemm_tn_kernel<A_PLAIN> : (const void*)gemm_tn_kernel<A_DZ>;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
         TimingScope ts(name, stream);
-        if (a.amode == A_PLAIN && a.bmode == A_PLAIN)
-            hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN, A_PLAIN>), grid, dim3(256), 0, stream, a, g);
-        else if (a.amode == A_PLAIN && a.bmode == A_GATHER)
-            hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN, A_GATHER>), grid, dim3(256), 0, stream, a, g);
-        else if (a.amode == A_DZ && a.bmode == A_PLAIN)
-            hipLaunchKernelGGL((gemm_tn_kernel<A_DZ, A_PLAIN>), grid, dim3(256), 0, stream, a, g);
-        else { set_error("%s: unsupported gemm_tn mode", name); return NRMS_EINVAL; }
+        if (a.amode == A_PLAIN)
+            hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN>), grid, dim3(TN_THREADS), lds_bytes, stream, a, g);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<A_DZ>), grid, dim3(TN_THREADS), lds_bytes, stream, a, g);
         int rc = check_launch(name);
         if (rc) return rc;
     }

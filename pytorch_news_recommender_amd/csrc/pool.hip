@@ -21,8 +21,7 @@ struct AddFwdArgs {
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LS];
-    __shared__ __attribute__((aligned(16))) float Bs[NT * 16 * NT_LS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (NT_BM + 16 * NT) * NT_BK];
     __shared__ float sc[NT_BM];
 
     const NTArgs& g = a.g;
@@ -33,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_nt_mainloop<NT, A_PLAIN>(g, row0, rows_valid, 0, acc, As, Bs);
+    gemm_nt_mainloop<NT, A_PLAIN>(g, row0, rows_valid, 0, acc, lds);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;

@@ -127,13 +127,14 @@ class NRMSEngine:
                                  w_add=base + 4 * b["w_add"], b_add=base + 4 * b["b_add"],
                                  q_vec=base + 4 * b["q_vec"])
 
-    def _acts(self, tag, M, need_bwd):
+    def _acts(self, tag, M, need_bwd, gather=False):
         d, q = self.dims.word_embed_size, self.dims.query_vector_dim
+        x = self._buf(tag + ".x", M * d) if gather else None
         qkv = self._buf(tag + ".qkv", M * 3 * d)
         ctx = self._buf(tag + ".ctx", M * d)
         t = self._buf(tag + ".t", M * q) if need_bwd else None
         w = self._buf(tag + ".w", M) if need_bwd else None
-        acts = _lib.EncoderActs(qkv=qkv.data_ptr(), ctx=ctx.data_ptr(),
+        acts = _lib.EncoderActs(x=None if x is None else x.data_ptr(), qkv=qkv.data_ptr(), ctx=ctx.data_ptr(),
                                 t=None if t is None else t.data_ptr(), w=None if w is None else w.data_ptr())
         return acts
 
@@ -151,7 +152,7 @@ class NRMSEngine:
         for s0 in range(0, N, max(step, 1)):
             n = min(step, N - s0)
             desc = self._desc(n, L, self.dims.n_words, p_drop, seed)
-            acts = self._acts(tag, n * L, save)
+            acts = self._acts(tag, n * L, save, gather=True)
             rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), C.c_void_p(ids[s0:].data_ptr()), None,
                                            C.byref(acts), C.c_void_p(out[s0:].data_ptr()), _stream())
             _lib.check(rc, "nrms_encoder_fwd(news)")
@@ -249,7 +250,7 @@ class NRMSEngine:
                                        C.c_size_t(ws.numel() * 4), _stream())
         _lib.check(rc, "nrms_encoder_bwd(user)")
         wn, gn = self._weights(flat, "news_encoder"), self._grads(gflat, "news_encoder")
-        acts_n = self._acts("news", N * L, True)
+        acts_n = self._acts("news", N * L, True, gather=True)
         rc = self.lib.nrms_encoder_bwd(C.byref(desc_n), C.byref(wn), _lib.ptr(sv["ids"]), None, C.byref(acts_n),
                                        _lib.ptr(dnv), C.byref(gn), None, _lib.ptr(ws),
                                        C.c_size_t(ws.numel() * 4), _stream())

@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.EncoderDesc) == 40
     assert _lib.EncoderDesc.seed.offset == 32
     assert ctypes.sizeof(_lib.EncoderWeights) == 48 and ctypes.sizeof(_lib.EncoderGrads) == 48
-    assert ctypes.sizeof(_lib.EncoderActs) == 32
+    assert ctypes.sizeof(_lib.EncoderActs) == 40
 
 
 def test_argument_validation_without_gpu():
