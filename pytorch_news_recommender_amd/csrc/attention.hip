@@ -247,7 +247,7 @@ template <int NS, int ND, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, WF = 3 * SP * RS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
     float* Qs = lds + wave * WF;
     float* Ks = Qs + SP * RS;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
     constexpr bool PF = NS == 1;      // prefetch across the compute only where registers allow
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1, WF = 4 * SP * RS + SP * TS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
     float* Qs = lds + wave * WF;
     float* Ks = Qs + SP * RS;

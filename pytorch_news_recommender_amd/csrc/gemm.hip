@@ -141,11 +141,16 @@ static TNGeom tn_geom(int N, int K) {
     return g;
 }
 
-template <int AMODE>
+// NTN x NTK = 16x16 tiles per wave, compile-time: every wave issues the same unconditional MFMA
+// block (tiles past the matrix edge multiply zero-filled LDS columns and are not stored), so the
+// loop body is branch-free -- a VGPR-derived "wave < n" guard makes hipcc wrap each MFMA in an
+// exec-mask save/restore + s_waitcnt lgkmcnt(0).
+template <int AMODE, int NTN, int NTK>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;
 
@@ -226,11 +231,11 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
             if (b_c[i] < TN_BW) *reinterpret_cast<f32x4*>(st + TN_MC * TN_SA + b_r[i] * TN_SB + b_c[i]) = bv[i];
     };
 
-    f32x4 acc[TN_NTN][TN_NTK];
+    f32x4 acc[NTN][NTK];
 #pragma unroll
-    for (int i = 0; i < TN_NTN; ++i)
+    for (int i = 0; i < NTN; ++i)
 #pragma unroll
-        for (int jj = 0; jj < TN_NTK; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jj = 0; jj < NTK; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int n_stage = (m_end - m_begin + TN_MC - 1) / TN_MC;
     if (n_stage > 0) {
@@ -248,19 +253,15 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int mrow = 16 * sub + 4 * kq + e;
-                float bf[TN_NTK];
+                float bf[NTK], af[NTN];
 #pragma unroll
-                for (int jj = 0; jj < TN_NTK; ++jj)
-                    bf[jj] = jj < my_ktn ? Bs[mrow * TN_SB + (my_kt0 + jj) * 16 + r16] : 0.f;
+                for (int jj = 0; jj < NTK; ++jj) bf[jj] = Bs[mrow * TN_SB + (my_kt0 + jj) * 16 + r16];
 #pragma unroll
-                for (int i = 0; i < TN_NTN; ++i) {
-                    if (i < my_ntn) {
-                        const float af = As[mrow * TN_SA + (my_nt0 + i) * 16 + r16];
+                for (int i = 0; i < NTN; ++i) af[i] = As[mrow * TN_SA + (my_nt0 + i) * 16 + r16];
 #pragma unroll
-                        for (int jj = 0; jj < TN_NTK; ++jj)
-                            if (jj < my_ktn) acc[i][jj] = mfma16(af, bf[jj], acc[i][jj]);
-                    }
-                }
+                for (int i = 0; i < NTN; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NTK; ++jj) acc[i][jj] = mfma16(af[i], bf[jj], acc[i][jj]);
             }
         }
         if (s + 1 < n_stage) store_stage(lds + ((s + 1) & 1) * TN_STAGE);
@@ -270,10 +271,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
     const long n_pad = (long)g.n_tiles * 16, k_pad = (long)g.k_tiles * 16;
     float* slab = a.partial + (long)split * n_pad * k_pad;
 #pragma unroll
-    for (int i = 0; i < TN_NTN; ++i) {
+    for (int i = 0; i < NTN; ++i) {
         if (i >= my_ntn) continue;
 #pragma unroll
-        for (int jj = 0; jj < TN_NTK; ++jj) {
+        for (int jj = 0; jj < NTK; ++jj) {
             if (jj >= my_ktn) continue;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
@@ -324,18 +325,28 @@ int launch_gemm_tn(const TNArgs& a_in, hipStream_t stream, const char* name) {
     a.splits = cdiv(a.M, a.rows_per_split);
     dim3 grid(cdiv(a.splits, 8) * 8 * g.n_wg * g.k_wg);
     constexpr size_t lds_bytes = 2 * TN_STAGE * sizeof(float);
-    {
-        const void* fn = a.amode == A_PLAIN ? (const void*)gemm_tn_kernel<A_PLAIN> : (const void*)gemm_tn_kernel<A_DZ>;
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
-        TimingScope ts(name, stream);
-        if (a.amode == A_PLAIN)
-            hipLaunchKernelGGL((gemm_tn_kernel<A_PLAIN>), grid, dim3(TN_THREADS), lds_bytes, stream, a, g);
-        else
-            hipLaunchKernelGGL((gemm_tn_kernel<A_DZ>), grid, dim3(TN_THREADS), lds_bytes, stream, a, g);
-        int rc = check_launch(name);
-        if (rc) return rc;
+    const int n_q = cdiv(g.n_tpw, TN_WN), k_h = cdiv(g.k_tpw, TN_WK);     // tiles per wave actually needed
+    int rc = NRMS_OK;
+#define TN_LAUNCH(MODE, NN, KK)                                                                                     \
+    do {                                                                                                            \
+        const void* fn = (const void*)gemm_tn_kernel<MODE, NN, KK>;                                                 \
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   \
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; } \
+        TimingScope ts(name, stream);                                                                               \
+        hipLaunchKernelGGL((gemm_tn_kernel<MODE, NN, KK>), grid, dim3(TN_THREADS), lds_bytes, stream, a, g);        \
+        rc = check_launch(name);                                                                                    \
+    } while (0)
+    if (a.amode == A_PLAIN) {
+        if (n_q <= 2 && k_h <= 2) TN_LAUNCH(A_PLAIN, 2, 2);
+        else if (n_q <= 4) TN_LAUNCH(A_PLAIN, 4, 5);
+        else TN_LAUNCH(A_PLAIN, 5, 5);
+    } else {
+        if (n_q <= 2 && k_h <= 2) TN_LAUNCH(A_DZ, 2, 2);
+        else if (n_q <= 4) TN_LAUNCH(A_DZ, 4, 5);
+        else TN_LAUNCH(A_DZ, 5, 5);
     }
+#undef TN_LAUNCH
+    if (rc) return rc;
     const long total = (long)a.N * (a.K + 1);
     TimingScope ts("tn_reduce", stream);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a.partial, a.splits, a.N, a.K,

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
     int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w, const float* T, float* ds,
     float* dq_partial) {
     __shared__ float dsl[ROWS_WPB][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long gw = (long)blockIdx.x * ROWS_WPB + wave, nw = (long)gridDim.x * ROWS_WPB;
     float dq[ROWS_MAXQ / 64] = {0.f, 0.f, 0.f, 0.f};
     for (long seq = gw; seq < n_seq; seq += nw) {
