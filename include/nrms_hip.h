@@ -126,6 +126,12 @@ int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, fl
                    float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
                    void* stream);
 
+/* Per-impression AUC of evaluate() (train_eval.py:219-227,255-271 + evaluation.py:26-27):
+ * scores, labels [n_imp, max_c] (padded), lens [n_imp] = candidates actually shown;
+ * auc[i] = roc_auc_score(labels[i,:lens[i]], scores[i,:lens[i]]) in float64 (NaN if one class only). */
+int nrms_impression_auc(int32_t n_imp, int32_t max_c, const float* scores, const uint8_t* labels,
+                        const int32_t* lens, double* auc, void* stream);
+
 /* The keep mask (1 = kept) the encoder kernels apply at a dropout site, for n_rows x d
  * elements: site 0 = embedding dropout (nrms_v0.py:137), site 1 = context dropout (:171-173).
  * Lets a test replay a training step through the oracle with identical masks. */

@@ -300,9 +300,55 @@ __global__ void keep_mask_kernel(uint64_t seed, uint32_t site, long groups, uint
     reinterpret_cast<uchar4*>(keep)[i] = k;
 }
 
+// Per-impression ROC-AUC on the un-padded prefix (train_eval.py:219-227 `auc_score(y_true,
+// rank_score[i][:len(y_true)])`, evaluation.py:26-27 = sklearn roc_auc_score): the Mann-Whitney
+// statistic  (#{pos > neg} + 0.5 #{pos == neg}) / (n_pos n_neg)  counted exactly in integers and
+// divided once in float64, so it equals the reference to the last bit.  One wave per impression.
+__global__ __launch_bounds__(256) void impression_auc_kernel(int n_imp, int max_c, const float* scores,
+                                                             const uint8_t* labels, const int32_t* lens, double* auc) {
+    const int lane = threadIdx.x & 63;
+    const int imp = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (imp >= n_imp) return;
+    const int n = min(lens[imp], max_c);
+    const float* s = scores + (long)imp * max_c;
+    const uint8_t* y = labels + (long)imp * max_c;
+    unsigned long long twice = 0;      // 2*greater + equal, over (pos, neg) pairs
+    unsigned npos = 0;
+    for (int i = lane; i < n; i += 64) {
+        if (y[i] == 0) continue;
+        ++npos;
+        const float si = s[i];
+        for (int j = 0; j < n; ++j) {
+            if (y[j] != 0) continue;
+            const float sj = s[j];
+            twice += si > sj ? 2u : (si == sj ? 1u : 0u);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        twice += __shfl_xor(twice, o, 64);
+        npos += __shfl_xor(npos, o, 64);
+    }
+    if (lane == 0) {
+        const unsigned nneg = (unsigned)n - npos;
+        auc[imp] = (npos == 0 || nneg == 0) ? __longlong_as_double(0x7FF8000000000000LL)      // undefined: NaN
+                                             : 0.5 * (double)twice / ((double)npos * (double)nneg);
+    }
+}
+
 }  // namespace nrms
 
 using namespace nrms;
+
+extern "C" int nrms_impression_auc(int32_t n_imp, int32_t max_c, const float* scores, const uint8_t* labels,
+                                   const int32_t* lens, double* auc, void* stream) {
+    NRMS_REQUIRE(n_imp >= 0 && max_c > 0 && scores && labels && lens && auc, "impression_auc: bad arguments");
+    if (n_imp == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    TimingScope ts("impression_auc", s);
+    hipLaunchKernelGGL(impression_auc_kernel, dim3(cdiv(n_imp, 4)), dim3(256), 0, s, n_imp, max_c, scores, labels, lens, auc);
+    return check_launch("impression_auc");
+}
 
 extern "C" int nrms_click_score_fwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,
                                     const uint8_t* mask, float* scores, void* stream) {

@@ -263,6 +263,34 @@ class NRMSEngine:
                                      C.c_float(eps), int(step), C.c_float(grad_scale), _stream())
         _lib.check(rc, "nrms_adam_step")
 
+    def impression_auc(self, scores, labels, lens):
+        """scores [n, Cmax] fp32, labels [n, Cmax] uint8, lens [n] int32 (device) -> float64 AUC per impression."""
+        n, cmax = scores.shape
+        auc = torch.empty(n, dtype=torch.float64, device=self.device)
+        rc = self.lib.nrms_impression_auc(n, cmax, _lib.ptr(scores.contiguous()), _lib.ptr(labels.contiguous()),
+                                          _lib.ptr(lens.contiguous()), _lib.ptr(auc), _stream())
+        _lib.check(rc, "nrms_impression_auc")
+        return auc
+
+    # ---- inference with unique-title caching (SURVEY f-1) -------------------------------------
+    def forward_dedup(self, flat, hist_ids, cand_ids, cand_mask):
+        """Same scores as forward(training=False), but every distinct title of the batch is encoded
+        once (the reference encodes all B*(H+C) slots, 350 per user at C=300, most of them padding
+        or repeats: train_eval.py:229-273 / data_handler.py:174-177)."""
+        B, H, L = hist_ids.shape
+        Cn = cand_ids.shape[1]
+        d = self.dims.word_embed_size
+        ids = torch.cat([hist_ids.reshape(B * H, L), cand_ids.reshape(B * Cn, L)], dim=0)
+        uniq, inverse = torch.unique(ids, dim=0, return_inverse=True)
+        vec = self.encode_titles(flat, uniq, tag="news_eval")
+        nv = vec.index_select(0, inverse)
+        hist = nv[:B * H].view(B, H, d).contiguous()
+        cand = nv[B * H:].view(B, Cn, d).contiguous()
+        user = self.encode_users(flat, hist, tag="user_eval")
+        if cand_mask is not None:
+            cand_mask = cand_mask.contiguous()
+        return self.click_scores(cand, user, cand_mask), int(uniq.shape[0])
+
     def dropout_keep_mask(self, seed, site, n_rows, p_drop):
         d = self.dims.word_embed_size
         keep = torch.empty(n_rows * d, dtype=torch.uint8, device=self.device)

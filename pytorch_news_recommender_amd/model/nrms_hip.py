@@ -177,6 +177,9 @@ class Model(nn.Module):
         params = [p for _, p in self._ordered_params()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _NRMSFunction.apply(self, bt, ct, mask, p_drop, seed, *params)
+        if p_drop == 0.0 and getattr(self, "dedup_inference", True):
+            scores, self.last_unique_titles = self._engine.forward_dedup(self._flat, bt, ct, mask)
+            return scores
         return self._engine.forward(self._flat, bt, ct, mask, training=False)
 
     def _ordered_params(self):

@@ -1,0 +1,167 @@
+"""Train / evaluate / test loops with the reference's behaviour
+(/root/reference/MIND_2020/train_eval.py:35-153, 219-273, 300-341) on the HIP path.
+
+train():    Adam(lr=config.learning_rate) + CrossEntropy with label 0, loss averaged every 100
+            iterations, dev AUC every ``config.eval_step`` batches and at each epoch end, checkpoint
+            ``T{time}_{model}_epoch{E}_iter_{n}_auc_{auc:.3f}.ckpt`` when the AUC improves
+            (train_eval.py:139-149).  The step itself is ``model.train_step`` (fused HIP forward + CE +
+            backward + Adam); ``use_autograd=True`` runs the reference's literal sequence instead
+            (``model(batch)`` -> criterion -> backward -> torch.optim.Adam) through the same kernels.
+evaluate(): per-impression AUC on the un-padded prefix, unweighted mean (train_eval.py:219-271), with
+            the scores never leaving the GPU (``nrms_impression_auc``) instead of a fork pool.
+test():     per-impression rank lists in the MIND submission format (train_eval.py:280-286,335-341).
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import parallel
+
+
+def _inner(model):
+    return model.model if hasattr(model, "model") and hasattr(model.model, "train_step") else model
+
+
+def _pad_labels(y_true, max_c, device):
+    n = len(y_true)
+    lab = np.zeros((n, max_c), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for i, y in enumerate(y_true):
+        k = min(len(y), max_c)
+        lab[i, :k] = np.asarray(y[:k], dtype=np.uint8)
+        lens[i] = k
+    return torch.from_numpy(lab).to(device), torch.from_numpy(lens).to(device)
+
+
+def evaluate(config, model, data_iter, y_true, AUC_best=None, verbose=True):
+    """y_true: list (one entry per impression, in data_iter order) of 0/1 label lists -- the
+    reference keeps it in the module global ``_y_true`` read from dev_behaviors.csv (:36-39)."""
+    net = _inner(model)
+    was_training = net.training
+    net.eval()
+    scores = []
+    with torch.no_grad():
+        for datas in data_iter:
+            scores.append(net(datas))
+    rank_score = torch.cat(scores, dim=0)
+    eng = net.engine
+    lab, lens = _pad_labels(y_true[:rank_score.shape[0]], rank_score.shape[1], rank_score.device)
+    aucs = eng.impression_auc(rank_score, lab, lens)
+    AUC = float(aucs.mean().item())
+    if verbose:
+        print('AUC:', AUC)
+    net.train(was_training)
+    return AUC
+
+
+def log_res(config, step, auc):
+    os.makedirs(config.log_path, exist_ok=True)
+    with open(os.path.join(config.log_path, 'res.txt'), 'a+') as f:
+        f.write('{}_{}_:auc_{}\n'.format(time.strftime('%m-%d_%H.%M'), auc, step))
+
+
+def _save(config, model, total_batch, auc):
+    os.makedirs(config.save_path, exist_ok=True)
+    name = 'T{}_{}_epoch{}_iter_{}_auc_{:.3f}.ckpt'.format(time.strftime('%m-%d_%H.%M'), config.model_name,
+                                                          config.num_epochs, total_batch, auc)
+    torch.save(model.state_dict(), os.path.join(config.save_path, name))
+    return name
+
+
+def train(config, model, train_iter, dev_iter=None, dev_labels=None, use_autograd=False, max_batches=None,
+          verbose=True):
+    """Returns dict(losses=[...per batch...], aucs=[(batch, auc), ...], ckpts=[...])."""
+    net = _inner(model)
+    rank, _, world = parallel.env_world()
+    reduce = parallel.GradAllReduce() if world > 1 and torch.distributed.is_initialized() else None
+    start = time.time()
+    model.train()
+    optimizer = criterion = None
+    if use_autograd:
+        optimizer = torch.optim.Adam(model.parameters(), lr=config.learning_rate)
+        criterion = nn.CrossEntropyLoss()
+    total_batch, AUC_best, STEP_SIZE = 0, 0.56, 100          # train_eval.py:59,61
+    hist = dict(losses=[], aucs=[], ckpts=[])
+    window = []
+    done = False
+    for epoch in range(config.num_epochs):
+        if verbose:
+            print('Epoch [{}/{}]'.format(epoch + 1, config.num_epochs))
+        for datas in train_iter:
+            B = len(datas['browsed_titles'])
+            if use_autograd:
+                outputs = model(datas)
+                model.zero_grad()
+                y = torch.zeros(len(outputs), dtype=torch.long, device=outputs.device)
+                loss = criterion(outputs, y)
+                loss.backward()
+                optimizer.step()
+                window.append(loss.detach())
+            else:
+                loss_sum = net.train_step(datas, world_size=world, all_reduce=reduce)
+                window.append(loss_sum / B)
+            if total_batch % STEP_SIZE == 0:                 # one host sync per 100 iterations, not two per step
+                vals = [float(v) for v in window]
+                hist['losses'].extend(vals)
+                window = []
+                if verbose:
+                    print('Iter: {0:>6},  Train Loss: {1:>5.6},  Time: {2:.1f}s'.format(
+                        total_batch, float(np.mean(vals)), time.time() - start))
+            total_batch += 1
+            if dev_iter is not None and total_batch % config.eval_step == 0:
+                auc = evaluate(config, model, dev_iter, dev_labels, AUC_best, verbose)
+                hist['aucs'].append((total_batch, auc))
+                log_res(config, auc, total_batch)
+                if auc > AUC_best:
+                    AUC_best = auc
+                    if config.save_flag and rank == 0:
+                        hist['ckpts'].append(_save(config, model, total_batch, AUC_best))
+            if max_batches is not None and total_batch >= max_batches:
+                done = True
+                break
+        if dev_iter is not None:
+            auc = evaluate(config, model, dev_iter, dev_labels, AUC_best, verbose)
+            hist['aucs'].append((total_batch, auc))
+            log_res(config, auc, 'epoch_{}'.format(epoch))
+            if auc > AUC_best:
+                AUC_best = auc
+                if config.save_flag and rank == 0:
+                    hist['ckpts'].append(_save(config, model, total_batch, AUC_best))
+        if done:
+            break
+    hist['losses'].extend(float(v) for v in window)
+    return hist
+
+
+def _cal_test(scores, n):
+    """Rank (1 = best) of each shown candidate (train_eval.py:280-286)."""
+    res = np.argsort(-np.asarray(scores[:n]), kind="stable")
+    rank = [0] * n
+    for pos, v in enumerate(res):
+        rank[v] = pos + 1
+    return rank
+
+
+def test(config, model, data_iter, test_list_nums, ckpt_file=None, out_file=None):
+    """Writes ``<impression index> [r1,r2,...]`` lines; returns the file name."""
+    net = _inner(model)
+    if ckpt_file is not None:
+        model.load_state_dict(torch.load(os.path.join(config.save_path, ckpt_file), weights_only=True))
+    net.eval()
+    scores = []
+    with torch.no_grad():
+        for datas in data_iter:
+            scores.append(net(datas).cpu())
+    test_rank_score = np.concatenate([s.numpy() for s in scores])
+    ranks = [_cal_test(test_rank_score[i], int(n)) for i, n in enumerate(test_list_nums[:len(test_rank_score)])]
+    file_name = out_file or 'sumbit_{}_{}.txt'.format(config.model_name, time.strftime('%m-%d_%H.%M', time.localtime()))
+    with open(file_name, 'w') as f:
+        for i, r in enumerate(ranks):
+            f.write(str(i + 1) + ' ')
+            f.write(str(r).replace(' ', '') + '\n')
+    return file_name
