@@ -44,12 +44,17 @@ typedef struct nrms_encoder_desc {
     int32_t  n_seq;        /* titles (B*(H+C)) or users (B) */
     int32_t  seq_len;      /* L or H, 1..64 */
     int32_t  d_model;      /* config.word_embed_size; multiple of 4; = n_heads * d_k */
-    int32_t  n_heads;      /* config.num_attention_heads; d_k = d_model / n_heads even, <= 64 */
+    int32_t  n_heads;      /* config.num_attention_heads (v1 news encoder: title_heads_num);
+                              d_k = d_model / n_heads even, <= 64 */
     int32_t  q_dim;        /* config.query_vector_dim, multiple of 4, <= 256 */
     int32_t  vocab;        /* rows of `table`, or 0 */
-    float    p_drop;       /* config.dropout when training, 0 in eval: both dropout sites of the
-                              news encoder (nrms_v0.py:137 and :171-173).  Must be 0 if vocab==0. */
+    float    p_drop_embed; /* dropout on the gathered embeddings (nrms_v0.py:137); 0 in eval / nrms_v1 */
+    float    p_drop_ctx;   /* dropout on the attention output (nrms_v0.py:171-173; nrms_v1.py:161 after W_O) */
     int32_t  precision;    /* NRMS_PRECISION_* */
+    int32_t  use_output_proj; /* 1: nrms_v1 topology, MHSA ends in output_linear W_O (nrms_v1.py:55,80) */
+    int32_t  mask_mode;    /* bit 0: pairwise attention mask mask_i*mask_j -> -1e9 (nrms_v1.py:27-33);
+                              bit 1: additive-attention mask -> -1e9 (nrms_v1.py:100-101); 0 = nrms_v0 */
+    int32_t  reserved;
     uint64_t seed;         /* counter-based RNG key for the dropout masks (per step) */
 } nrms_encoder_desc;
 
@@ -59,6 +64,8 @@ typedef struct nrms_encoder_weights {
     const float* table;    /* [vocab, d]   news_encoder.word_embedding.0.weight, or NULL */
     const float* w_qkv;    /* [3d, d] */
     const float* b_qkv;    /* [3d] */
+    const float* w_o;      /* [d, d]       output_linear.weight (nrms_v1.py:55) or NULL */
+    const float* b_o;      /* [d] */
     const float* w_add;    /* [q, d]       additive_attention.linear.weight (nrms_v0.py:91) */
     const float* b_add;    /* [q] */
     const float* q_vec;    /* [q]          additive_attention.attention_query_vector (:92-93) */
@@ -68,6 +75,8 @@ typedef struct nrms_encoder_grads {   /* same shapes as the weights; accumulated
     float* table;          /* dense [vocab, d]; row 0 never written (padding_idx=0, nrms_v0.py:136) */
     float* w_qkv;
     float* b_qkv;
+    float* w_o;            /* NULL unless use_output_proj */
+    float* b_o;
     float* w_add;
     float* b_add;
     float* q_vec;
@@ -79,17 +88,19 @@ typedef struct nrms_encoder_acts {
     float* x;              /* [M, d]   news encoder only: gathered word embeddings AFTER dropout
                                        (the user encoder's input is the caller's `x`); may be NULL if vocab==0 */
     float* qkv;            /* [M, 3d]  Q|K|V projections incl. bias */
+    float* attn;           /* [M, d]   use_output_proj only: head-concatenated attention output (input of W_O) */
     float* ctx;            /* [M, d]   head-concatenated attention output AFTER dropout */
     float* t;              /* [M, q]   tanh(linear(ctx))            (nrms_v0.py:108) */
     float* w;              /* [M]      additive-attention softmax weights (nrms_v0.py:110-112) */
 } nrms_encoder_acts;
 
 /* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V
- * -> dropout -> tanh(linear)·q -> softmax over the sequence -> weighted sum.
- * Replaces model/nrms_v0.py:13-23,46-76,100-126,154-176,188-199.
+ * [-> output projection W_O] -> dropout -> tanh(linear)·q -> softmax over the sequence -> weighted sum.
+ * Replaces model/nrms_v0.py:13-23,46-76,100-126,154-176,188-199 and, with use_output_proj / mask_mode,
+ * model/nrms_v1.py:15-105,128-162,208-211.
  * out: [n_seq, d].  Exactly one of ids / x is used (by desc->vocab). */
 int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w,
-                     const int64_t* ids, const float* x,
+                     const int64_t* ids, const float* x, const uint8_t* mask /* [n_seq, seq_len] or NULL */,
                      const nrms_encoder_acts* acts, float* out, void* stream);
 
 /* Backward of the above (autograd through the same lines; `loss.backward()` train_eval.py:126).
@@ -98,7 +109,7 @@ int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* 
  * (the dense embedding gradient the reference builds 55x per step). */
 size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc);
 int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w,
-                     const int64_t* ids, const float* x,
+                     const int64_t* ids, const float* x, const uint8_t* mask,
                      const nrms_encoder_acts* acts, const float* dout,
                      const nrms_encoder_grads* grads, float* dx,
                      void* workspace, size_t workspace_bytes, void* stream);

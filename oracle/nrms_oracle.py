@@ -96,8 +96,24 @@ def _apply_keep(x, keep, p_drop):
     return x * keep.to(x.dtype) / (1.0 - p_drop)
 
 
+def v1_to_v0_names(params):
+    """nrms_v1's parameter names (model/nrms_v1.py:54-55,87,115) -> the v0-style keys the functions
+    here use; the math is shared, only the names and the presence of W_O differ."""
+    out = {}
+    for k, v in params.items():
+        k = k.replace("multi_head_self_attention.linear_layers.0", "multihead_self_attention.W_Q")
+        k = k.replace("multi_head_self_attention.linear_layers.1", "multihead_self_attention.W_K")
+        k = k.replace("multi_head_self_attention.linear_layers.2", "multihead_self_attention.W_V")
+        k = k.replace("multi_head_self_attention.output_linear", "multihead_self_attention.W_O")
+        k = k.replace("additive_attention.query_vector", "additive_attention.attention_query_vector")
+        if k == "news_encoder.word_embedding.weight":
+            k = "news_encoder.word_embedding.0.weight"
+        out[k] = v
+    return out
+
+
 def news_encoder(p, ids, n_heads, p_drop=0.0, keep_embed=None, keep_ctx=None, training=False,
-                 generator=None):
+                 generator=None, embed_dropout=True, mask=None, mask_mode=0):
     """model/nrms_v0.py:154-176 -- embedding (row 0 = pad row, used as stored) -> dropout ->
     MHSA -> F.dropout -> additive attention.  ids [N,L] int64 -> [N,d].
 
@@ -105,23 +121,26 @@ def news_encoder(p, ids, n_heads, p_drop=0.0, keep_embed=None, keep_ctx=None, tr
     explicit keep masks let tests replay the HIP path's counter-based masks."""
     table = p["news_encoder.word_embedding.0.weight"]
     X = F.embedding(ids, table, padding_idx=0)
-    if training and keep_embed is None and p_drop > 0:
-        X = F.dropout(X, p_drop, True)
-    else:
-        X = _apply_keep(X, keep_embed, p_drop)
-    ctx = multihead_self_attention(p, "news_encoder.multihead_self_attention.", X, n_heads)
+    if embed_dropout:                       # nrms_v1 has no embedding dropout (nrms_v1.py:159-161)
+        if training and keep_embed is None and p_drop > 0:
+            X = F.dropout(X, p_drop, True)
+        else:
+            X = _apply_keep(X, keep_embed, p_drop)
+    ctx = multihead_self_attention(p, "news_encoder.multihead_self_attention.", X, n_heads,
+                                   mask=mask if (mask_mode & 1) else None)
     if training and keep_ctx is None and p_drop > 0:
         ctx = F.dropout(ctx, p_drop, True)
     else:
         ctx = _apply_keep(ctx, keep_ctx, p_drop)
-    return additive_attention(p, "news_encoder.additive_attention.", ctx)
+    return additive_attention(p, "news_encoder.additive_attention.", ctx, mask if (mask_mode & 2) else None)
 
 
-def user_encoder(p, news_vectors, n_heads):
+def user_encoder(p, news_vectors, n_heads, mask=None, mask_mode=0):
     """model/nrms_v0.py:188-199 -- MHSA over the clicked-news vectors + additive pooling;
-    no dropout, no mask."""
-    ctx = multihead_self_attention(p, "user_encoder.multihead_self_attention.", news_vectors, n_heads)
-    return additive_attention(p, "user_encoder.additive_attention.", ctx)
+    no dropout, no mask (v1's UserEncoder.forward accepts attn_masks, nrms_v1.py:208-211)."""
+    ctx = multihead_self_attention(p, "user_encoder.multihead_self_attention.", news_vectors, n_heads,
+                                   mask=mask if (mask_mode & 1) else None)
+    return additive_attention(p, "user_encoder.additive_attention.", ctx, mask if (mask_mode & 2) else None)
 
 
 def click_scores(cand_vec, user_vec, cand_mask=None):
@@ -132,7 +151,8 @@ def click_scores(cand_vec, user_vec, cand_mask=None):
     return s
 
 
-def forward(p, batch, n_heads, p_drop=0.0, keep=None, training=False, per_slot=False):
+def forward(p, batch, n_heads, p_drop=0.0, keep=None, training=False, per_slot=False, news_heads=None,
+            embed_dropout=True):
     """model/nrms_v0.py:230-276 -- scores [B,C].
 
     per_slot=False encodes all B*(H+C) titles in one batched call (same math);
@@ -145,18 +165,19 @@ def forward(p, batch, n_heads, p_drop=0.0, keep=None, training=False, per_slot=F
     ct = torch.as_tensor(batch["candidate_titles"]).long()
     B, H, L = bt.shape
     C = ct.shape[1]
+    nh = n_heads if news_heads is None else news_heads      # nrms_v1: title_heads_num (nrms_v1.py:122)
     if per_slot:
         assert keep is None
-        cand = torch.stack([news_encoder(p, x, n_heads, p_drop, training=training)
+        cand = torch.stack([news_encoder(p, x, nh, p_drop, training=training, embed_dropout=embed_dropout)
                             for x in ct.permute(1, 0, 2)], dim=1)
-        hist = torch.stack([news_encoder(p, x, n_heads, p_drop, training=training)
+        hist = torch.stack([news_encoder(p, x, nh, p_drop, training=training, embed_dropout=embed_dropout)
                             for x in bt.permute(1, 0, 2)], dim=1)
     else:
         ids = torch.cat([bt.reshape(B * H, L), ct.reshape(B * C, L)], dim=0)
         ke = kc = None
         if keep is not None:
             ke, kc = keep.get("embed"), keep.get("ctx")
-        nv = news_encoder(p, ids, n_heads, p_drop, ke, kc, training=training)
+        nv = news_encoder(p, ids, nh, p_drop, ke, kc, training=training, embed_dropout=embed_dropout)
         hist = nv[:B * H].view(B, H, -1)
         cand = nv[B * H:].view(B, C, -1)
     user = user_encoder(p, hist, n_heads)
@@ -173,11 +194,12 @@ def loss_fn(scores):
 
 
 def loss_and_grads(params_np, batch, n_heads, dtype=torch.float32, p_drop=0.0, keep=None,
-                   per_slot=False):
+                   per_slot=False, news_heads=None, embed_dropout=True):
     """One forward + backward (train_eval.py:111-126).  Returns scores, loss, dict of grads
     (numpy).  The embedding gradient is dense [V,d] with row 0 zero (padding_idx=0)."""
     p = to_torch(params_np, dtype, requires_grad=True)
-    scores, aux = forward(p, batch, n_heads, p_drop, keep, per_slot=per_slot)
+    scores, aux = forward(p, batch, n_heads, p_drop, keep, per_slot=per_slot, news_heads=news_heads,
+                          embed_dropout=embed_dropout)
     loss = loss_fn(scores)
     loss.backward()
     grads = {k: (v.grad.detach().numpy().copy() if v.grad is not None

@@ -21,30 +21,33 @@ class NrmsError(RuntimeError):
 class EncoderDesc(C.Structure):
     _fields_ = [("n_seq", C.c_int32), ("seq_len", C.c_int32), ("d_model", C.c_int32),
                 ("n_heads", C.c_int32), ("q_dim", C.c_int32), ("vocab", C.c_int32),
-                ("p_drop", C.c_float), ("precision", C.c_int32), ("seed", C.c_uint64)]
+                ("p_drop_embed", C.c_float), ("p_drop_ctx", C.c_float), ("precision", C.c_int32),
+                ("use_output_proj", C.c_int32), ("mask_mode", C.c_int32), ("reserved", C.c_int32),
+                ("seed", C.c_uint64)]
 
 
 class EncoderWeights(C.Structure):
-    _fields_ = [("table", C.c_void_p), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p),
-                ("w_add", C.c_void_p), ("b_add", C.c_void_p), ("q_vec", C.c_void_p)]
+    _fields_ = [("table", C.c_void_p), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p), ("w_o", C.c_void_p),
+                ("b_o", C.c_void_p), ("w_add", C.c_void_p), ("b_add", C.c_void_p), ("q_vec", C.c_void_p)]
 
 
 class EncoderGrads(C.Structure):
-    _fields_ = [("table", C.c_void_p), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p),
-                ("w_add", C.c_void_p), ("b_add", C.c_void_p), ("q_vec", C.c_void_p)]
+    _fields_ = [("table", C.c_void_p), ("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p), ("w_o", C.c_void_p),
+                ("b_o", C.c_void_p), ("w_add", C.c_void_p), ("b_add", C.c_void_p), ("q_vec", C.c_void_p)]
 
 
 class EncoderActs(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("t", C.c_void_p), ("w", C.c_void_p)]
+    _fields_ = [("x", C.c_void_p), ("qkv", C.c_void_p), ("attn", C.c_void_p), ("ctx", C.c_void_p),
+                ("t", C.c_void_p), ("w", C.c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/nrms_hip.h declares.
 SIGNATURES = {
     "nrms_encoder_fwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
-                                   C.POINTER(EncoderActs), C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, C.POINTER(EncoderActs), C.c_void_p, C.c_void_p]),
     "nrms_encoder_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "nrms_encoder_bwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
-                                   C.POINTER(EncoderActs), C.c_void_p, C.POINTER(EncoderGrads), C.c_void_p,
+                                   C.c_void_p, C.POINTER(EncoderActs), C.c_void_p, C.POINTER(EncoderGrads), C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "nrms_click_score_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),

@@ -23,6 +23,8 @@ struct AttnArgs {
     const float* dctx;      // bwd in  [M, d] gradient w.r.t. the POST-dropout context; the mask (site 1,
                             // same Philox counters as the forward) is applied while it is loaded
     float* dqkv;            // bwd out [M, 3d]
+    const uint8_t* mask;    // optional [n_seq, S]: v1's pairwise mask mask_i*mask_j -> masked_fill(-1e9)
+                            // (model/nrms_v1.py:27-33); null = v0 (no mask at all)
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -137,11 +139,15 @@ __device__ __forceinline__ void abt_tiles(const float* A, const float* B, int RS
         }
 }
 
-// in-register softmax over keys (rows of the transposed tile) for each query column
+// in-register softmax over keys (rows of the transposed tile) for each query column.
+// msk (wave-private LDS, 1.0 / 0.0 per position) reproduces v1's masked_fill(mask_i*mask_j == 0, -1e9):
+// a fully masked query row ends up uniform over the S real keys, exactly like the reference.
 template <int NS>
-__device__ __forceinline__ void softmax_cols(f32x16 (&st)[NS][NS], float scale, int S, int hh) {
+__device__ __forceinline__ void softmax_cols(f32x16 (&st)[NS][NS], float scale, int S, int l32, int hh,
+                                             const float* msk) {
 #pragma unroll
     for (int it = 0; it < NS; ++it) {
+        const float mi = msk != nullptr ? msk[it * 32 + l32] : 1.0f;
         float mx = -1e30f;
 #pragma unroll
         for (int jt = 0; jt < NS; ++jt)
@@ -149,6 +155,7 @@ __device__ __forceinline__ void softmax_cols(f32x16 (&st)[NS][NS], float scale, 
             for (int r = 0; r < 16; ++r) {
                 const int j = jt * 32 + crow32(r, hh);
                 float s = st[jt][it][r] * scale;
+                if (msk != nullptr) s = (mi * msk[j] != 0.f) ? s : -1e9f;
                 s = j < S ? s : -1e30f;
                 st[jt][it][r] = s;
                 mx = fmaxf(mx, s);
@@ -245,13 +252,14 @@ __device__ __forceinline__ void stage_out(float* dst, int RS, const f32x16 (&o)[
 // ---------------------------------------------------------------------------------------
 template <int NS, int ND, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
-    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, WF = 3 * SP * RS;
+    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, WF = 3 * SP * RS + 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
     float* Qs = lds + wave * WF;
     float* Ks = Qs + SP * RS;
     float* Vs = Ks + SP * RS;
+    float* Ms = Vs + SP * RS;
     for (int i = lane; i < WF; i += 64) Qs[i] = 0.f;
     wave_sync();
 
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
         pq.store(Qs, RS, a.S, a.dk, lane);
         pk.store(Ks, RS, a.S, a.dk, lane);
         pv.store(Vs, RS, a.S, a.dk, lane);
+        if (a.mask != nullptr) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
         wave_sync();
         if (u + ustride < total) {            // next unit's operands fly while this one computes
             const long un = u + ustride, sn = un / a.h;
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 
         f32x16 st[NS][NS];
         abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
-        softmax_cols<NS>(st, a.scale, a.S, hh);
+        softmax_cols<NS>(st, a.scale, a.S, l32, hh, a.mask != nullptr ? Ms : nullptr);
         f32x16 o[ND][NS];
         at_x_tiles<NS, ND>(Vs, RS, l32, hh, st, o);
         wave_sync();
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 template <int NS, int ND, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
     constexpr bool PF = NS == 1;      // prefetch across the compute only where registers allow
-    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1, WF = 4 * SP * RS + SP * TS;
+    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1, WF = 4 * SP * RS + SP * TS + 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
     float* Vs = Ks + SP * RS;
     float* Gs = Vs + SP * RS;
     float* Tb = Gs + SP * RS;
+    float* Ms = Tb + SP * TS;
     for (int i = lane; i < WF; i += 64) Qs[i] = 0.f;
     wave_sync();
 
@@ -356,6 +366,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
         pk.store(Ks, RS, a.S, a.dk, lane);
         pv.store(Vs, RS, a.S, a.dk, lane);
         pg.store_drop(Gs, RS, a.S, a.dk, lane, a.d, a.drop, (uint64_t)(seq * a.S * a.d + head * a.dk));
+        if (a.mask != nullptr) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
         wave_sync();
         if (PF && u + ustride < total) {
             const long un = u + ustride, sn = un / a.h;
@@ -369,7 +380,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
 
         f32x16 st[NS][NS], dp[NS][NS];
         abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
-        softmax_cols<NS>(st, a.scale, a.S, hh);            // st = P^T
+        const float* msk = a.mask != nullptr ? Ms : nullptr;
+        softmax_cols<NS>(st, a.scale, a.S, l32, hh, msk);  // st = P^T
         abt_tiles<NS, ND>(Vs, Gs, RS, l32, hh, dp);         // dp = dP^T
 #pragma unroll
         for (int it = 0; it < NS; ++it) {
@@ -382,7 +394,12 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int jt = 0; jt < NS; ++jt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[jt][it][r] = st[jt][it][r] * (dp[jt][it][r] - D) * a.scale;   // dS^T
+                for (int r = 0; r < 16; ++r) {
+                    float dsv = st[jt][it][r] * (dp[jt][it][r] - D) * a.scale;                           // dS^T
+                    // masked_fill passes no gradient to the scores it overwrote
+                    if (msk != nullptr && msk[it * 32 + l32] * msk[jt * 32 + crow32(r, hh)] == 0.f) dsv = 0.f;
+                    dp[jt][it][r] = dsv;
+                }
         }
         // dV^T = dO^T P   (queries summed: P through the transpose image); V is dead -> stage dV there
         transpose_to_lds<NS>(Tb, st, l32, hh);
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
 template <int NS, int ND, int WPB, bool BWD>
 static int launch_attn_inst(const AttnArgs& a, hipStream_t stream) {
     constexpr int SP = 32 * NS, RS = 32 * ND + 4;
-    constexpr size_t wf = BWD ? (4 * SP * RS + SP * (SP + 1)) : (3 * SP * RS);
+    constexpr size_t wf = BWD ? (4 * SP * RS + SP * (SP + 1) + 64) : (3 * SP * RS + 64);
     constexpr size_t bytes = wf * WPB * sizeof(float);
     const long total = (long)a.n_seq * a.h;
     int blocks = (int)((total + WPB - 1) / WPB);
@@ -458,8 +475,9 @@ static int launch_attn_inst(const AttnArgs& a, hipStream_t stream) {
 }
 
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
-                     const float* dctx, float* dqkv, hipStream_t stream) {
+                     const float* dctx, float* dqkv, const uint8_t* mask, hipStream_t stream) {
     AttnArgs a;
+    a.mask = mask;
     a.n_seq = n_seq; a.S = S; a.d = d; a.h = h; a.dk = d / h;
     a.scale = 1.0f / sqrtf((float)a.dk);
     a.qkv = qkv; a.ctx = ctx; a.drop = drop; a.dctx = dctx; a.dqkv = dqkv;

@@ -10,12 +10,13 @@
 namespace nrms {
 
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
-                     const float* dctx, float* dqkv, hipStream_t stream);
+                     const float* dctx, float* dqkv, const uint8_t* mask, hipStream_t stream);
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
-                       const float* q_vec, float* T, float* wout, float* out, hipStream_t stream);
+                       const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, hipStream_t stream);
 int addattn_bwd_rows_waves(int n_seq);
 int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w,
-                            const float* T, float* ds, float* dq_partial, float* dq, hipStream_t stream);
+                            const float* T, float* ds, float* dq_partial, float* dq, const uint8_t* mask,
+                            hipStream_t stream);
 
 // ---- error text -----------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -75,15 +76,17 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d->q_dim > 0 && (d->q_dim & 3) == 0 && d->q_dim <= 256, "%s: q_dim=%d must be a multiple of 4 <= 256",
                  who, d->q_dim);
     NRMS_REQUIRE(d->vocab >= 0, "%s: vocab=%d", who, d->vocab);
-    NRMS_REQUIRE(d->p_drop >= 0.f && d->p_drop < 1.f, "%s: p_drop=%f", who, (double)d->p_drop);
-    NRMS_REQUIRE(d->vocab > 0 || d->p_drop == 0.f, "%s: dropout is only defined for the news encoder", who);
+    NRMS_REQUIRE(d->p_drop_embed >= 0.f && d->p_drop_embed < 1.f && d->p_drop_ctx >= 0.f && d->p_drop_ctx < 1.f,
+                 "%s: dropout probabilities must be in [0,1)", who);
+    NRMS_REQUIRE(d->vocab > 0 || d->p_drop_embed == 0.f, "%s: embedding dropout needs the news encoder (vocab>0)", who);
     NRMS_REQUIRE(d->precision == NRMS_PRECISION_FP32, "%s: unsupported precision %d", who, d->precision);
+    NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
     return NRMS_OK;
 }
 
 struct BwdWorkspace {
-    size_t dctx, dqkv, ds, wqkv_t, wadd_t, tn_partial, dq_partial, total;   // byte offsets
+    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, total;   // byte offsets
 };
 
 static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
@@ -93,12 +96,15 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     auto take = [&](size_t floats) { size_t o = off; off = align_up(off + floats * sizeof(float), 256); return o; };
     w.dctx = take(M * dm);
     w.dqkv = take(M * 3 * dm);
+    w.dattn = take(d->use_output_proj ? M * dm : 0);
     w.ds = take(M);
     w.wqkv_t = take(3 * dm * dm);
     w.wadd_t = take(q * dm);
+    w.wo_t = take(d->use_output_proj ? dm * dm : 0);
     const size_t p1 = gemm_tn_workspace_floats((int)M, (int)(3 * dm), (int)dm, nullptr);
     const size_t p2 = gemm_tn_workspace_floats((int)M, (int)q, (int)dm, nullptr);
-    w.tn_partial = take(p1 > p2 ? p1 : p2);
+    const size_t p3 = d->use_output_proj ? gemm_tn_workspace_floats((int)M, (int)dm, (int)dm, nullptr) : 0;
+    w.tn_partial = take(p1 > p2 ? (p1 > p3 ? p1 : p3) : (p2 > p3 ? p2 : p3));
     w.dq_partial = take((size_t)addattn_bwd_rows_waves(d->n_seq) * q);
     w.total = off;
     return w;
@@ -109,24 +115,31 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
 using namespace nrms;
 
 extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
-                                const float* x, const nrms_encoder_acts* acts, float* out, void* stream) {
+                                const float* x, const uint8_t* mask, const nrms_encoder_acts* acts, float* out,
+                                void* stream) {
     int rc = validate_desc(desc, "encoder_fwd");
     if (rc) return rc;
     NRMS_REQUIRE(w && acts && out, "encoder_fwd: null argument");
     NRMS_REQUIRE(w->w_qkv && w->b_qkv && w->w_add && w->b_add && w->q_vec, "encoder_fwd: null weight");
     NRMS_REQUIRE(acts->qkv && acts->ctx, "encoder_fwd: acts.qkv / acts.ctx are required");
-    const bool gather = desc->vocab > 0;
+    const bool gather = desc->vocab > 0, wo = desc->use_output_proj != 0;
     NRMS_REQUIRE(gather ? (ids != nullptr && w->table != nullptr) : (x != nullptr),
                  "encoder_fwd: %s input missing", gather ? "ids/table" : "x");
+    NRMS_REQUIRE(!wo || (w->w_o && w->b_o && acts->attn), "encoder_fwd: use_output_proj needs w_o, b_o and acts.attn");
+    NRMS_REQUIRE(desc->mask_mode == 0 || mask != nullptr, "encoder_fwd: mask_mode=%d but mask is null", desc->mask_mode);
     if (desc->n_seq == 0) return NRMS_OK;
     hipStream_t s = (hipStream_t)stream;
     const int S = desc->seq_len, d = desc->d_model, q = desc->q_dim, M = desc->n_seq * S;
-    const Dropout drop = make_dropout(desc->seed, desc->p_drop);
+    const Dropout drop_e = make_dropout(desc->seed, desc->p_drop_embed);
+    const Dropout drop_c = make_dropout(desc->seed, desc->p_drop_ctx);
+    const Dropout no_drop = make_dropout(0, 0.f);
+    const uint8_t* amask = (desc->mask_mode & 1) ? mask : nullptr;
+    const uint8_t* pmask = (desc->mask_mode & 2) ? mask : nullptr;
 
     const float* xin = x;
     if (gather) {
         NRMS_REQUIRE(acts->x != nullptr, "encoder_fwd: acts.x (gathered embeddings) is required for the news encoder");
-        rc = launch_gather_dropout((long)M, d, ids, w->table, drop, acts->x, s);
+        rc = launch_gather_dropout((long)M, d, ids, w->table, drop_e, acts->x, s);
         if (rc) return rc;
         xin = acts->x;
     }
@@ -136,9 +149,20 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     g.W = w->w_qkv; g.bias = w->b_qkv; g.C = acts->qkv; g.ldc = 3 * d;
     rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "qkv_proj_fwd");
     if (rc) return rc;
-    rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, acts->ctx, drop, nullptr, nullptr, s);
+    // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
+    // concatenation, the output projection follows and carries the dropout in its epilogue.
+    rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
+                          wo ? no_drop : drop_c, nullptr, nullptr, amask, s);
     if (rc) return rc;
-    return launch_addattn_fwd(desc->n_seq, S, d, q, acts->ctx, w->w_add, w->b_add, w->q_vec, acts->t, acts->w, out, s);
+    if (wo) {
+        NTArgs o{};
+        o.M = M; o.N = d; o.K = d; o.rows_per_tile = NT_BM;
+        o.A = acts->attn; o.lda = d; o.W = w->w_o; o.bias = w->b_o; o.C = acts->ctx; o.ldc = d; o.drop = drop_c;
+        rc = launch_gemm_nt(A_PLAIN, E_STORE, o, s, "out_proj_fwd");
+        if (rc) return rc;
+    }
+    return launch_addattn_fwd(desc->n_seq, S, d, q, acts->ctx, w->w_add, w->b_add, w->q_vec, acts->t, acts->w, out,
+                              pmask, s);
 }
 
 extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc) {
@@ -147,7 +171,7 @@ extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc
 }
 
 extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
-                                const float* x, const nrms_encoder_acts* acts, const float* dout,
+                                const float* x, const uint8_t* mask, const nrms_encoder_acts* acts, const float* dout,
                                 const nrms_encoder_grads* grads, float* dx, void* workspace, size_t workspace_bytes,
                                 void* stream) {
     int rc = validate_desc(desc, "encoder_bwd");
@@ -156,9 +180,12 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     NRMS_REQUIRE(acts->qkv && acts->ctx && acts->t && acts->w, "encoder_bwd: all saved activations are required");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec,
                  "encoder_bwd: null gradient buffer");
-    const bool gather = desc->vocab > 0;
+    const bool gather = desc->vocab > 0, wo = desc->use_output_proj != 0;
     NRMS_REQUIRE(gather ? (ids != nullptr && acts->x != nullptr && grads->table != nullptr) : (x != nullptr && dx != nullptr),
                  "encoder_bwd: %s missing", gather ? "ids/acts.x/grads.table" : "x/dx");
+    NRMS_REQUIRE(!wo || (w->w_o && acts->attn && grads->w_o && grads->b_o),
+                 "encoder_bwd: use_output_proj needs w_o, acts.attn, grads.w_o, grads.b_o");
+    NRMS_REQUIRE(desc->mask_mode == 0 || mask != nullptr, "encoder_bwd: mask_mode=%d but mask is null", desc->mask_mode);
     const BwdWorkspace L = bwd_layout(desc);
     if (workspace_bytes < L.total) {
         set_error("encoder_bwd: workspace %zu < required %zu bytes", workspace_bytes, L.total);
@@ -168,20 +195,29 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     if (desc->n_seq == 0) return NRMS_OK;
     hipStream_t s = (hipStream_t)stream;
     const int S = desc->seq_len, d = desc->d_model, q = desc->q_dim, M = desc->n_seq * S;
-    const Dropout drop = make_dropout(desc->seed, desc->p_drop);
+    const Dropout drop_e = make_dropout(desc->seed, desc->p_drop_embed);
+    const Dropout drop_c = make_dropout(desc->seed, desc->p_drop_ctx);
+    const Dropout no_drop = make_dropout(0, 0.f);
+    const uint8_t* amask = (desc->mask_mode & 1) ? mask : nullptr;
+    const uint8_t* pmask = (desc->mask_mode & 2) ? mask : nullptr;
     char* base = (char*)workspace;
     float* dctx = (float*)(base + L.dctx);
     float* dqkv = (float*)(base + L.dqkv);
+    float* dattn = (float*)(base + L.dattn);
     float* ds = (float*)(base + L.ds);
     float* wqkv_t = (float*)(base + L.wqkv_t);
     float* wadd_t = (float*)(base + L.wadd_t);
+    float* wo_t = (float*)(base + L.wo_t);
     float* tn_partial = (float*)(base + L.tn_partial);
     float* dq_partial = (float*)(base + L.dq_partial);
 
     // 1. pooling rows: ds, d(q_vec)
-    rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec, s);
+    rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
+                                 pmask, s);
     if (rc) return rc;
-    // 2. d(ctx) = dZ Wa + w_s dout, through the context dropout mask
+    // 2. d(ctx) = dZ Wa + w_s dout.  v0: left as the gradient of the POST-dropout context (the attention
+    //    backward applies the mask while loading it).  v1: the mask is applied here, because the output
+    //    projection's backward GEMMs come in between.
     rc = launch_transpose(w->w_add, wadd_t, q, d, s);
     if (rc) return rc;
     {
@@ -190,6 +226,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         g.ds = ds; g.qv = w->q_vec; g.T = acts->t;
         g.W = wadd_t; g.C = dctx; g.ldc = d;
         g.wrow = acts->w; g.dout = dout; g.S = S;
+        if (wo) g.drop = drop_c;
         rc = launch_gemm_nt(A_DZ, E_DCTX, g, s, "dctx_bwd");
         if (rc) return rc;
     }
@@ -202,8 +239,27 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = launch_gemm_tn(t, s, "dwadd_bwd");
         if (rc) return rc;
     }
+    const float* dattn_in = dctx;
+    if (wo) {
+        // 3b. output projection: d(W_O), d(b_O) = dC^T [attn | 1];  d(attn) = dC W_O
+        TNArgs t{};
+        t.M = M; t.N = d; t.K = d; t.amode = A_PLAIN;
+        t.A = dctx; t.lda = d; t.B = acts->attn; t.ldb = d;
+        t.dW = grads->w_o; t.dbias = grads->b_o; t.partial = tn_partial;
+        rc = launch_gemm_tn(t, s, "dwo_bwd");
+        if (rc) return rc;
+        rc = launch_transpose(w->w_o, wo_t, d, d, s);
+        if (rc) return rc;
+        NTArgs g{};
+        g.M = M; g.N = d; g.K = d; g.rows_per_tile = NT_BM;
+        g.A = dctx; g.lda = d; g.W = wo_t; g.C = dattn; g.ldc = d;
+        rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "dattn_bwd");
+        if (rc) return rc;
+        dattn_in = dattn;
+    }
     // 4. attention backward
-    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, drop, dctx, dqkv, s);
+    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, wo ? no_drop : drop_c, dattn_in,
+                          dqkv, amask, s);
     if (rc) return rc;
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings)
     const float* xin = gather ? acts->x : x;
@@ -227,7 +283,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "dx_bwd");
         if (rc) return rc;
     }
-    if (gather) rc = launch_scatter_dropout((long)M, d, ids, dctx, drop, grads->table, s);
+    if (gather) rc = launch_scatter_dropout((long)M, d, ids, dctx, drop_e, grads->table, s);
     return rc;
 }
 
@@ -261,4 +317,4 @@ extern "C" int nrms_timing_read(const char* prefix, double* total_ms, int64_t* l
 }
 
 extern "C" const char* nrms_last_error(void) { return g_err; }
-extern "C" const char* nrms_version(void) { return "nrms_hip 0.2 (gfx950, fp32 MFMA)"; }
+extern "C" const char* nrms_version(void) { return "nrms_hip 0.3 (gfx950, fp32 MFMA; nrms_v0 + nrms_v1 topologies)"; }

@@ -37,6 +37,8 @@ struct NTArgs {
     const float* wrow;        // E_DCTX: [M] pooling weights
     const float* dout;        // E_DCTX: [n_seq, N]
     int S;                    // E_DCTX: rows per sequence
+    Dropout drop;             // optional epilogue dropout (thresh != 0), Philox site 1, element index
+                              // g*N + n -- only the output-projection topology (nrms_v1) needs it here
 };
 
 // LDS image of a K-stage: [rows][4 chunks of 16 B], the chunk index XOR-swizzled per 4-row group

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
                 } else {
                     v += wr * dout_row[n];
                 }
+                if (a.drop.thresh != 0u)
+                    v *= dropout_scale1(a.drop.seed, 1u, (uint64_t)(g * a.N + n), a.drop.thresh, a.drop.inv_keep);
                 a.C[g * a.ldc + n] = v;
             }
         }

@@ -17,6 +17,7 @@ struct AddFwdArgs {
     float* wout;           // [M]   or null
     float* out;            // [n_seq, d]
     int S, d;
+    const uint8_t* mask;   // optional [M]: masked_fill(mask == 0, -1e9) before the softmax (nrms_v1.py:100-101)
 };
 
 template <int NT>
@@ -62,6 +63,9 @@ __global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
     const int spb = rows_valid / a.S;
     if (tid < spb) {
         float* s = sc + tid * a.S;
+        if (a.mask != nullptr)
+            for (int i = 0; i < a.S; ++i)
+                if (a.mask[(long)row0 + tid * a.S + i] == 0) s[i] = -1e9f;
         float mx = -1e30f;
         for (int i = 0; i < a.S; ++i) mx = fmaxf(mx, s[i]);
         float sum = 0.f;
@@ -92,13 +96,13 @@ static int launch_addfwd_inst(const AddFwdArgs& a, hipStream_t stream) {
 }
 
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
-                       const float* q_vec, float* T, float* wout, float* out, hipStream_t stream) {
+                       const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, hipStream_t stream) {
     if (n_seq <= 0) return NRMS_OK;
     AddFwdArgs a{};
     a.g.M = n_seq * S; a.g.N = q; a.g.K = d;
     a.g.rows_per_tile = (NT_BM / S) * S;
     a.g.A = ctx; a.g.lda = d; a.g.W = w_add; a.g.bias = b_add;
-    a.qv = q_vec; a.T = T; a.wout = wout; a.out = out; a.S = S; a.d = d;
+    a.qv = q_vec; a.T = T; a.wout = wout; a.out = out; a.S = S; a.d = d; a.mask = mask;
     if (q <= 32) return launch_addfwd_inst<2>(a, stream);
     if (q <= 64) return launch_addfwd_inst<4>(a, stream);
     if (q <= 128) return launch_addfwd_inst<8>(a, stream);
@@ -119,7 +123,7 @@ constexpr int ROWS_MAXQ = 256;
 
 __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
     int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w, const float* T, float* ds,
-    float* dq_partial) {
+    float* dq_partial, const uint8_t* mask) {
     __shared__ float dsl[ROWS_WPB][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long gw = (long)blockIdx.x * ROWS_WPB + wave, nw = (long)gridDim.x * ROWS_WPB;
@@ -140,7 +144,9 @@ __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
         }
         const float my_w = lane < S ? w[seq * S + lane] : 0.f;
         const float dot = wave_sum(my_w * my_dw);
-        const float my_ds = my_w * (my_dw - dot);
+        float my_ds = my_w * (my_dw - dot);
+        // masked_fill passes no gradient to the overwritten scores
+        if (mask != nullptr && lane < S && mask[seq * S + lane] == 0) my_ds = 0.f;
         if (lane < S) ds[seq * S + lane] = my_ds;
         dsl[wave][lane] = my_ds;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -184,13 +190,14 @@ int addattn_bwd_rows_waves(int n_seq) {
 }
 
 int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w,
-                            const float* T, float* ds, float* dq_partial, float* dq, hipStream_t stream) {
+                            const float* T, float* ds, float* dq_partial, float* dq, const uint8_t* mask,
+                            hipStream_t stream) {
     if (n_seq <= 0) return NRMS_OK;
     const int waves = addattn_bwd_rows_waves(n_seq);
     {
         TimingScope ts("addattn_bwd_rows", stream);
         hipLaunchKernelGGL(addattn_bwd_rows_kernel, dim3(waves / ROWS_WPB), dim3(64 * ROWS_WPB), 0, stream, n_seq, S,
-                           d, q, ctx, dout, w, T, ds, dq_partial);
+                           d, q, ctx, dout, w, T, ds, dq_partial, mask);
         int rc = check_launch("addattn_bwd_rows");
         if (rc) return rc;
     }

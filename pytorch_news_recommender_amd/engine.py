@@ -18,19 +18,52 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from .synth import ENCODERS, param_names
+from .synth import ENCODERS
 
 
 @dataclass(frozen=True)
 class ModelDims:
     n_words: int
     word_embed_size: int
-    num_attention_heads: int
+    num_attention_heads: int            # user-encoder heads (and news-encoder heads unless news_heads is set)
     query_vector_dim: int
+    news_heads: int = 0                 # nrms_v1: config.title_heads_num for the news encoder
+    output_proj: bool = False           # nrms_v1 topology: MHSA ends in output_linear (W_O)
+    style: str = "v0"                   # parameter naming: "v0" (model/nrms_v0.py) or "v1" (model/nrms_v1.py)
+
+    def heads(self, enc):
+        return self.news_heads if (enc == "news_encoder" and self.news_heads) else self.num_attention_heads
+
+
+def role_names(style: str, output_proj: bool):
+    """Ordered (parameter name, encoder, role) triples; the order IS the flat-buffer order."""
+    out = []
+    if style == "v0":
+        out.append(("news_encoder.word_embedding.0.weight", "news_encoder", "table"))
+    else:
+        out.append(("news_encoder.word_embedding.weight", "news_encoder", "table"))
+    for enc in ENCODERS:
+        if style == "v0":
+            a = enc + ".multihead_self_attention."
+            qkv = [a + "W_Q", a + "W_K", a + "W_V"]
+            wo = a + "W_O"
+            qv = enc + ".additive_attention.attention_query_vector"
+        else:
+            a = enc + ".multi_head_self_attention."
+            qkv = [a + "linear_layers.%d" % i for i in range(3)]
+            wo = a + "output_linear"
+            qv = enc + ".additive_attention.query_vector"
+        out += [(n + ".weight", enc, r) for n, r in zip(qkv, ("wq", "wk", "wv"))]
+        out += [(n + ".bias", enc, r) for n, r in zip(qkv, ("bq", "bk", "bv"))]
+        if output_proj:
+            out += [(wo + ".weight", enc, "wo"), (wo + ".bias", enc, "bo")]
+        out += [(enc + ".additive_attention.linear.weight", enc, "wa"),
+                (enc + ".additive_attention.linear.bias", enc, "ba"), (qv, enc, "qv")]
+    return out
 
 
 class FlatLayout:
-    """Offsets (in floats) of the 19 reference-named tensors inside the flat buffer.
+    """Offsets (in floats) of the reference-named tensors inside the flat buffer.
     W_Q/W_K/W_V (and their biases) are adjacent so the kernels see one [3d, d] matrix."""
 
     def __init__(self, dims: ModelDims):
@@ -39,41 +72,25 @@ class FlatLayout:
             raise ValueError("word_embed_size and query_vector_dim must be multiples of 4")
         self.dims = dims
         self.entries = {}
+        self.blocks = {enc: {} for enc in ENCODERS}
+        shapes = {"table": (V, d), "wq": (d, d), "wk": (d, d), "wv": (d, d), "bq": (d,), "bk": (d,), "bv": (d,),
+                  "wo": (d, d), "bo": (d,), "wa": (q, d), "ba": (q,), "qv": (q,)}
         off = 0
-        for name in param_names():
-            if name.endswith("word_embedding.0.weight"):
-                shp = (V, d)
-            elif name.endswith("attention_query_vector") or name.endswith("linear.bias"):
-                shp = (q,)
-            elif name.endswith("linear.weight"):
-                shp = (q, d)
-            elif name.endswith(".bias"):
-                shp = (d,)
-            else:
-                shp = (d, d)
+        for name, enc, role in role_names(dims.style, dims.output_proj):
+            shp = shapes[role]
             n = 1
-            for s in shp:
-                n *= s
+            for x in shp:
+                n *= x
             self.entries[name] = (off, shp, n)
+            self.blocks[enc][role] = off
             off += n
         self.total = off
-        self.blocks = {}
+        self.names = list(self.entries)
         for enc in ENCODERS:
-            a = enc + ".multihead_self_attention."
-            b = enc + ".additive_attention."
-            self.blocks[enc] = {
-                "w_qkv": self.entries[a + "W_Q.weight"][0],
-                "b_qkv": self.entries[a + "W_Q.bias"][0],
-                "w_add": self.entries[b + "linear.weight"][0],
-                "b_add": self.entries[b + "linear.bias"][0],
-                "q_vec": self.entries[b + "attention_query_vector"][0],
-            }
-            # adjacency the kernels rely on
-            assert self.entries[a + "W_K.weight"][0] == self.blocks[enc]["w_qkv"] + d * d
-            assert self.entries[a + "W_V.weight"][0] == self.blocks[enc]["w_qkv"] + 2 * d * d
-            assert self.entries[a + "W_K.bias"][0] == self.blocks[enc]["b_qkv"] + d
-            assert self.entries[a + "W_V.bias"][0] == self.blocks[enc]["b_qkv"] + 2 * d
-        self.table = self.entries["news_encoder.word_embedding.0.weight"][0]
+            b = self.blocks[enc]
+            assert b["wk"] == b["wq"] + d * d and b["wv"] == b["wq"] + 2 * d * d      # adjacency the kernels rely on
+            assert b["bk"] == b["bq"] + d and b["bv"] == b["bq"] + 2 * d
+        self.table = self.blocks["news_encoder"]["table"]
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         off, shp, n = self.entries[name]
@@ -105,69 +122,74 @@ class NRMSEngine:
             self._bufs[key] = t
         return t
 
-    def _desc(self, n_seq, seq_len, vocab, p_drop, seed):
+    def _desc(self, enc, n_seq, seq_len, p_embed=0.0, p_ctx=0.0, seed=0, mask_mode=0):
         d = self.dims
-        return _lib.EncoderDesc(n_seq=n_seq, seq_len=seq_len, d_model=d.word_embed_size,
-                                n_heads=d.num_attention_heads, q_dim=d.query_vector_dim, vocab=vocab,
-                                p_drop=float(p_drop), precision=_lib.NRMS_PRECISION_FP32, seed=int(seed))
+        return _lib.EncoderDesc(n_seq=n_seq, seq_len=seq_len, d_model=d.word_embed_size, n_heads=d.heads(enc),
+                                q_dim=d.query_vector_dim, vocab=d.n_words if enc == "news_encoder" else 0,
+                                p_drop_embed=float(p_embed), p_drop_ctx=float(p_ctx),
+                                precision=_lib.NRMS_PRECISION_FP32, use_output_proj=int(d.output_proj),
+                                mask_mode=int(mask_mode), reserved=0, seed=int(seed))
 
-    def _weights(self, flat, enc):
+    def _ptrs(self, cls, flat, enc):
         b = self.layout.blocks[enc]
         base = flat.data_ptr()
-        table = base + 4 * self.layout.table if enc == "news_encoder" else None
-        return _lib.EncoderWeights(table=table, w_qkv=base + 4 * b["w_qkv"], b_qkv=base + 4 * b["b_qkv"],
-                                   w_add=base + 4 * b["w_add"], b_add=base + 4 * b["b_add"],
-                                   q_vec=base + 4 * b["q_vec"])
+        p = lambda role: (base + 4 * b[role]) if role in b else None
+        return cls(table=p("table"), w_qkv=p("wq"), b_qkv=p("bq"), w_o=p("wo"), b_o=p("bo"), w_add=p("wa"),
+                   b_add=p("ba"), q_vec=p("qv"))
+
+    def _weights(self, flat, enc):
+        return self._ptrs(_lib.EncoderWeights, flat, enc)
 
     def _grads(self, gflat, enc):
-        b = self.layout.blocks[enc]
-        base = gflat.data_ptr()
-        table = base + 4 * self.layout.table if enc == "news_encoder" else None
-        return _lib.EncoderGrads(table=table, w_qkv=base + 4 * b["w_qkv"], b_qkv=base + 4 * b["b_qkv"],
-                                 w_add=base + 4 * b["w_add"], b_add=base + 4 * b["b_add"],
-                                 q_vec=base + 4 * b["q_vec"])
+        return self._ptrs(_lib.EncoderGrads, gflat, enc)
 
     def _acts(self, tag, M, need_bwd, gather=False):
         d, q = self.dims.word_embed_size, self.dims.query_vector_dim
         x = self._buf(tag + ".x", M * d) if gather else None
         qkv = self._buf(tag + ".qkv", M * 3 * d)
+        attn = self._buf(tag + ".attn", M * d) if self.dims.output_proj else None
         ctx = self._buf(tag + ".ctx", M * d)
         t = self._buf(tag + ".t", M * q) if need_bwd else None
         w = self._buf(tag + ".w", M) if need_bwd else None
-        acts = _lib.EncoderActs(x=None if x is None else x.data_ptr(), qkv=qkv.data_ptr(), ctx=ctx.data_ptr(),
-                                t=None if t is None else t.data_ptr(), w=None if w is None else w.data_ptr())
-        return acts
+        dp = lambda z: None if z is None else z.data_ptr()
+        return _lib.EncoderActs(x=dp(x), qkv=dp(qkv), attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w))
 
     # ---- news vectors for an arbitrary list of titles (a-5, a-9 get_news_vector) ---------
-    def encode_titles(self, flat, ids, out=None, p_drop=0.0, seed=0, save=False, tag="news", chunk_titles=32768):
+    def encode_titles(self, flat, ids, out=None, p_embed=0.0, p_ctx=0.0, seed=0, save=False, tag="news",
+                      chunk_titles=32768, mask=None, mask_mode=0):
         """ids [N, L] int64 on the device -> news vectors [N, d].  With save=True (training) the
-        activations are kept for encode_titles_bwd and the call is not chunked."""
+        activations are kept for the backward and the call is not chunked.  mask [N, L] uint8 with
+        mask_mode bits (1 = attention pairs, 2 = pooling) gives nrms_v1's masked primitives."""
         N, L = ids.shape
         d = self.dims.word_embed_size
         if out is None:
             out = torch.empty(N, d, dtype=torch.float32, device=self.device)
         ids = ids.contiguous()
+        if mask is not None:
+            mask = mask.contiguous()
         w = self._weights(flat, "news_encoder")
         step = N if save else min(N, chunk_titles)
         for s0 in range(0, N, max(step, 1)):
             n = min(step, N - s0)
-            desc = self._desc(n, L, self.dims.n_words, p_drop, seed)
+            desc = self._desc("news_encoder", n, L, p_embed, p_ctx, seed, mask_mode if mask is not None else 0)
             acts = self._acts(tag, n * L, save, gather=True)
-            rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), C.c_void_p(ids[s0:].data_ptr()), None,
+            mp = None if mask is None else C.c_void_p(mask[s0:].data_ptr())
+            rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), C.c_void_p(ids[s0:].data_ptr()), None, mp,
                                            C.byref(acts), C.c_void_p(out[s0:].data_ptr()), _stream())
             _lib.check(rc, "nrms_encoder_fwd(news)")
         return out
 
-    def encode_users(self, flat, news_vectors, out=None, save=False, tag="user"):
+    def encode_users(self, flat, news_vectors, out=None, save=False, tag="user", mask=None, mask_mode=0):
         """news_vectors [B, H, d] -> user vectors [B, d] (a-6, a-9 get_user_vector)."""
         B, H, d = news_vectors.shape
         if out is None:
             out = torch.empty(B, d, dtype=torch.float32, device=self.device)
         w = self._weights(flat, "user_encoder")
-        desc = self._desc(B, H, 0, 0.0, 0)
+        desc = self._desc("user_encoder", B, H, mask_mode=mask_mode if mask is not None else 0)
         acts = self._acts(tag, B * H, save)
         rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), None, C.c_void_p(news_vectors.data_ptr()),
-                                       C.byref(acts), C.c_void_p(out.data_ptr()), _stream())
+                                       _lib.ptr(None if mask is None else mask.contiguous()), C.byref(acts),
+                                       C.c_void_p(out.data_ptr()), _stream())
         _lib.check(rc, "nrms_encoder_fwd(user)")
         return out
 
@@ -181,7 +203,8 @@ class NRMSEngine:
         return out
 
     # ---- full model forward (a-8) -------------------------------------------------------
-    def forward(self, flat, hist_ids, cand_ids, cand_mask, training, p_drop=0.0, seed=0):
+    def forward(self, flat, hist_ids, cand_ids, cand_mask, training, p_drop=0.0, seed=0, user_mask=None,
+                user_mask_mode=0):
         """hist_ids [B,H,L], cand_ids [B,C,L] int64 and cand_mask [B,C] uint8 (or None) on the
         device -> scores [B,C].  training=True keeps what backward() needs."""
         B, H, L = hist_ids.shape
@@ -193,17 +216,21 @@ class NRMSEngine:
         ids[B * H:].copy_(cand_ids.reshape(B * Cn, L))
         nv = self._buf("news_vec", N * d)[:N * d].view(N, d)
         p = p_drop if training else 0.0
-        self.encode_titles(flat, ids, out=nv, p_drop=p, seed=seed, save=training)
+        p_embed = 0.0 if self.dims.style == "v1" else p        # nrms_v1 has no embedding dropout (nrms_v1.py:159-161)
+        self.encode_titles(flat, ids, out=nv, p_embed=p_embed, p_ctx=p, seed=seed, save=training)
         hist = nv[:B * H].view(B, H, d)
         cand = nv[B * H:].view(B, Cn, d)
         user = self._buf("user_vec", B * d)[:B * d].view(B, d)
-        self.encode_users(flat, hist, out=user, save=training)
+        self.encode_users(flat, hist, out=user, save=training, mask=user_mask, mask_mode=user_mask_mode)
         if cand_mask is not None:
             cand_mask = cand_mask.contiguous()
         scores = torch.empty(B, Cn, dtype=torch.float32, device=self.device)
         self.click_scores(cand, user, cand_mask, out=scores)
         if training:
-            self._saved = dict(B=B, H=H, C=Cn, L=L, ids=ids, nv=nv, user=user, mask=cand_mask, p=p, seed=seed)
+            self._saved = dict(B=B, H=H, C=Cn, L=L, ids=ids, nv=nv, user=user, mask=cand_mask, p=p, p_embed=p_embed,
+                               seed=seed, user_mask=user_mask, user_mask_mode=user_mask_mode if user_mask is not None else 0)
+        else:
+            self._saved = None
         return scores
 
     def ce_loss(self, scores, grad_scale=None, want_grad=True):
@@ -217,6 +244,27 @@ class NRMSEngine:
                                            C.c_float(gs), _stream())
         _lib.check(rc, "nrms_ce_loss_fwd_bwd")
         return loss_sum, dscores
+
+    def _bwd_workspace(self, *descs):
+        nbytes = max(self.lib.nrms_encoder_bwd_workspace_bytes(C.byref(d)) for d in descs)
+        return self._buf("bwd_ws", (nbytes + 3) // 4)
+
+    def encode_users_backward(self, flat, gflat, news_vectors, dout, dx=None, tag="user", mask=None, mask_mode=0):
+        """Backward of encode_users(save=True): accumulates the user-encoder parameter gradients into
+        gflat and returns d(news_vectors) [B, H, d]."""
+        B, H, d = news_vectors.shape
+        if dx is None:
+            dx = torch.empty(B * H, d, dtype=torch.float32, device=self.device)
+        desc = self._desc("user_encoder", B, H, mask_mode=mask_mode if mask is not None else 0)
+        ws = self._bwd_workspace(desc)
+        w, g = self._weights(flat, "user_encoder"), self._grads(gflat, "user_encoder")
+        acts = self._acts(tag, B * H, True)
+        rc = self.lib.nrms_encoder_bwd(C.byref(desc), C.byref(w), None, _lib.ptr(news_vectors),
+                                       _lib.ptr(None if mask is None else mask.contiguous()), C.byref(acts),
+                                       _lib.ptr(dout.contiguous()), C.byref(g), _lib.ptr(dx), _lib.ptr(ws),
+                                       C.c_size_t(ws.numel() * 4), _stream())
+        _lib.check(rc, "nrms_encoder_bwd(user)")
+        return dx[:B * H].view(B, H, d)
 
     # ---- full model backward ------------------------------------------------------------
     def backward(self, flat, gflat, dscores):
@@ -238,20 +286,14 @@ class NRMSEngine:
                                            _stream())
         _lib.check(rc, "nrms_click_score_bwd")
         # user encoder: its input gradient lands directly in the history rows of d(news vectors)
-        desc_u = self._desc(B, H, 0, 0.0, 0)
-        desc_n = self._desc(N, L, self.dims.n_words, sv["p"], sv["seed"])
-        ws_bytes = max(self.lib.nrms_encoder_bwd_workspace_bytes(C.byref(desc_u)),
-                       self.lib.nrms_encoder_bwd_workspace_bytes(C.byref(desc_n)))
-        ws = self._buf("bwd_ws", (ws_bytes + 3) // 4)
-        wu, gu = self._weights(flat, "user_encoder"), self._grads(gflat, "user_encoder")
-        acts_u = self._acts("user", B * H, True)
-        rc = self.lib.nrms_encoder_bwd(C.byref(desc_u), C.byref(wu), None, _lib.ptr(hist), C.byref(acts_u),
-                                       _lib.ptr(duser), C.byref(gu), _lib.ptr(dnv), _lib.ptr(ws),
-                                       C.c_size_t(ws.numel() * 4), _stream())
-        _lib.check(rc, "nrms_encoder_bwd(user)")
+        desc_u = self._desc("user_encoder", B, H, mask_mode=sv["user_mask_mode"])
+        desc_n = self._desc("news_encoder", N, L, sv["p_embed"], sv["p"], sv["seed"])
+        ws = self._bwd_workspace(desc_u, desc_n)
+        self.encode_users_backward(flat, gflat, hist.view(B, H, d), duser, dx=dnv, mask=sv["user_mask"],
+                                   mask_mode=sv["user_mask_mode"])
         wn, gn = self._weights(flat, "news_encoder"), self._grads(gflat, "news_encoder")
         acts_n = self._acts("news", N * L, True, gather=True)
-        rc = self.lib.nrms_encoder_bwd(C.byref(desc_n), C.byref(wn), _lib.ptr(sv["ids"]), None, C.byref(acts_n),
+        rc = self.lib.nrms_encoder_bwd(C.byref(desc_n), C.byref(wn), _lib.ptr(sv["ids"]), None, None, C.byref(acts_n),
                                        _lib.ptr(dnv), C.byref(gn), None, _lib.ptr(ws),
                                        C.c_size_t(ws.numel() * 4), _stream())
         _lib.check(rc, "nrms_encoder_bwd(news)")

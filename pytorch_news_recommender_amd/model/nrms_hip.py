@@ -19,7 +19,6 @@ import torch.nn as nn
 
 from .. import _lib
 from ..engine import FlatLayout, ModelDims, NRMSEngine
-from ..synth import param_names
 
 
 class _MultiHeadSelfAttentionParams(nn.Module):
@@ -103,16 +102,13 @@ class Model(nn.Module):
         super().__init__()
         self.config = config
         table = _load_table(config, pretrained_word_embedding)
-        self.news_encoder = _NewsEncoderParams(config, table)
-        self.user_encoder = _UserEncoderParams(config)
         V, d = table.shape
         if d != config.word_embed_size:
             raise ValueError("embedding width %d != config.word_embed_size %d" % (d, config.word_embed_size))
-        self._dims = ModelDims(n_words=int(V), word_embed_size=int(d),
-                               num_attention_heads=int(config.num_attention_heads),
-                               query_vector_dim=int(config.query_vector_dim))
+        self._build_modules(config, table)
+        self._dims = self._make_dims(config, int(V), int(d))
         self._layout = FlatLayout(self._dims)
-        self._names = param_names()
+        self._names = self._layout.names
         named = dict(self.named_parameters())
         missing = [n for n in self._names if n not in named]
         assert not missing and len(named) == len(self._names), (missing, sorted(named))
@@ -121,6 +117,15 @@ class Model(nn.Module):
         self._opt = None
         self._calls = 0
         self._flatten(table.device)
+
+    # ---- topology hooks (overridden by model/nrms_v1_hip.py) ---------------------------------------
+    def _build_modules(self, config, table):
+        self.news_encoder = _NewsEncoderParams(config, table)
+        self.user_encoder = _UserEncoderParams(config)
+
+    def _make_dims(self, config, V, d):
+        return ModelDims(n_words=V, word_embed_size=d, num_attention_heads=int(config.num_attention_heads),
+                         query_vector_dim=int(config.query_vector_dim))
 
     # ---- flat parameter storage ----------------------------------------------------------
     def _flatten(self, device):
@@ -191,7 +196,9 @@ class Model(nn.Module):
         dev = self._prepare()
         ids = torch.as_tensor(news).to(dev, dtype=torch.int64)
         p_drop = float(self.config.dropout) if self.training else 0.0
-        return self._engine.encode_titles(self._flat, ids, p_drop=p_drop, seed=self._next_seed() if p_drop else 0)
+        p_embed = 0.0 if self._dims.style == "v1" else p_drop
+        return self._engine.encode_titles(self._flat, ids, p_embed=p_embed, p_ctx=p_drop,
+                                          seed=self._next_seed() if p_drop else 0)
 
     def get_user_vector(self, clicked_news_vector):
         """[B, H, d] -> [B, d] (nrms_v0.py:291-299); inference only."""

@@ -175,3 +175,26 @@ def make_eval_impressions(n_imp: int, max_cand: int, seed: int = 7, min_cand: in
         scores[i, :n] = s
         labels.append(y)
     return scores, labels
+
+
+def make_params_v1(shape: Shape, seed: int = 0):
+    """Parameters with nrms_v1's names (model/nrms_v1.py:54-55,87,115): linear_layers.{0,1,2},
+    output_linear (W_O), query_vector; same initial distributions as make_params."""
+    from .engine import ModelDims, FlatLayout      # local import: engine imports this module
+    dims = ModelDims(shape.n_words, shape.word_embed_size, shape.num_attention_heads, shape.query_vector_dim,
+                     output_proj=True, style="v1")
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, (_, shp, _) in FlatLayout(dims).entries.items():
+        if name.endswith("word_embedding.weight"):
+            t = rng.normal(0.0, 0.4, size=shp)
+            t[0] = 0.0
+        elif name.endswith("query_vector"):
+            t = rng.uniform(-0.1, 0.1, size=shp)
+        elif name.endswith(".weight"):
+            bound = np.sqrt(6.0 / (shp[0] + shp[1]))
+            t = rng.uniform(-bound, bound, size=shp)
+        else:
+            t = rng.uniform(-1.0, 1.0, size=shp) / np.sqrt(shape.word_embed_size)
+        out[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return out

@@ -1,0 +1,113 @@
+"""nrms_v1 semantics on the HIP path (SURVEY 8a rows a-3', a-4 mask variant, f-3): output projection
+W_O, per-encoder head counts (6 news / 10 user), dropout only after the attention block, pairwise
+attention mask and masked additive attention.  The oracle's v1 primitives are pinned to the
+reference's own classes by fixture g3 (tests/test_oracle_golden.py::test_g3_v1_semantics)."""
+import numpy as np
+import pytest
+import torch
+
+from pytorch_news_recommender_amd import synth
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL, GRAD_RTOL, GRAD_ATOL = 1e-5, 1e-3, 2e-6
+
+
+def make_v1(shape, params, title_heads, dropout=0.0):
+    from pytorch_news_recommender_amd.config import Config
+    from pytorch_news_recommender_amd.model.nrms_v1_hip import Model
+    cfg = Config("nrms_v1")
+    cfg.__nrms__()
+    cfg.word_embed_size, cfg.query_vector_dim = shape.word_embed_size, shape.query_vector_dim
+    cfg.num_attention_heads, cfg.title_heads_num = shape.num_attention_heads, title_heads
+    cfg.dropout = dropout
+    m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    return m.to("cuda")
+
+
+def fwd_bwd(model, batch):
+    model.zero_grad()
+    scores = model({k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()})
+    loss = torch.nn.functional.cross_entropy(scores, torch.zeros(len(scores), dtype=torch.long, device=scores.device))
+    loss.backward()
+    return scores.detach().cpu().numpy(), float(loss.detach()), {n: p.grad.cpu().numpy() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("shape,title_heads", [
+    (synth.Shape(n_words=800, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                 batch_size=6, history_len=50, n_candidates=5, n_words_title=20), 6),       # res_logs.md:4 setup: L=20, h=6/10
+    (synth.Shape(n_words=90, word_embed_size=48, num_attention_heads=4, query_vector_dim=16,
+                 batch_size=3, history_len=5, n_candidates=2, n_words_title=7), 2),
+])
+def test_v1_model_forward_backward_vs_oracle(shape, title_heads):
+    from oracle import nrms_oracle as orc
+    params = synth.make_params_v1(shape, seed=71)
+    batch = synth.make_batch(shape, seed=72, ragged=True, min_title=1, mask_some_candidates=True)
+    model = make_v1(shape, params, title_heads).train()
+    assert len(list(model.parameters())) == 23
+    scores, loss, grads = fwd_bwd(model, batch)
+    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(orc.v1_to_v0_names(params), batch, shape.num_attention_heads,
+                                                      news_heads=title_heads, embed_dropout=False)
+    np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
+    assert abs(loss - o_loss) < SCORE_TOL
+    o_grads = {k: v for k, v in o_grads.items()}
+    back = {v: k for k, v in zip(params.keys(), orc.v1_to_v0_names(params).keys())}
+    for v0name, g in o_grads.items():
+        np.testing.assert_allclose(grads[back[v0name]], g, rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=v0name)
+
+
+def test_v1_dropout_only_after_attention_replayed():
+    from oracle import nrms_oracle as orc
+    shape = synth.Shape(n_words=300, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
+                        batch_size=5, history_len=8, n_candidates=3, n_words_title=10)
+    params = synth.make_params_v1(shape, seed=81)
+    batch = synth.make_batch(shape, seed=82, ragged=True, min_title=2)
+    model = make_v1(shape, params, title_heads=3, dropout=0.25).train()
+    scores, loss, grads = fwd_bwd(model, batch)
+    sv = model.engine._saved
+    assert sv["p_embed"] == 0.0 and sv["p"] == 0.25
+    n_titles = shape.batch_size * (shape.history_len + shape.n_candidates)
+    keep_ctx = model.engine.dropout_keep_mask(sv["seed"], 1, n_titles * shape.n_words_title, 0.25).cpu().view(
+        n_titles, shape.n_words_title, shape.word_embed_size)
+    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(orc.v1_to_v0_names(params), batch, shape.num_attention_heads,
+                                                      p_drop=0.25, keep={"ctx": keep_ctx}, news_heads=3,
+                                                      embed_dropout=False)
+    np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
+    back = {v: k for k, v in zip(params.keys(), orc.v1_to_v0_names(params).keys())}
+    for v0name, g in o_grads.items():
+        np.testing.assert_allclose(grads[back[v0name]], g, rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=v0name)
+
+
+@pytest.mark.parametrize("mask_mode", [1, 2, 3])
+def test_masked_primitives_forward_backward(mask_mode):
+    """User encoder with v1's masks (UserEncoder.forward(news_vectors, attn_masks), nrms_v1.py:208-211):
+    pairwise attention mask (bit 0) and masked additive attention (bit 1), including a fully masked
+    sequence (uniform attention over its real positions, as masked_fill(-1e9) gives)."""
+    from oracle import nrms_oracle as orc
+    shape = synth.Shape(n_words=50, word_embed_size=300, num_attention_heads=6, query_vector_dim=200,
+                        batch_size=5, history_len=11, n_candidates=2, n_words_title=4)
+    params = synth.make_params_v1(shape, seed=31)
+    model = make_v1(shape, params, title_heads=6)
+    eng, flat = model.engine, model._flat
+    rng = np.random.default_rng(5)
+    X = rng.normal(0, 0.5, size=(5, 11, 300)).astype(np.float32)
+    lens = np.array([11, 7, 1, 0, 9])
+    mask = (np.arange(11)[None, :] < lens[:, None]).astype(np.uint8)
+    dout = rng.normal(0, 1, size=(5, 300)).astype(np.float32)
+    Xd, md, dd = (torch.from_numpy(a).cuda() for a in (X, mask, dout))
+    out = eng.encode_users(flat, Xd, save=True, mask=md, mask_mode=mask_mode)
+    gflat = torch.zeros_like(flat)
+    dx = eng.encode_users_backward(flat, gflat, Xd, dd, mask=md, mask_mode=mask_mode)
+    # oracle
+    p = orc.to_torch(orc.v1_to_v0_names(params), requires_grad=True)
+    Xt = torch.from_numpy(X).requires_grad_(True)
+    o = orc.user_encoder(p, Xt, shape.num_attention_heads, mask=torch.from_numpy(mask), mask_mode=mask_mode)
+    (o * torch.from_numpy(dout)).sum().backward()
+    np.testing.assert_allclose(out.cpu().numpy(), o.detach().numpy(), rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(dx.cpu().numpy(), Xt.grad.numpy(), rtol=GRAD_RTOL, atol=GRAD_ATOL)
+    back = {v: k for k, v in zip(params.keys(), orc.v1_to_v0_names(params).keys())}
+    for v0name, t in p.items():
+        if not v0name.startswith("user_encoder") or t.grad is None:
+            continue
+        got = model._layout.view(gflat, back[v0name]).cpu().numpy()
+        np.testing.assert_allclose(got, t.grad.numpy(), rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=v0name)

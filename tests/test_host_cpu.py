@@ -37,30 +37,30 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # field order / widths of the POD structs (x86-64 SysV): desc = 8 x 4 bytes + u64
-    assert ctypes.sizeof(_lib.EncoderDesc) == 40
-    assert _lib.EncoderDesc.seed.offset == 32
-    assert ctypes.sizeof(_lib.EncoderWeights) == 48 and ctypes.sizeof(_lib.EncoderGrads) == 48
-    assert ctypes.sizeof(_lib.EncoderActs) == 40
+    assert ctypes.sizeof(_lib.EncoderDesc) == 56
+    assert _lib.EncoderDesc.seed.offset == 48
+    assert ctypes.sizeof(_lib.EncoderWeights) == 64 and ctypes.sizeof(_lib.EncoderGrads) == 64
+    assert ctypes.sizeof(_lib.EncoderActs) == 48
 
 
 def test_argument_validation_without_gpu():
     """Validation runs before any HIP call, so bad descriptors are reported on a CPU-only host."""
     lib = _lib.load()
-    bad = _lib.EncoderDesc(n_seq=1, seq_len=65, d_model=300, n_heads=10, q_dim=200, vocab=0, p_drop=0.0,
-                           precision=0, seed=0)
+    bad = _lib.EncoderDesc(n_seq=1, seq_len=65, d_model=300, n_heads=10, q_dim=200, vocab=0, p_drop_embed=0.0,
+                           p_drop_ctx=0.0, precision=0, seed=0)
     assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(bad)) == 0
     assert b"seq_len" in lib.nrms_last_error()
-    ok = _lib.EncoderDesc(n_seq=28160, seq_len=30, d_model=300, n_heads=10, q_dim=200, vocab=45800, p_drop=0.2,
-                          precision=0, seed=1)
+    ok = _lib.EncoderDesc(n_seq=28160, seq_len=30, d_model=300, n_heads=10, q_dim=200, vocab=45800,
+                          p_drop_embed=0.2, p_drop_ctx=0.2, precision=0, seed=1)
     need = lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(ok))
     M = 28160 * 30
     assert need >= 4 * (M * 300 + M * 900 + M)           # dctx + dqkv + ds at least
     w = _lib.EncoderWeights()
     acts = _lib.EncoderActs()
-    rc = lib.nrms_encoder_fwd(ctypes.byref(ok), ctypes.byref(w), None, None, ctypes.byref(acts), None, None)
+    rc = lib.nrms_encoder_fwd(ctypes.byref(ok), ctypes.byref(w), None, None, None, ctypes.byref(acts), None, None)
     assert rc == -1 and b"null" in lib.nrms_last_error()
-    odd = _lib.EncoderDesc(n_seq=1, seq_len=5, d_model=30, n_heads=10, q_dim=200, vocab=0, p_drop=0.0,
-                           precision=0, seed=0)
+    odd = _lib.EncoderDesc(n_seq=1, seq_len=5, d_model=30, n_heads=10, q_dim=200, vocab=0, p_drop_embed=0.0,
+                           p_drop_ctx=0.0, precision=0, seed=0)
     assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(odd)) == 0      # d_model % 4 != 0
     with pytest.raises(_lib.NrmsError):
         _lib.check(-1, "unit test")
@@ -72,6 +72,11 @@ def test_flat_layout_adjacency_and_names():
     assert lay.total == 14402600
     assert list(lay.entries) == synth.param_names()
     assert len(lay.entries) == 19
+    v1 = FlatLayout(ModelDims(n_words=45800, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                              news_heads=6, output_proj=True, style="v1"))
+    assert len(v1.entries) == 23 and v1.total == lay.total + 2 * (300 * 300 + 300)
+    assert "user_encoder.multi_head_self_attention.output_linear.weight" in v1.entries
+    assert "news_encoder.additive_attention.query_vector" in v1.entries
     for off, shp, n in lay.entries.values():
         assert off % 4 == 0 and n == int(np.prod(shp))
     flat = torch.arange(lay.total, dtype=torch.float32)
