@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--users-per-gpu", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-users", type=int, default=64)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"])
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.init_process_group(os.environ.get("NRMS_DIST_BACKEND"))
@@ -117,6 +118,7 @@ def main():
     cfg.batch_size = B
     cfg.dropout = 0.2
     cfg.learning_rate = 1e-3
+    cfg.precision = args.precision
     params = synth.make_params(shape, seed=0)
     model = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})

@@ -33,7 +33,11 @@ extern "C" {
 #define NRMS_ELAUNCH      -2   /* HIP launch or runtime error */
 #define NRMS_EWORKSPACE   -3   /* workspace too small */
 
-#define NRMS_PRECISION_FP32 0  /* f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32): exact fp32 */
+#define NRMS_PRECISION_FP32   0 /* f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32): exact fp32 */
+#define NRMS_PRECISION_BF16X3 1 /* dense projections as split-bf16: x = hi + lo, hi*hi + hi*lo + lo*hi on
+                                   v_mfma_f32_16x16x32_bf16, fp32 accumulate (~2^-16 relative per product);
+                                   attention, softmaxes, pooling, loss, optimizer and all HBM tensors stay fp32 */
+#define NRMS_PRECISION_BF16   2 /* same kernels, hi*hi only: plain bf16 inputs, fp32 accumulate */
 
 /* One self-attention + additive-pooling encoder pass over n_seq sequences of seq_len rows.
  * vocab > 0  : news encoder -- input is `ids` [n_seq, seq_len] int64, rows gathered from
@@ -92,6 +96,7 @@ typedef struct nrms_encoder_acts {
     float* ctx;            /* [M, d]   head-concatenated attention output AFTER dropout */
     float* t;              /* [M, q]   tanh(linear(ctx))            (nrms_v0.py:108) */
     float* w;              /* [M]      additive-attention softmax weights (nrms_v0.py:110-112) */
+    void*  scratch;        /* nrms_encoder_fwd_scratch_bytes(desc) bytes (bf16 weight planes); NULL if that is 0 */
 } nrms_encoder_acts;
 
 /* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V
@@ -99,6 +104,7 @@ typedef struct nrms_encoder_acts {
  * Replaces model/nrms_v0.py:13-23,46-76,100-126,154-176,188-199 and, with use_output_proj / mask_mode,
  * model/nrms_v1.py:15-105,128-162,208-211.
  * out: [n_seq, d].  Exactly one of ids / x is used (by desc->vocab). */
+size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc);
 int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w,
                      const int64_t* ids, const float* x, const uint8_t* mask /* [n_seq, seq_len] or NULL */,
                      const nrms_encoder_acts* acts, float* out, void* stream);

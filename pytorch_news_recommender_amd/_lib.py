@@ -12,6 +12,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libnrms_hip.so")
 
 NRMS_PRECISION_FP32 = 0
+NRMS_PRECISION_BF16X3 = 1
+NRMS_PRECISION_BF16 = 2
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
 
 
 class NrmsError(RuntimeError):
@@ -38,7 +41,7 @@ class EncoderGrads(C.Structure):
 
 class EncoderActs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("qkv", C.c_void_p), ("attn", C.c_void_p), ("ctx", C.c_void_p),
-                ("t", C.c_void_p), ("w", C.c_void_p)]
+                ("t", C.c_void_p), ("w", C.c_void_p), ("scratch", C.c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/nrms_hip.h declares.
@@ -46,6 +49,7 @@ SIGNATURES = {
     "nrms_encoder_fwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(EncoderActs), C.c_void_p, C.c_void_p]),
     "nrms_encoder_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
+    "nrms_encoder_fwd_scratch_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "nrms_encoder_bwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(EncoderActs), C.c_void_p, C.POINTER(EncoderGrads), C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -44,6 +44,8 @@ class Config(object):
         self.require_improvement = 10000
         self.warm_up_steps = 500
         self.warm_up = False
+        # HIP path only: "fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections) or "bf16"
+        self.precision = "fp32"
 
     def __nrms__(self):
         self.query_vector_dim = 200

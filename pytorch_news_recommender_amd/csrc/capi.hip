@@ -79,14 +79,38 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d->p_drop_embed >= 0.f && d->p_drop_embed < 1.f && d->p_drop_ctx >= 0.f && d->p_drop_ctx < 1.f,
                  "%s: dropout probabilities must be in [0,1)", who);
     NRMS_REQUIRE(d->vocab > 0 || d->p_drop_embed == 0.f, "%s: embedding dropout needs the news encoder (vocab>0)", who);
-    NRMS_REQUIRE(d->precision == NRMS_PRECISION_FP32, "%s: unsupported precision %d", who, d->precision);
+    NRMS_REQUIRE(d->precision >= NRMS_PRECISION_FP32 && d->precision <= NRMS_PRECISION_BF16,
+                 "%s: unsupported precision %d", who, d->precision);
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
     return NRMS_OK;
 }
 
+// NT GEMM in the precision the descriptor asks for
+static int nt_gemm(const nrms_encoder_desc* d, int amode, int emode, const NTArgs& g, void* wplanes, hipStream_t s,
+                   const char* name) {
+    if (d->precision == NRMS_PRECISION_FP32) return launch_gemm_nt(amode, emode, g, s, name);
+    return launch_gemm_nt_bf16(amode, emode, d->precision == NRMS_PRECISION_BF16X3 ? 3 : 1, g, wplanes, s, name);
+}
+
+static int tn_gemm(const nrms_encoder_desc* d, const TNArgs& t, hipStream_t s, const char* name) {
+    if (d->precision == NRMS_PRECISION_FP32) return launch_gemm_tn(t, s, name);
+    return launch_gemm_tn_bf16(d->precision == NRMS_PRECISION_BF16X3 ? 3 : 1, t, s, name);
+}
+
+static size_t wplane_bytes(const nrms_encoder_desc* d) {
+    if (d->precision == NRMS_PRECISION_FP32) return 0;
+    const int dm = d->d_model, q = d->q_dim;
+    size_t m = gemm_nt_bf16_wplane_bytes(3 * dm, dm);                    // QKV
+    const size_t a = gemm_nt_bf16_wplane_bytes(dm, 3 * dm);             // dX
+    const size_t b = gemm_nt_bf16_wplane_bytes(dm, q);                  // dctx
+    if (a > m) m = a;
+    if (b > m) m = b;
+    return align_up(m, 256);
+}
+
 struct BwdWorkspace {
-    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, total;   // byte offsets
+    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, total;   // byte offsets
 };
 
 static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
@@ -106,6 +130,7 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     const size_t p3 = d->use_output_proj ? gemm_tn_workspace_floats((int)M, (int)dm, (int)dm, nullptr) : 0;
     w.tn_partial = take(p1 > p2 ? (p1 > p3 ? p1 : p3) : (p2 > p3 ? p2 : p3));
     w.dq_partial = take((size_t)addattn_bwd_rows_waves(d->n_seq) * q);
+    w.wplanes = take(wplane_bytes(d) / sizeof(float));
     w.total = off;
     return w;
 }
@@ -147,7 +172,8 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     g.M = M; g.N = 3 * d; g.K = d; g.rows_per_tile = NT_BM;
     g.A = xin; g.lda = d;
     g.W = w->w_qkv; g.bias = w->b_qkv; g.C = acts->qkv; g.ldc = 3 * d;
-    rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "qkv_proj_fwd");
+    NRMS_REQUIRE(wplane_bytes(desc) == 0 || acts->scratch != nullptr, "encoder_fwd: acts.scratch is required for this precision");
+    rc = nt_gemm(desc, A_PLAIN, E_STORE, g, acts->scratch, s, "qkv_proj_fwd");
     if (rc) return rc;
     // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
     // concatenation, the output projection follows and carries the dropout in its epilogue.
@@ -158,11 +184,16 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
         NTArgs o{};
         o.M = M; o.N = d; o.K = d; o.rows_per_tile = NT_BM;
         o.A = acts->attn; o.lda = d; o.W = w->w_o; o.bias = w->b_o; o.C = acts->ctx; o.ldc = d; o.drop = drop_c;
-        rc = launch_gemm_nt(A_PLAIN, E_STORE, o, s, "out_proj_fwd");
+        rc = nt_gemm(desc, A_PLAIN, E_STORE, o, acts->scratch, s, "out_proj_fwd");
         if (rc) return rc;
     }
     return launch_addattn_fwd(desc->n_seq, S, d, q, acts->ctx, w->w_add, w->b_add, w->q_vec, acts->t, acts->w, out,
                               pmask, s);
+}
+
+extern "C" size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc) {
+    if (validate_desc(desc, "encoder_fwd_scratch_bytes")) return 0;
+    return wplane_bytes(desc);
 }
 
 extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc) {
@@ -210,6 +241,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     float* wo_t = (float*)(base + L.wo_t);
     float* tn_partial = (float*)(base + L.tn_partial);
     float* dq_partial = (float*)(base + L.dq_partial);
+    void* wplanes = (void*)(base + L.wplanes);
 
     // 1. pooling rows: ds, d(q_vec)
     rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
@@ -227,7 +259,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         g.W = wadd_t; g.C = dctx; g.ldc = d;
         g.wrow = acts->w; g.dout = dout; g.S = S;
         if (wo) g.drop = drop_c;
-        rc = launch_gemm_nt(A_DZ, E_DCTX, g, s, "dctx_bwd");
+        rc = nt_gemm(desc, A_DZ, E_DCTX, g, wplanes, s, "dctx_bwd");
         if (rc) return rc;
     }
     // 3. d(w_add), d(b_add) = dZ^T [ctx | 1]
@@ -236,7 +268,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         t.M = M; t.N = q; t.K = d; t.amode = A_DZ;
         t.ds = ds; t.qv = w->q_vec; t.T = acts->t; t.B = acts->ctx; t.ldb = d;
         t.dW = grads->w_add; t.dbias = grads->b_add; t.partial = tn_partial;
-        rc = launch_gemm_tn(t, s, "dwadd_bwd");
+        rc = tn_gemm(desc, t, s, "dwadd_bwd");
         if (rc) return rc;
     }
     const float* dattn_in = dctx;
@@ -246,14 +278,14 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         t.M = M; t.N = d; t.K = d; t.amode = A_PLAIN;
         t.A = dctx; t.lda = d; t.B = acts->attn; t.ldb = d;
         t.dW = grads->w_o; t.dbias = grads->b_o; t.partial = tn_partial;
-        rc = launch_gemm_tn(t, s, "dwo_bwd");
+        rc = tn_gemm(desc, t, s, "dwo_bwd");
         if (rc) return rc;
         rc = launch_transpose(w->w_o, wo_t, d, d, s);
         if (rc) return rc;
         NTArgs g{};
         g.M = M; g.N = d; g.K = d; g.rows_per_tile = NT_BM;
         g.A = dctx; g.lda = d; g.W = wo_t; g.C = dattn; g.ldc = d;
-        rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "dattn_bwd");
+        rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "dattn_bwd");
         if (rc) return rc;
         dattn_in = dattn;
     }
@@ -268,7 +300,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN;
         t.A = dqkv; t.lda = 3 * d; t.B = xin; t.ldb = d;
         t.dW = grads->w_qkv; t.dbias = grads->b_qkv; t.partial = tn_partial;
-        rc = launch_gemm_tn(t, s, "dwqkv_bwd");
+        rc = tn_gemm(desc, t, s, "dwqkv_bwd");
         if (rc) return rc;
     }
     // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: dX goes to the (now dead)
@@ -280,7 +312,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         g.M = M; g.N = d; g.K = 3 * d; g.rows_per_tile = NT_BM;
         g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t;
         g.C = gather ? dctx : dx; g.ldc = d;
-        rc = launch_gemm_nt(A_PLAIN, E_STORE, g, s, "dx_bwd");
+        rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "dx_bwd");
         if (rc) return rc;
     }
     if (gather) rc = launch_scatter_dropout((long)M, d, ids, dctx, drop_e, grads->table, s);

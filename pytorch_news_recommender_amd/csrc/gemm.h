@@ -148,6 +148,55 @@ __device__ __forceinline__ void gemm_nt_mainloop(const NTArgs& a, int row0, int 
     }
 }
 
+// ---- NT epilogue: accumulator tile -> HBM in whole rows.
+// The MFMA C layout puts one column per lane (16 lanes = one 64-byte row fragment), so storing from
+// registers costs one scalar store instruction per accumulator register and touches four partial
+// lines each: store-issue-bound (it capped the bf16 kernels at 21 % MFMA utilisation).  Instead each
+// wave bounces 8 rows at a time through a private LDS strip [8][16 NT + 8] (stride = 8 mod 16 floats:
+// conflict-free ds_write_b32) and writes float4 per lane = contiguous 1 KiB per wave-instruction,
+// applying bias / w_s*dout / dropout (ONE Philox call per float4) on the way out.
+//   wave_lds: 8 * (16 NT + 8) floats private to the calling wave.
+template <int NT, int EMODE>
+__device__ __forceinline__ void nt_epilogue(const NTArgs& g, const f32x4 (&acc)[2][NT], int row0, int rows_valid,
+                                            int col0, int wave, int lane, float* wave_lds) {
+    constexpr int S = 16 * NT + 8;
+    constexpr int F4_ROW = 4 * NT;               // float4 per row of the tile
+    const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // rows 4 kq + 2 h + b of the 16-row tile -> strip row 2 kq + b
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wave_lds[(2 * kq + b) * S + 16 * nt + r16] = acc[mt][nt][2 * h + b];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int idx = lane; idx < 8 * F4_ROW; idx += 64) {
+                const int sr = idx / F4_ROW, c4 = idx - sr * F4_ROW;
+                const int rl = 32 * wave + 16 * mt + 4 * (sr >> 1) + 2 * h + (sr & 1);
+                const int n = col0 + 4 * c4;
+                if (rl >= rows_valid || n >= g.N) continue;
+                const long gr = (long)row0 + rl;
+                f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + sr * S + 4 * c4);
+                if (EMODE == E_STORE) {
+                    if (g.bias != nullptr) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                } else {
+                    v += g.wrow[gr] * *reinterpret_cast<const f32x4*>(g.dout + (gr / g.S) * (long)g.N + n);
+                }
+                if (g.drop.thresh != 0u)
+                    v *= dropout_scale4(g.drop.seed, 1u, (uint64_t)(gr * g.N + n) >> 2, g.drop.thresh, g.drop.inv_keep);
+                *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + n) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 int launch_gemm_nt(int amode, int emode, const NTArgs& a, hipStream_t stream, const char* name);
 
 // ---------------------------------------------------------------------------------------
@@ -169,6 +218,13 @@ size_t gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int launch_gemm_tn(const TNArgs& a, hipStream_t stream, const char* name);
 
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t stream);
+
+// gemm_bf16.hip: same NT contract with split-bf16 (npass 3) / bf16 (npass 1) MFMAs; wplanes is a
+// scratch of gemm_nt_bf16_wplane_bytes(N, K) bytes that receives the bf16 planes of W
+int launch_gemm_nt_bf16(int amode, int emode, int npass, const NTArgs& a, void* wplanes, hipStream_t stream,
+                        const char* name);
+size_t gemm_nt_bf16_wplane_bytes(int N, int K);
+int launch_gemm_tn_bf16(int npass, const TNArgs& a, hipStream_t stream, const char* name);
 
 // embed.hip
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,

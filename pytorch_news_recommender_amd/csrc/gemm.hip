@@ -29,37 +29,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
 
     gemm_nt_mainloop<NT, AMODE>(a, row0, rows_valid, col0, acc, lds);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int rl = 32 * wave + 16 * mt + 4 * kq + reg;
-            if (rl >= rows_valid) continue;
-            const long g = (long)row0 + rl;
-            float wr = 0.f;
-            const float* dout_row = nullptr;
-            if (EMODE == E_DCTX) {
-                wr = a.wrow[g];
-                dout_row = a.dout + (g / a.S) * (long)a.N;
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = col0 + 16 * nt + r16;
-                if (n >= a.N) continue;
-                float v = acc[mt][nt][reg];
-                if (EMODE == E_STORE) {
-                    if (a.bias != nullptr) v += a.bias[n];
-                } else {
-                    v += wr * dout_row[n];
-                }
-                if (a.drop.thresh != 0u)
-                    v *= dropout_scale1(a.drop.seed, 1u, (uint64_t)(g * a.N + n), a.drop.thresh, a.drop.inv_keep);
-                a.C[g * a.ldc + n] = v;
-            }
-        }
-    }
+    // the stage buffers are dead now: reuse them as the per-wave epilogue strips
+    static_assert(4 * 8 * (16 * NT + 8) <= 2 * (NT_BM + 16 * NT) * NT_BK, "epilogue strips must fit the stage buffers");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    nt_epilogue<NT, EMODE>(a, acc, row0, rows_valid, col0, wave, lane, lds + wave * 8 * (16 * NT + 8));
 }
 
 template <int NT, int AMODE, int EMODE>

@@ -1,0 +1,540 @@
+// Split-bf16 ("bf16x3") and plain bf16 GEMMs on v_mfma_f32_16x16x32_bf16.
+//
+// fp32 operands are written x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits
+// together).  A product is accumulated in fp32 as  hi_a*hi_b + hi_a*lo_b + lo_a*hi_b  (the lo*lo term,
+// 2^-16 relative, is dropped): three bf16 MFMAs per fp32-equivalent MFMA step, i.e. 3/16 of the
+// f32-MFMA time at ~2^-16 relative error per product -- two orders of magnitude inside the 1e-4 score
+// bar.  NPASS = 1 keeps only hi*hi (plain bf16 inputs, fp32 accumulate).
+//
+// HBM tensors stay fp32: weights are split ONCE per call into bf16 hi/lo planes by split_planes_kernel
+// (they are < 1.1 MB and re-read by every row tile), activations are split while being staged into
+// LDS (16 VALU ops per thread and stage, negligible next to the gather/RNG work that was moved out of
+// the GEMM waves -- see gemm.h).
+#include "gemm.h"
+
+namespace nrms {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BF_BM = 256;            // rows per workgroup tile (8 waves x 32)
+constexpr int BF_BK = 32;             // bf16 elements of K per stage = one 64-byte row segment
+constexpr int BF_THREADS = 512;
+constexpr int BF_ROWB = 64;           // bytes per staged row (32 bf16)
+
+struct Split8 { bf16x8 hi, lo; };
+
+__device__ __forceinline__ Split8 split8(const f32x4& u, const f32x4& v) {
+    Split8 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h0 = (__bf16)u[i], h1 = (__bf16)v[i];
+        s.hi[i] = h0; s.hi[4 + i] = h1;
+        s.lo[i] = (__bf16)(u[i] - (float)h0);
+        s.lo[4 + i] = (__bf16)(v[i] - (float)h1);
+    }
+    return s;
+}
+
+// w [rows, cols] fp32  ->  hi, lo [rows, cols_p] bf16, zero padded to cols_p (a multiple of 32)
+__global__ void split_planes_kernel(const float* w, int rows, int cols, int cols_p, __bf16* hi, __bf16* lo) {
+    const long total = (long)rows * cols_p;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols_p;
+        const int c = (int)(i - r * cols_p);
+        const float x = c < cols ? w[r * cols + c] : 0.f;
+        const __bf16 h = (__bf16)x;
+        hi[i] = h;
+        lo[i] = (__bf16)(x - (float)h);
+    }
+}
+
+int launch_split_planes(const float* w, int rows, int cols, int cols_p, void* hi, void* lo, hipStream_t stream) {
+    const long total = (long)rows * cols_p;
+    TimingScope ts("split_planes", stream);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256)), dim3(256), 0, stream,
+                       w, rows, cols, cols_p, (__bf16*)hi, (__bf16*)lo);
+    return check_launch("split_planes");
+}
+
+struct BFArgs {
+    NTArgs g;                 // same meaning as the fp32 kernel; g.W is unused
+    const __bf16* whi;        // [N, Kp] bf16, zero padded
+    const __bf16* wlo;        // [N, Kp] (NPASS == 3)
+    int Kp;
+};
+
+// LDS stage image (bytes): A_hi [256][64] | A_lo | B_hi [16 NT][64] | B_lo ; 16-byte chunk index
+// XOR-swizzled per 4-row group exactly as in the fp32 loop (same 64-byte rows, same read pattern).
+template <int NT, int AMODE, int EMODE, int NPASS>
+__global__ __launch_bounds__(BF_THREADS, 2) void gemm_nt_bf16_kernel(BFArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int P = NPASS == 3 ? 2 : 1;
+    constexpr int A_PLANE = BF_BM * BF_ROWB, B_PLANE = NT * 16 * BF_ROWB;
+    constexpr int STAGE = P * (A_PLANE + B_PLANE);
+    constexpr int B_CH = NT * 16 * 4;                      // 16-byte chunks per B plane
+    constexpr int B_IT = (B_CH + BF_THREADS - 1) / BF_THREADS;
+    const NTArgs& g = a.g;
+
+    const int n_ct = (g.N + NT * 16 - 1) / (NT * 16);
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int rt = (jb / n_ct) * 8 + xcd;
+    const int row0 = rt * g.rows_per_tile;
+    if (row0 >= g.M) return;
+    const int rows_valid = min(g.rows_per_tile, g.M - row0);
+    const int col0 = (jb % n_ct) * (NT * 16);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int chunk = tid & 3;
+
+    // ---- staging slots: A rows (tid>>2) and (tid>>2)+128, chunk tid&3 (8 consecutive k)
+    const float* arow[2];
+    float ascale[2];
+    int a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 2) + 128 * i;
+        const long gr = (long)row0 + r;
+        arow[i] = nullptr;
+        ascale[i] = 0.f;
+        a_off[i] = (r * 4 + (chunk ^ nt_swz(r))) * 16;
+        if (r < rows_valid) {
+            if (AMODE == A_PLAIN) arow[i] = g.A + gr * g.lda;
+            else { arow[i] = g.T + gr * (long)g.K; ascale[i] = g.ds[gr]; }
+        }
+    }
+    long b_src[B_IT];
+    int b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + BF_THREADS * i;
+        const int r = idx >> 2, n = col0 + r;
+        b_src[i] = (idx < B_CH && n < g.N) ? (long)n * a.Kp + 8 * chunk : -1;
+        b_off[i] = idx < B_CH ? (r * 4 + (chunk ^ nt_swz(r))) * 16 : -1;
+    }
+    const int fsw = (kq ^ nt_swz(r16)) * 16;
+    const int a_frag0 = (32 * wave + r16) * BF_ROWB + fsw;
+    const int a_frag1 = (32 * wave + 16 + r16) * BF_ROWB + fsw;
+    const int b_frag = P * A_PLANE + r16 * BF_ROWB + fsw;
+
+    f32x4 av[2][2];
+    bf16x8 bh[B_IT], bl[B_IT];
+    auto load_stage = [&](int k0) {
+        const int k = k0 + chunk * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+            if (arow[i] != nullptr) {
+                if (k < g.K) u = *reinterpret_cast<const f32x4*>(arow[i] + k);
+                if (k + 4 < g.K) v = *reinterpret_cast<const f32x4*>(arow[i] + k + 4);
+                if (AMODE == A_DZ) {
+                    if (k < g.K) u = ascale[i] * *reinterpret_cast<const f32x4*>(g.qv + k) * (1.0f - u * u);
+                    if (k + 4 < g.K) v = ascale[i] * *reinterpret_cast<const f32x4*>(g.qv + k + 4) * (1.0f - v * v);
+                }
+            }
+            av[i][0] = u; av[i][1] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            bh[i] = z; bl[i] = z;
+            if (b_src[i] >= 0) {
+                bh[i] = *reinterpret_cast<const bf16x8*>(a.whi + b_src[i] + k0);
+                if (NPASS == 3) bl[i] = *reinterpret_cast<const bf16x8*>(a.wlo + b_src[i] + k0);
+            }
+        }
+    };
+    auto store_stage = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const Split8 s = split8(av[i][0], av[i][1]);
+            *reinterpret_cast<bf16x8*>(st + a_off[i]) = s.hi;
+            if (NPASS == 3) *reinterpret_cast<bf16x8*>(st + A_PLANE + a_off[i]) = s.lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            if (b_off[i] >= 0) {
+                *reinterpret_cast<bf16x8*>(st + P * A_PLANE + b_off[i]) = bh[i];
+                if (NPASS == 3) *reinterpret_cast<bf16x8*>(st + P * A_PLANE + B_PLANE + b_off[i]) = bl[i];
+            }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // K stages are walked from a per-workgroup starting point (wrapping): workgroups that run in
+    // lockstep then read DIFFERENT 64-byte column slices of the weight planes at any moment instead
+    // of all hitting the same L2 lines (the sum over K is order-independent up to fp32 rounding).
+    const int n_stage = (g.K + BF_BK - 1) / BF_BK;
+    const int s0 = (int)(blockIdx.x % (unsigned)n_stage);
+    auto stage_k = [&](int s) { int t = s + s0; if (t >= n_stage) t -= n_stage; return t * BF_BK; };
+    load_stage(stage_k(0));
+    store_stage(smem);
+    __syncthreads();
+    for (int s = 0; s < n_stage; ++s) {
+        const char* cur = smem + (s & 1) * STAGE;
+        if (s + 1 < n_stage) load_stage(stage_k(s + 1));
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(cur + a_frag0);
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(cur + a_frag1);
+        bf16x8 al0, al1;
+        if (NPASS == 3) {
+            al0 = *reinterpret_cast<const bf16x8*>(cur + A_PLANE + a_frag0);
+            al1 = *reinterpret_cast<const bf16x8*>(cur + A_PLANE + a_frag1);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(cur + b_frag + nt * 16 * BF_ROWB);
+            if (NPASS == 3) {
+                const bf16x8 blo = *reinterpret_cast<const bf16x8*>(cur + b_frag + B_PLANE + nt * 16 * BF_ROWB);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, blo, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, blo, acc[1][nt], 0, 0, 0);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bhi, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bhi, acc[1][nt], 0, 0, 0);
+            }
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bhi, acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bhi, acc[1][nt], 0, 0, 0);
+        }
+        if (s + 1 < n_stage) store_stage(smem + ((s + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+
+    // ---- epilogue (same C layout as the fp32 16x16x4 MFMA); the stage buffers are dead: reuse them
+    // (launch_bf_inst sizes the dynamic LDS as max(2 stages, 8 waves x strip))
+    nt_epilogue<NT, EMODE>(g, acc, row0, rows_valid, col0, wave, lane,
+                           reinterpret_cast<float*>(smem) + wave * 8 * (16 * NT + 8));
+}
+
+template <int NT, int AMODE, int EMODE, int NPASS>
+static int launch_bf_inst(const BFArgs& a, hipStream_t stream, const char* name) {
+    constexpr int P = NPASS == 3 ? 2 : 1;
+    constexpr size_t stage_bytes = 2 * (size_t)P * (BF_BM + NT * 16) * BF_ROWB;
+    constexpr size_t strip_bytes = (size_t)8 * 8 * (16 * NT + 8) * sizeof(float);
+    constexpr size_t lds_bytes = stage_bytes > strip_bytes ? stage_bytes : strip_bytes;
+    const void* fn = (const void*)gemm_nt_bf16_kernel<NT, AMODE, EMODE, NPASS>;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    dim3 grid(cdiv(cdiv(a.g.M, a.g.rows_per_tile), 8) * 8 * cdiv(a.g.N, NT * 16));
+    TimingScope ts(name, stream);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<NT, AMODE, EMODE, NPASS>), grid, dim3(BF_THREADS), lds_bytes, stream, a);
+    return check_launch(name);
+}
+
+template <int AMODE, int EMODE, int NPASS>
+static int launch_bf_mode(const BFArgs& a, hipStream_t stream, const char* name) {
+    const int N = a.g.N;
+    // widest tile that wastes least; 19 (304) and 13 (208) cover d = 300, 3d = 900, q = 200
+    int nt = 19;
+    long best = -1;
+    const int cand[4] = {19, 13, 8, 4};
+    for (int i = 0; i < 4; ++i) {
+        const long pad = (long)cdiv(N, cand[i] * 16) * cand[i] * 16;
+        if (best < 0 || pad < best) { best = pad; nt = cand[i]; }
+    }
+    switch (nt) {
+        case 19: return launch_bf_inst<19, AMODE, EMODE, NPASS>(a, stream, name);
+        case 13: return launch_bf_inst<13, AMODE, EMODE, NPASS>(a, stream, name);
+        case 8: return launch_bf_inst<8, AMODE, EMODE, NPASS>(a, stream, name);
+        default: return launch_bf_inst<4, AMODE, EMODE, NPASS>(a, stream, name);
+    }
+}
+
+// W planes: hi at wplanes, lo at wplanes + N*Kp (bf16 elements); Kp = K rounded up to 32.
+int launch_gemm_nt_bf16(int amode, int emode, int npass, const NTArgs& g_in, void* wplanes, hipStream_t stream,
+                        const char* name) {
+    if (g_in.M <= 0) return NRMS_OK;
+    if ((g_in.K & 3) != 0) { set_error("%s: K=%d must be a multiple of 4", name, g_in.K); return NRMS_EINVAL; }
+    BFArgs a;
+    a.g = g_in;
+    a.g.rows_per_tile = BF_BM;
+    a.Kp = cdiv(g_in.K, BF_BK) * BF_BK;
+    a.whi = (const __bf16*)wplanes;
+    a.wlo = a.whi + (long)g_in.N * a.Kp;
+    int rc = launch_split_planes(g_in.W, g_in.N, g_in.K, a.Kp, wplanes, (void*)(a.whi + (long)g_in.N * a.Kp), stream);
+    if (rc) return rc;
+    if (npass == 3) {
+        if (amode == A_PLAIN && emode == E_STORE) return launch_bf_mode<A_PLAIN, E_STORE, 3>(a, stream, name);
+        if (amode == A_DZ && emode == E_DCTX) return launch_bf_mode<A_DZ, E_DCTX, 3>(a, stream, name);
+    } else {
+        if (amode == A_PLAIN && emode == E_STORE) return launch_bf_mode<A_PLAIN, E_STORE, 1>(a, stream, name);
+        if (amode == A_DZ && emode == E_DCTX) return launch_bf_mode<A_DZ, E_DCTX, 1>(a, stream, name);
+    }
+    set_error("%s: unsupported bf16 gemm mode %d/%d", name, amode, emode);
+    return NRMS_EINVAL;
+}
+
+// =======================================================================================
+// TN in split-bf16: dW[N,K(+1)] = sum_m A'[m,N]^T B'[m,K(+ones)]
+// =======================================================================================
+// Same decomposition as the fp32 kernel (gemm.hip): 8 waves = 4 (N) x 2 (K), NTN x NTK tiles of
+// 16x16 per wave, 32 rows of M per stage, M split over workgroups into partial slabs.  Here a stage
+// is exactly ONE v_mfma_f32_16x16x32_bf16 k-step: the staged fp32 rows are split into bf16 hi/lo
+// planes [32 m][cols] (row-major, as they arrive), and both MFMA operands -- which need 8
+// consecutive m for one column -- come from ds_read_b64_tr_b16, the hardware transposed read (a
+// 16-lane group reads 4 rows x 16 columns and returns them column-major).
+//   k <-> m assignment inside a stage: lane group kq (= lane>>4) takes m = 4 kq + j (j < 4) and
+//   16 + 4 kq + (j-4): then one 32-lane half reads rows {0..7} (or {16..23}) and, with a row pitch
+//   of 8*odd dwords, its 32 eight-byte accesses tile the 64 banks exactly (conflict-free).
+constexpr int TB_WN = 4, TB_WK = 2, TB_MC = 32, TB_THREADS = 512;
+constexpr int TB_AW = 320, TB_BW = 160;                 // staged columns (max)
+constexpr int TB_PA = 336, TB_PB = 176;                 // row pitch in bf16 elements: 168 / 88 dwords = 8*odd
+constexpr int TB_A_PLANE = TB_MC * TB_PA * 2, TB_B_PLANE = TB_MC * TB_PB * 2;     // bytes
+constexpr int TB_A_IT = (TB_MC * TB_AW / 4) / TB_THREADS;                           // 5
+constexpr int TB_B_IT = (TB_MC * TB_BW / 4 + TB_THREADS - 1) / TB_THREADS;          // 3
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct TNGeomB { int n_tiles, k_tiles, n_wg, k_wg, n_tpw, k_tpw; };
+
+static TNGeomB tnb_geom(int N, int K) {
+    TNGeomB g;
+    g.n_tiles = cdiv(N, 16);
+    g.k_tiles = cdiv(K + 1, 16);
+    g.n_wg = cdiv(g.n_tiles, TB_WN * 5);
+    g.k_wg = cdiv(g.k_tiles, TB_WK * 5);
+    while (g.n_wg * g.k_wg < 32 && (32 % (g.n_wg * g.k_wg)) != 0 && g.n_wg < g.n_tiles) ++g.n_wg;
+    g.n_tpw = cdiv(g.n_tiles, g.n_wg);
+    g.k_tpw = cdiv(g.k_tiles, g.k_wg);
+    return g;
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* plane, int pitch_b, int col0, int lane) {
+    // operand fragment for columns col0..col0+15: element j of lane (c = lane&15, kq = lane>>4)
+    // = image[m(kq, j)][col0 + c]
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int q = l16 >> 2, p = l16 & 3;
+    const char* a0 = plane + (4 * kq + q) * pitch_b + (col0 + 4 * p) * 2;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 16 * pitch_b));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = lo4[i]; r[4 + i] = hi4[i]; }
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int AMODE, int NTN, int NTK, int NPASS>
+__global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, TNGeomB g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int P = NPASS == 3 ? 2 : 1;
+    constexpr int STAGE = P * (TB_A_PLANE + TB_B_PLANE);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    const int out_wgs = g.n_wg * g.k_wg;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = jb % out_wgs;
+    const int split = (jb / out_wgs) * 8 + xcd;
+    if (split >= a.splits) return;
+    const int bx = tile % g.n_wg, by = tile / g.n_wg;
+    const int nt0 = bx * g.n_tpw, nt_cnt = max(0, min(g.n_tpw, g.n_tiles - nt0));
+    const int kt0 = by * g.k_tpw, kt_cnt = max(0, min(g.k_tpw, g.k_tiles - kt0));
+    const int n_q = (nt_cnt + TB_WN - 1) / TB_WN, k_h = (kt_cnt + TB_WK - 1) / TB_WK;
+    const int my_nt0 = wn * n_q, my_ntn = max(0, min(n_q, nt_cnt - my_nt0));
+    const int my_kt0 = wk * k_h, my_ktn = max(0, min(k_h, kt_cnt - my_kt0));
+    const int n_cols = nt_cnt * 16, k_cols = kt_cnt * 16;
+    const int ncol0 = nt0 * 16, kcol0 = kt0 * 16;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+
+    int a_r[TB_A_IT], a_c[TB_A_IT], b_r[TB_B_IT], b_c[TB_B_IT];
+#pragma unroll
+    for (int i = 0; i < TB_A_IT; ++i) {
+        const int sl = tid + TB_THREADS * i;
+        a_r[i] = sl / (TB_AW / 4);
+        a_c[i] = (sl - a_r[i] * (TB_AW / 4)) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < TB_B_IT; ++i) {
+        const int sl = tid + TB_THREADS * i;
+        b_r[i] = sl / (TB_BW / 4);
+        b_c[i] = (sl - b_r[i] * (TB_BW / 4)) * 4;
+        if (b_r[i] >= TB_MC) { b_r[i] = 0; b_c[i] = TB_BW; }
+    }
+
+    f32x4 av[TB_A_IT], bv[TB_B_IT];
+    auto load_stage = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < TB_A_IT; ++i) {
+            const long m = (long)m0 + a_r[i];
+            const int n = ncol0 + a_c[i];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end && a_c[i] < n_cols && n < a.N) {
+                if (AMODE == A_PLAIN) {
+                    v = *reinterpret_cast<const f32x4*>(a.A + m * a.lda + n);
+                } else {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(a.T + m * (long)a.N + n);
+                    v = a.ds[m] * *reinterpret_cast<const f32x4*>(a.qv + n) * (1.0f - t * t);
+                }
+            }
+            av[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < TB_B_IT; ++i) {
+            const long m = (long)m0 + b_r[i];
+            const int k = kcol0 + b_c[i];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end && b_c[i] < k_cols) {
+                if (k < a.K) v = *reinterpret_cast<const f32x4*>(a.B + m * a.ldb + k);
+                else if (k == a.K) v[0] = 1.0f;
+            }
+            bv[i] = v;
+        }
+    };
+    auto split4 = [](const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)v[e];
+            hi[e] = h;
+            lo[e] = (__bf16)(v[e] - (float)h);
+        }
+    };
+    auto store_stage = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < TB_A_IT; ++i) {
+            bf16x4 hi, lo;
+            split4(av[i], hi, lo);
+            const int off = (a_r[i] * TB_PA + a_c[i]) * 2;
+            *reinterpret_cast<bf16x4*>(st + off) = hi;
+            if (NPASS == 3) *reinterpret_cast<bf16x4*>(st + TB_A_PLANE + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < TB_B_IT; ++i) {
+            if (b_c[i] >= TB_BW) continue;
+            bf16x4 hi, lo;
+            split4(bv[i], hi, lo);
+            const int off = P * TB_A_PLANE + (b_r[i] * TB_PB + b_c[i]) * 2;
+            *reinterpret_cast<bf16x4*>(st + off) = hi;
+            if (NPASS == 3) *reinterpret_cast<bf16x4*>(st + TB_B_PLANE + off) = lo;
+        }
+    };
+
+    f32x4 acc[NTN][NTK];
+#pragma unroll
+    for (int i = 0; i < NTN; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NTK; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int n_stage = (m_end - m_begin + TB_MC - 1) / TB_MC;
+    if (n_stage > 0) {
+        load_stage(m_begin);
+        store_stage(smem);
+    }
+    __syncthreads();
+    for (int s = 0; s < n_stage; ++s) {
+        const char* As = smem + (s & 1) * STAGE;
+        const char* Bs = As + P * TB_A_PLANE;
+        if (s + 1 < n_stage) load_stage(m_begin + (s + 1) * TB_MC);
+        bf16x8 bh[NTK], bl[NTK];
+#pragma unroll
+        for (int jj = 0; jj < NTK; ++jj) {
+            bh[jj] = tr_frag(Bs, TB_PB * 2, (my_kt0 + jj) * 16, lane);
+            if (NPASS == 3) bl[jj] = tr_frag(Bs + TB_B_PLANE, TB_PB * 2, (my_kt0 + jj) * 16, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < NTN; ++i) {
+            const bf16x8 ah = tr_frag(As, TB_PA * 2, (my_nt0 + i) * 16, lane);
+            bf16x8 al;
+            if (NPASS == 3) al = tr_frag(As + TB_A_PLANE, TB_PA * 2, (my_nt0 + i) * 16, lane);
+#pragma unroll
+            for (int jj = 0; jj < NTK; ++jj) {
+                if (NPASS == 3) {
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[jj], acc[i][jj], 0, 0, 0);
+                }
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[jj], acc[i][jj], 0, 0, 0);
+            }
+        }
+        if (s + 1 < n_stage) store_stage(smem + ((s + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+    const long n_pad = (long)g.n_tiles * 16, k_pad = (long)g.k_tiles * 16;
+    float* slab = a.partial + (long)split * n_pad * k_pad;
+#pragma unroll
+    for (int i = 0; i < NTN; ++i) {
+        if (i >= my_ntn) continue;
+#pragma unroll
+        for (int jj = 0; jj < NTK; ++jj) {
+            if (jj >= my_ktn) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long n = ncol0 + (my_nt0 + i) * 16 + 4 * kq + reg;
+                const long k = kcol0 + (my_kt0 + jj) * 16 + r16;
+                slab[n * k_pad + k] = acc[i][jj][reg];
+            }
+        }
+    }
+}
+
+__global__ void tnb_reduce_kernel(const float* partial, int splits, int N, int K, long n_pad, long k_pad, float* dW,
+                                  float* dbias) {
+    const long total = (long)N * (K + 1);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long n = idx / (K + 1), k = idx - n * (K + 1);
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += partial[(long)sp * n_pad * k_pad + n * k_pad + k];
+        if (k < K) dW[n * K + k] += s;
+        else if (dbias != nullptr) dbias[n] += s;
+    }
+}
+
+static int tnb_splits(int M, const TNGeomB& g) {
+    const int out_wgs = g.n_wg * g.k_wg;
+    int splits = 8 * (out_wgs <= 32 ? 32 / out_wgs : 1);
+    const int max_splits = cdiv(M, 8 * TB_MC);
+    if (splits > max_splits) splits = max_splits;
+    return splits < 1 ? 1 : splits;
+}
+
+// same partial-slab workspace as the fp32 kernel (gemm_tn_workspace_floats covers it)
+int launch_gemm_tn_bf16(int npass, const TNArgs& a_in, hipStream_t stream, const char* name) {
+    if (a_in.M <= 0) return NRMS_OK;
+    TNArgs a = a_in;
+    const TNGeomB g = tnb_geom(a.N, a.K);
+    if ((a.N & 3) != 0 || (a.K & 3) != 0) { set_error("%s: N,K must be multiples of 4", name); return NRMS_EINVAL; }
+    a.splits = tnb_splits(a.M, g);
+    a.rows_per_split = cdiv(cdiv(a.M, a.splits), TB_MC) * TB_MC;
+    a.splits = cdiv(a.M, a.rows_per_split);
+    dim3 grid(cdiv(a.splits, 8) * 8 * g.n_wg * g.k_wg);
+    const int n_q = cdiv(g.n_tpw, TB_WN), k_h = cdiv(g.k_tpw, TB_WK);
+    int rc = NRMS_OK;
+#define TNB_LAUNCH(MODE, NN, KK, NP)                                                                                \
+    do {                                                                                                            \
+        constexpr size_t lds_bytes = 2 * (size_t)(NP == 3 ? 2 : 1) * (TB_A_PLANE + TB_B_PLANE);                     \
+        const void* fn = (const void*)gemm_tn_bf16_kernel<MODE, NN, KK, NP>;                                        \
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   \
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; } \
+        TimingScope ts(name, stream);                                                                               \
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<MODE, NN, KK, NP>), grid, dim3(TB_THREADS), lds_bytes, stream, a, g); \
+        rc = check_launch(name);                                                                                    \
+    } while (0)
+#define TNB_SHAPE(MODE, NP)                                        \
+    do {                                                           \
+        if (n_q <= 2 && k_h <= 2) TNB_LAUNCH(MODE, 2, 2, NP);      \
+        else if (n_q <= 4) TNB_LAUNCH(MODE, 4, 5, NP);             \
+        else TNB_LAUNCH(MODE, 5, 5, NP);                           \
+    } while (0)
+    if (a.amode == A_PLAIN) { if (npass == 3) TNB_SHAPE(A_PLAIN, 3); else TNB_SHAPE(A_PLAIN, 1); }
+    else { if (npass == 3) TNB_SHAPE(A_DZ, 3); else TNB_SHAPE(A_DZ, 1); }
+#undef TNB_SHAPE
+#undef TNB_LAUNCH
+    if (rc) return rc;
+    const long total = (long)a.N * (a.K + 1);
+    TimingScope ts("tn_reduce", stream);
+    hipLaunchKernelGGL(tnb_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a.partial, a.splits, a.N, a.K,
+                       (long)g.n_tiles * 16, (long)g.k_tiles * 16, a.dW, a.dbias);
+    return check_launch("tn_reduce");
+}
+
+size_t gemm_nt_bf16_wplane_bytes(int N, int K) { return (size_t)2 * N * (cdiv(K, BF_BK) * BF_BK) * sizeof(__bf16); }
+
+}  // namespace nrms

@@ -104,15 +104,22 @@ def _stream():
 class NRMSEngine:
     """One NRMS forward / backward / optimizer step on one GPU."""
 
-    def __init__(self, dims: ModelDims, device):
+    def __init__(self, dims: ModelDims, device, precision="fp32"):
         self.lib = _lib.load()
         self.dims = dims
+        self.set_precision(precision)
         self.layout = FlatLayout(dims)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.NrmsError("the NRMS HIP engine needs a GPU device (got %s); there is no CPU path" % device)
         self._bufs = {}
         self._saved = None
+
+    def set_precision(self, precision):
+        """"fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections, ~2^-16 relative) or "bf16"."""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
+        self.precision = precision
 
     # ---- buffers ----------------------------------------------------------------------
     def _buf(self, key, numel, dtype=torch.float32):
@@ -127,7 +134,7 @@ class NRMSEngine:
         return _lib.EncoderDesc(n_seq=n_seq, seq_len=seq_len, d_model=d.word_embed_size, n_heads=d.heads(enc),
                                 q_dim=d.query_vector_dim, vocab=d.n_words if enc == "news_encoder" else 0,
                                 p_drop_embed=float(p_embed), p_drop_ctx=float(p_ctx),
-                                precision=_lib.NRMS_PRECISION_FP32, use_output_proj=int(d.output_proj),
+                                precision=_lib.PRECISIONS[self.precision], use_output_proj=int(d.output_proj),
                                 mask_mode=int(mask_mode), reserved=0, seed=int(seed))
 
     def _ptrs(self, cls, flat, enc):
@@ -151,8 +158,9 @@ class NRMSEngine:
         ctx = self._buf(tag + ".ctx", M * d)
         t = self._buf(tag + ".t", M * q) if need_bwd else None
         w = self._buf(tag + ".w", M) if need_bwd else None
+        scratch = self._buf("fwd_scratch", 1 << 20) if self.precision != "fp32" else None     # 4 MB >= any weight planes
         dp = lambda z: None if z is None else z.data_ptr()
-        return _lib.EncoderActs(x=dp(x), qkv=dp(qkv), attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w))
+        return _lib.EncoderActs(x=dp(x), qkv=dp(qkv), attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
 
     # ---- news vectors for an arbitrary list of titles (a-5, a-9 get_news_vector) ---------
     def encode_titles(self, flat, ids, out=None, p_embed=0.0, p_ctx=0.0, seed=0, save=False, tag="news",

@@ -157,8 +157,11 @@ class Model(nn.Module):
         if self._flat.device.type != "cuda":
             raise _lib.NrmsError("NRMS HIP model parameters are on %s: move the model to a GPU "
                                  "(there is no CPU fallback)" % self._flat.device)
+        prec = getattr(self.config, "precision", "fp32")
         if self._engine is None or self._engine.device != self._flat.device:
-            self._engine = NRMSEngine(self._dims, self._flat.device)
+            self._engine = NRMSEngine(self._dims, self._flat.device, precision=prec)
+        elif self._engine.precision != prec:
+            self._engine.set_precision(prec)
         return self._flat.device
 
     def _next_seed(self):

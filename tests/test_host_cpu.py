@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.EncoderDesc) == 56
     assert _lib.EncoderDesc.seed.offset == 48
     assert ctypes.sizeof(_lib.EncoderWeights) == 64 and ctypes.sizeof(_lib.EncoderGrads) == 64
-    assert ctypes.sizeof(_lib.EncoderActs) == 48
+    assert ctypes.sizeof(_lib.EncoderActs) == 56
 
 
 def test_argument_validation_without_gpu():
