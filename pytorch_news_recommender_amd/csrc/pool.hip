@@ -171,15 +171,21 @@ __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
 }
 
 __global__ __launch_bounds__(256) void colsum_add_kernel(const float* partial, int rows, int cols, float* out) {
-    // one block per 64 columns; 4 row-groups of 64 lanes each, coalesced along the columns
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    // one block per 16 columns: 16 row-groups x 16 columns per pass keep 16 loads per column in flight
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c < cols)
-        for (int r = rg; r < rows; r += 4) s += partial[(long)r * cols + c];
-    red[rg][threadIdx.x & 63] = s;
+        for (int r = rg; r < rows; r += 16) s += partial[(long)r * cols + c];
+    red[rg][cl] = s;
     __syncthreads();
-    if (rg == 0 && c < cols) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rg == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        out[c] += t;
+    }
 }
 
 int addattn_bwd_rows_waves(int n_seq) {
@@ -202,7 +208,7 @@ int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, co
         if (rc) return rc;
     }
     TimingScope ts("colsum_add", stream);
-    hipLaunchKernelGGL(colsum_add_kernel, dim3(cdiv(q, 64)), dim3(256), 0, stream, dq_partial, waves, q, dq);
+    hipLaunchKernelGGL(colsum_add_kernel, dim3(cdiv(q, 16)), dim3(256), 0, stream, dq_partial, waves, q, dq);
     return check_launch("colsum_add");
 }
 
