@@ -20,8 +20,7 @@ struct AttnArgs {
     const float* qkv;       // [M, 3d]
     float* ctx;             // fwd out [M, d]
     Dropout drop;           // fwd: site 1 on ctx
-    const float* dctx;      // bwd in  [M, d] gradient w.r.t. the POST-dropout context; the mask (site 1,
-                            // same Philox counters as the forward) is applied while it is loaded
+    const float* dctx;      // bwd in  [M, d] gradient w.r.t. the pre-dropout context (mask already applied)
     float* dqkv;            // bwd out [M, 3d]
     const uint8_t* mask;    // optional [n_seq, S]: v1's pairwise mask mask_i*mask_j -> masked_fill(-1e9)
                             // (model/nrms_v1.py:27-33); null = v0 (no mask at all)
@@ -35,83 +34,36 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// stage rows [0,S) x cols [0,dk) of a [*, ld] matrix into LDS [SP][RS]
-template <int ND>
-__device__ __forceinline__ void stage_in(float* dst, int RS, const float* src, long ld, int S, int dk, int lane) {
-    constexpr int LPR = 16 * ND, RPI = 64 / LPR;
-    const int c2 = lane % LPR, rsub = lane / LPR;
-    if (2 * c2 < dk) {
-        for (int r = rsub; r < S; r += RPI) {
-            const float2 v = *reinterpret_cast<const float2*>(src + r * ld + 2 * c2);
-            *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = v;
-        }
-    }
-}
-
-// same, for the context gradient: applies the context-dropout mask (site 1) of the forward while
-// loading, element index = base_elem + r*ld + c (ld = d for the [M, d] gradient)
-template <int ND>
-__device__ __forceinline__ void stage_in_drop(float* dst, int RS, const float* src, long ld, int S, int dk, int lane,
-                                              const Dropout& drop, uint64_t base_elem) {
-    constexpr int LPR = 16 * ND, RPI = 64 / LPR;
-    const int c2 = lane % LPR, rsub = lane / LPR;
-    if (2 * c2 < dk) {
-        for (int r = rsub; r < S; r += RPI) {
-            float2 v = *reinterpret_cast<const float2*>(src + r * ld + 2 * c2);
-            if (drop.thresh != 0u) {
-                uint32_t rnd[4];
-                const uint64_t e = base_elem + (uint64_t)r * ld + 2 * c2;
-                philox4x32_7(drop.seed, e >> 2, 1u, rnd);
-                const int q = (int)(e & 3);          // 0 or 2
-                v.x = (q == 0 ? rnd[0] : rnd[2]) >= drop.thresh ? v.x * drop.inv_keep : 0.f;
-                v.y = (q == 0 ? rnd[1] : rnd[3]) >= drop.thresh ? v.y * drop.inv_keep : 0.f;
-            }
-            *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = v;
-        }
-    }
-}
-
 // Register prefetch of one [S x d_k] operand of the NEXT unit (global -> VGPR), written to LDS
 // after the current unit's compute: keeps HBM requests in flight while the wave is on the MFMAs.
 template <int NS, int ND>
 struct Prefetch {
     static constexpr int LPR = 16 * ND, RPI = 64 / LPR, IT = 32 * NS / RPI;
     float2 v[IT];
+    // Branch-free: every lane loads from a clamped (always valid) address and the out-of-range lanes
+    // are zeroed by a select afterwards.  A predicated load (`cond ? *p : 0`) makes hipcc branch
+    // around EACH load with an exec-mask save/restore and a wait, serialising the 32 loads of a unit.
     __device__ __forceinline__ void load(const float* src, long ld, int S, int dk, int lane) {
         const int c2 = lane % LPR, rsub = lane / LPR;
+        const bool cok = 2 * c2 < dk;
+        const float* col = src + (cok ? 2 * c2 : 0);
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = rsub + it * RPI;
-            v[it] = (2 * c2 < dk && r < S) ? *reinterpret_cast<const float2*>(src + r * ld + 2 * c2) : float2{0.f, 0.f};
+            const float2 t = *reinterpret_cast<const float2*>(col + (long)min(r, S - 1) * ld);
+            const bool ok = cok && r < S;
+            v[it].x = ok ? t.x : 0.f;
+            v[it].y = ok ? t.y : 0.f;
         }
     }
+    // unconditional: out-of-range entries are zeros and land on the zero padding (rows < 32 NS,
+    // columns < 32 ND are always inside the [SP][RS] image), which they thereby re-establish
     __device__ __forceinline__ void store(float* dst, int RS, int S, int dk, int lane) const {
         const int c2 = lane % LPR, rsub = lane / LPR;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = rsub + it * RPI;
-            if (2 * c2 < dk && r < S) *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = v[it];
-        }
-    }
-    // store through the context-dropout mask (site 1); element index = base_elem + r*ld + c
-    __device__ __forceinline__ void store_drop(float* dst, int RS, int S, int dk, int lane, long ld, const Dropout& drop,
-                                               uint64_t base_elem) const {
-        const int c2 = lane % LPR, rsub = lane / LPR;
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int r = rsub + it * RPI;
-            if (2 * c2 < dk && r < S) {
-                float2 x = v[it];
-                if (drop.thresh != 0u) {
-                    uint32_t rnd[4];
-                    const uint64_t e = base_elem + (uint64_t)r * ld + 2 * c2;
-                    philox4x32_7(drop.seed, e >> 2, 1u, rnd);
-                    const int q = (int)(e & 3);
-                    x.x = (q == 0 ? rnd[0] : rnd[2]) >= drop.thresh ? x.x * drop.inv_keep : 0.f;
-                    x.y = (q == 0 ? rnd[1] : rnd[3]) >= drop.thresh ? x.y * drop.inv_keep : 0.f;
-                }
-                *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = x;
-            }
+            *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = v[it];
         }
     }
 };
@@ -142,12 +94,12 @@ __device__ __forceinline__ void abt_tiles(const float* A, const float* B, int RS
 // in-register softmax over keys (rows of the transposed tile) for each query column.
 // msk (wave-private LDS, 1.0 / 0.0 per position) reproduces v1's masked_fill(mask_i*mask_j == 0, -1e9):
 // a fully masked query row ends up uniform over the S real keys, exactly like the reference.
-template <int NS>
+template <int NS, bool MASKED>
 __device__ __forceinline__ void softmax_cols(f32x16 (&st)[NS][NS], float scale, int S, int l32, int hh,
                                              const float* msk) {
 #pragma unroll
     for (int it = 0; it < NS; ++it) {
-        const float mi = msk != nullptr ? msk[it * 32 + l32] : 1.0f;
+        const float mi = MASKED ? msk[it * 32 + l32] : 1.0f;
         float mx = -1e30f;
 #pragma unroll
         for (int jt = 0; jt < NS; ++jt)
@@ -155,7 +107,7 @@ __device__ __forceinline__ void softmax_cols(f32x16 (&st)[NS][NS], float scale, 
             for (int r = 0; r < 16; ++r) {
                 const int j = jt * 32 + crow32(r, hh);
                 float s = st[jt][it][r] * scale;
-                if (msk != nullptr) s = (mi * msk[j] != 0.f) ? s : -1e9f;
+                if (MASKED) s = (mi * msk[j] != 0.f) ? s : -1e9f;
                 s = j < S ? s : -1e30f;
                 st[jt][it][r] = s;
                 mx = fmaxf(mx, s);
@@ -166,7 +118,9 @@ __device__ __forceinline__ void softmax_cols(f32x16 (&st)[NS][NS], float scale, 
         for (int jt = 0; jt < NS; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = expf(st[jt][it][r] - mx);
+                // exp via v_exp_f32 (exp2): |x| <= ~90 here, relative error ~1e-7 -- far inside the
+                // 1e-5 score tolerance, and ~10x fewer VALU instructions than the libm expf
+                const float p = __expf(st[jt][it][r] - mx);
                 st[jt][it][r] = p;
                 sum += p;
             }
@@ -234,7 +188,10 @@ __device__ __forceinline__ void transpose_to_lds(float* T, const f32x16 (&xt)[NS
             for (int r = 0; r < 16; ++r) T[(it * 32 + l32) * TS + jt * 32 + crow32(r, hh)] = xt[jt][it][r];
 }
 
-// out^T[dd][i] accumulator tiles -> LDS rows [i][dd] (valid part only, pads stay zero)
+// out^T[dd][i] accumulator tiles -> LDS rows [i][dd].  Unconditional: the padding positions get
+// finite garbage, which is harmless because the next unit's Prefetch::store rewrites the whole
+// [32 NS][32 ND] image (zeros in the padding) before anything reads it, and the global store
+// below only reads the valid [S][dk] part.
 template <int NS, int ND>
 __device__ __forceinline__ void stage_out(float* dst, int RS, const f32x16 (&o)[ND][NS], int S, int dk, int l32,
                                           int hh) {
@@ -243,14 +200,11 @@ __device__ __forceinline__ void stage_out(float* dst, int RS, const f32x16 (&o)[
 #pragma unroll
         for (int it = 0; it < NS; ++it)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dd = dt * 32 + crow32(r, hh), i = it * 32 + l32;
-                if (i < S && dd < dk) dst[i * RS + dd] = o[dt][it][r];
-            }
+            for (int r = 0; r < 16; ++r) dst[(it * 32 + l32) * RS + dt * 32 + crow32(r, hh)] = o[dt][it][r];
 }
 
 // ---------------------------------------------------------------------------------------
-template <int NS, int ND, int WPB>
+template <int NS, int ND, int WPB, bool MASKED>
 __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, WF = 3 * SP * RS + 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -281,7 +235,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
         pq.store(Qs, RS, a.S, a.dk, lane);
         pk.store(Ks, RS, a.S, a.dk, lane);
         pv.store(Vs, RS, a.S, a.dk, lane);
-        if (a.mask != nullptr) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
+        if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
         wave_sync();
         if (u + ustride < total) {            // next unit's operands fly while this one computes
             const long un = u + ustride, sn = un / a.h;
@@ -293,7 +247,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 
         f32x16 st[NS][NS];
         abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
-        softmax_cols<NS>(st, a.scale, a.S, l32, hh, a.mask != nullptr ? Ms : nullptr);
+        softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, Ms);
         f32x16 o[ND][NS];
         at_x_tiles<NS, ND>(Vs, RS, l32, hh, st, o);
         wave_sync();
@@ -329,10 +283,15 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 //   dV^T = dO^T P ; dQ^T = K^T dS^T ; dK^T = Q^T dS
 // The two products that sum over the query index need P / dS with queries in rows: one
 // 32x32 transpose through a wave-private LDS image each.
-template <int NS, int ND, int WPB>
+template <int NS, int ND, int WPB, bool MASKED>
 __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
     constexpr bool PF = NS == 1;      // prefetch across the compute only where registers allow
-    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1, WF = 4 * SP * RS + SP * TS + 64;
+    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1;
+    // the 32x32 transpose image fits inside the V region once V is dead (after dP^T): no LDS of its
+    // own -> 18.7 KB per wave instead of 22.9 KB, i.e. 8 waves per CU instead of 6 (this kernel is a
+    // long chain of LDS round trips, so it lives off occupancy)
+    constexpr bool ALIAS = SP * TS <= SP * RS;
+    constexpr int WF = 4 * SP * RS + (ALIAS ? 0 : SP * TS) + 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
@@ -340,8 +299,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
     float* Ks = Qs + SP * RS;
     float* Vs = Ks + SP * RS;
     float* Gs = Vs + SP * RS;
-    float* Tb = Gs + SP * RS;
-    float* Ms = Tb + SP * TS;
+    float* Tb = ALIAS ? Vs : Gs + SP * RS;
+    float* Ms = Gs + SP * RS + (ALIAS ? 0 : SP * TS);
     for (int i = lane; i < WF; i += 64) Qs[i] = 0.f;
     wave_sync();
 
@@ -365,8 +324,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
         pq.store(Qs, RS, a.S, a.dk, lane);
         pk.store(Ks, RS, a.S, a.dk, lane);
         pv.store(Vs, RS, a.S, a.dk, lane);
-        pg.store_drop(Gs, RS, a.S, a.dk, lane, a.d, a.drop, (uint64_t)(seq * a.S * a.d + head * a.dk));
-        if (a.mask != nullptr) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
+        pg.store(Gs, RS, a.S, a.dk, lane);      // dctx arrives already masked (dctx GEMM epilogue)
+        if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
         wave_sync();
         if (PF && u + ustride < total) {
             const long un = u + ustride, sn = un / a.h;
@@ -380,8 +339,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
 
         f32x16 st[NS][NS], dp[NS][NS];
         abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
-        const float* msk = a.mask != nullptr ? Ms : nullptr;
-        softmax_cols<NS>(st, a.scale, a.S, l32, hh, msk);  // st = P^T
+        const float* msk = Ms;
+        softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, msk);  // st = P^T
         abt_tiles<NS, ND>(Vs, Gs, RS, l32, hh, dp);         // dp = dP^T
 #pragma unroll
         for (int it = 0; it < NS; ++it) {
@@ -397,19 +356,17 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     float dsv = st[jt][it][r] * (dp[jt][it][r] - D) * a.scale;                           // dS^T
                     // masked_fill passes no gradient to the scores it overwrote
-                    if (msk != nullptr && msk[it * 32 + l32] * msk[jt * 32 + crow32(r, hh)] == 0.f) dsv = 0.f;
+                    if (MASKED && msk[it * 32 + l32] * msk[jt * 32 + crow32(r, hh)] == 0.f) dsv = 0.f;
                     dp[jt][it][r] = dsv;
                 }
         }
-        // dV^T = dO^T P   (queries summed: P through the transpose image); V is dead -> stage dV there
+        // dV^T = dO^T P  (queries summed: P through the transpose image, which may live in the dead V
+        // region); dV stays in registers until that image has also served dK
+        wave_sync();
         transpose_to_lds<NS>(Tb, st, l32, hh);
         wave_sync();
-        {
-            f32x16 dv[ND][NS];
-            at_lds_tiles<NS, ND>(Gs, RS, Tb, l32, hh, dv);
-            wave_sync();
-            stage_out<NS, ND>(Vs, RS, dv, a.S, a.dk, l32, hh);
-        }
+        f32x16 dv[ND][NS];
+        at_lds_tiles<NS, ND>(Gs, RS, Tb, l32, hh, dv);
         // dQ^T = K^T dS^T  (keys summed: dS^T straight from registers); K is dead afterwards -> stage dQ there
         {
             f32x16 dq[ND][NS];
@@ -426,6 +383,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
             wave_sync();
             stage_out<NS, ND>(Gs, RS, dkk, a.S, a.dk, l32, hh);
         }
+        stage_out<NS, ND>(Vs, RS, dv, a.S, a.dk, l32, hh);     // transpose image is dead now
         wave_sync();
 
         constexpr int LPR = 16 * ND, RPI = 64 / LPR;
@@ -452,10 +410,11 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-template <int NS, int ND, int WPB, bool BWD>
-static int launch_attn_inst(const AttnArgs& a, hipStream_t stream) {
+template <int NS, int ND, int WPB, bool BWD, bool MASKED>
+static int launch_attn_inst2(const AttnArgs& a, hipStream_t stream) {
     constexpr int SP = 32 * NS, RS = 32 * ND + 4;
-    constexpr size_t wf = BWD ? (4 * SP * RS + SP * (SP + 1) + 64) : (3 * SP * RS + 64);
+    constexpr bool ALIAS = SP * (SP + 1) <= SP * RS;
+    constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : SP * (SP + 1)) + 64) : (3 * SP * RS + 64);
     constexpr size_t bytes = wf * WPB * sizeof(float);
     const long total = (long)a.n_seq * a.h;
     int blocks = (int)((total + WPB - 1) / WPB);
@@ -463,15 +422,21 @@ static int launch_attn_inst(const AttnArgs& a, hipStream_t stream) {
     if (blocks > cap) blocks = cap;
     const char* name = BWD ? "attn_bwd" : "attn_fwd";
     hipError_t e;
-    if (BWD) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NS, ND, WPB>,
+    if (BWD) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NS, ND, WPB, MASKED>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    else e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NS, ND, WPB>,
+    else e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NS, ND, WPB, MASKED>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
     TimingScope ts(name, stream);
-    if (BWD) hipLaunchKernelGGL((attn_bwd_kernel<NS, ND, WPB>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
+    if (BWD) hipLaunchKernelGGL((attn_bwd_kernel<NS, ND, WPB, MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB, MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
     return check_launch(name);
+}
+
+template <int NS, int ND, int WPB, bool BWD>
+static int launch_attn_inst(const AttnArgs& a, hipStream_t stream) {
+    return a.mask != nullptr ? launch_attn_inst2<NS, ND, WPB, BWD, true>(a, stream)
+                             : launch_attn_inst2<NS, ND, WPB, BWD, false>(a, stream);
 }
 
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,

@@ -247,9 +247,8 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
                                  pmask, s);
     if (rc) return rc;
-    // 2. d(ctx) = dZ Wa + w_s dout.  v0: left as the gradient of the POST-dropout context (the attention
-    //    backward applies the mask while loading it).  v1: the mask is applied here, because the output
-    //    projection's backward GEMMs come in between.
+    // 2. d(ctx) = dZ Wa + w_s dout, then through the context-dropout mask in the GEMM's coalesced
+    //    epilogue (one Philox call per float4) -- the attention backward then carries no RNG work.
     rc = launch_transpose(w->w_add, wadd_t, q, d, s);
     if (rc) return rc;
     {
@@ -258,7 +257,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         g.ds = ds; g.qv = w->q_vec; g.T = acts->t;
         g.W = wadd_t; g.C = dctx; g.ldc = d;
         g.wrow = acts->w; g.dout = dout; g.S = S;
-        if (wo) g.drop = drop_c;
+        g.drop = drop_c;
         rc = nt_gemm(desc, A_DZ, E_DCTX, g, wplanes, s, "dctx_bwd");
         if (rc) return rc;
     }
@@ -290,8 +289,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         dattn_in = dattn;
     }
     // 4. attention backward
-    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, wo ? no_drop : drop_c, dattn_in,
-                          dqkv, amask, s);
+    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask, s);
     if (rc) return rc;
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings)
     const float* xin = gather ? acts->x : x;
