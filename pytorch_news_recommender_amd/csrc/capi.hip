@@ -12,7 +12,8 @@ namespace nrms {
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
                      const float* dctx, float* dqkv, const uint8_t* mask, hipStream_t stream);
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
-                       const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, hipStream_t stream);
+                       const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, int npass,
+                       void* wplanes, hipStream_t stream);
 int addattn_bwd_rows_waves(int n_seq);
 int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w,
                             const float* T, float* ds, float* dq_partial, float* dq, const uint8_t* mask,
@@ -187,8 +188,9 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = nt_gemm(desc, A_PLAIN, E_STORE, o, acts->scratch, s, "out_proj_fwd");
         if (rc) return rc;
     }
+    const int npass = desc->precision == NRMS_PRECISION_FP32 ? 0 : (desc->precision == NRMS_PRECISION_BF16X3 ? 3 : 1);
     return launch_addattn_fwd(desc->n_seq, S, d, q, acts->ctx, w->w_add, w->b_add, w->q_vec, acts->t, acts->w, out,
-                              pmask, s);
+                              pmask, npass, acts->scratch, s);
 }
 
 extern "C" size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc) {

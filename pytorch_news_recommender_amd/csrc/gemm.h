@@ -226,6 +226,18 @@ int launch_gemm_nt_bf16(int amode, int emode, int npass, const NTArgs& a, void* 
 size_t gemm_nt_bf16_wplane_bytes(int N, int K);
 int launch_gemm_tn_bf16(int npass, const TNArgs& a, hipStream_t stream, const char* name);
 
+// additive-attention forward (pool.hip: fp32 MFMA; gemm_bf16.hip: split-bf16 main loop)
+struct AddFwdArgs {
+    NTArgs g;              // A = ctx [M,d], W = w_add [q,d], bias = b_add, N = q, K = d
+    const float* qv;       // [q]
+    float* T;              // [M,q] or null
+    float* wout;           // [M]   or null
+    float* out;            // [n_seq, d]
+    int S, d;
+    const uint8_t* mask;   // optional [M]: masked_fill(mask == 0, -1e9) before the softmax (nrms_v1.py:100-101)
+};
+int launch_addattn_fwd_bf16(int npass, const AddFwdArgs& a, void* wplanes, hipStream_t stream);
+
 // embed.hip
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,
                           hipStream_t stream);

@@ -317,6 +317,122 @@ int launch_gemm_nt_bf16(int amode, int emode, int npass, const NTArgs& g_in, voi
 }
 
 // =======================================================================================
+// Additive-attention forward on the split-bf16 main loop (AdditiveAttention, model/nrms_v0.py:100-126):
+// one workgroup owns floor(256/S) whole sequences; T = tanh(C Wa^T + ba) from the MFMA accumulators,
+// s = T.q reduced across the tile's columns in registers, T written in whole rows through the LDS
+// strips, then softmax over each sequence and the weighted pooling of the (L2-resident) C rows.
+// =======================================================================================
+template <int NT, int NPASS>
+__global__ __launch_bounds__(BF_THREADS, 2) void addattn_fwd_bf16_kernel(AddFwdArgs a, BFArgs b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float sc[BF_BM];
+    const NTArgs& g = b.g;
+    const int row0 = blockIdx.x * g.rows_per_tile;
+    const int rows_valid = min(g.rows_per_tile, g.M - row0);
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16_nt_mainloop<NT, A_PLAIN, NPASS>(b, row0, rows_valid, 0, acc, smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float part = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = 16 * nt + r16;
+                float t = 0.f;
+                if (n < g.N) {
+                    t = tanhf(acc[mt][nt][reg] + g.bias[n]);
+                    part += t * a.qv[n];
+                }
+                acc[mt][nt][reg] = t;
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 8, 64);
+            if (r16 == 0) sc[32 * wave + 16 * mt + 4 * kq + reg] = part;
+        }
+    if (a.T != nullptr) {
+        NTArgs tg = g;                      // T [M, q]: plain coalesced store of the tanh tile
+        tg.bias = nullptr; tg.C = a.T; tg.ldc = g.N;
+        nt_epilogue<NT, E_STORE>(tg, acc, row0, rows_valid, 0, wave, lane,
+                                 reinterpret_cast<float*>(smem) + wave * 8 * (16 * NT + 8));
+    }
+    __syncthreads();
+    const int spb = rows_valid / a.S;
+    if (tid < spb) {
+        float* s = sc + tid * a.S;
+        if (a.mask != nullptr)
+            for (int i = 0; i < a.S; ++i)
+                if (a.mask[(long)row0 + tid * a.S + i] == 0) s[i] = -1e9f;
+        float mx = -1e30f;
+        for (int i = 0; i < a.S; ++i) mx = fmaxf(mx, s[i]);
+        float sum = 0.f;
+        for (int i = 0; i < a.S; ++i) { const float e = expf(s[i] - mx); s[i] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int i = 0; i < a.S; ++i) {
+            s[i] *= inv;
+            if (a.wout != nullptr) a.wout[(long)row0 + tid * a.S + i] = s[i];
+        }
+    }
+    __syncthreads();
+    const long seq0 = row0 / a.S;
+    for (int idx = tid; idx < spb * (a.d / 4); idx += BF_THREADS) {
+        const int sq = idx / (a.d / 4), c4 = idx - sq * (a.d / 4);
+        const float* crow = g.A + ((long)row0 + sq * a.S) * g.lda + 4 * c4;
+        const float* w = sc + sq * a.S;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < a.S; ++i) o += w[i] * *reinterpret_cast<const f32x4*>(crow + (long)i * g.lda);
+        *reinterpret_cast<f32x4*>(a.out + (seq0 + sq) * a.d + 4 * c4) = o;
+    }
+}
+
+template <int NT, int NPASS>
+static int launch_addfwd_bf_inst(const AddFwdArgs& a, const BFArgs& b, hipStream_t stream) {
+    constexpr int P = NPASS == 3 ? 2 : 1;
+    constexpr size_t stage_bytes = 2 * (size_t)P * (NT * 16) * BF_ROWB;
+    constexpr size_t strip_bytes = (size_t)8 * 8 * (16 * NT + 8) * sizeof(float);
+    constexpr size_t lds_bytes = stage_bytes > strip_bytes ? stage_bytes : strip_bytes;
+    const void* fn = (const void*)addattn_fwd_bf16_kernel<NT, NPASS>;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { set_error("addattn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    TimingScope ts("addattn_fwd", stream);
+    hipLaunchKernelGGL((addattn_fwd_bf16_kernel<NT, NPASS>), dim3(cdiv(b.g.M, b.g.rows_per_tile)), dim3(BF_THREADS),
+                       lds_bytes, stream, a, b);
+    return check_launch("addattn_fwd");
+}
+
+int launch_split_planes(const float* w, int rows, int cols, int cols_p, void* hi, void* lo, hipStream_t stream);
+
+int launch_addattn_fwd_bf16(int npass, const AddFwdArgs& a, void* wplanes, hipStream_t stream) {
+    BFArgs b;
+    b.g = a.g;
+    b.g.rows_per_tile = (BF_BM / a.S) * a.S;
+    b.Kp = cdiv(a.g.K, BF_BK) * BF_BK;
+    b.whi = (const __bf16*)wplanes;
+    b.wlo = b.whi + (long)a.g.N * b.Kp;
+    int rc = launch_split_planes(a.g.W, a.g.N, a.g.K, b.Kp, wplanes, (void*)b.wlo, stream);
+    if (rc) return rc;
+    const int q = a.g.N;
+    if (npass == 3) {
+        if (q <= 64) return launch_addfwd_bf_inst<4, 3>(a, b, stream);
+        if (q <= 128) return launch_addfwd_bf_inst<8, 3>(a, b, stream);
+        return launch_addfwd_bf_inst<13, 3>(a, b, stream);
+    }
+    if (q <= 64) return launch_addfwd_bf_inst<4, 1>(a, b, stream);
+    if (q <= 128) return launch_addfwd_bf_inst<8, 1>(a, b, stream);
+    return launch_addfwd_bf_inst<13, 1>(a, b, stream);
+}
+
+// =======================================================================================
 // TN in split-bf16: dW[N,K(+1)] = sum_m A'[m,N]^T B'[m,K(+ones)]
 // =======================================================================================
 // Same decomposition as the fp32 kernel (gemm.hip): 8 waves = 4 (N) x 2 (K), NTN x NTK tiles of

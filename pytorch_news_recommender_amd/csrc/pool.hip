@@ -10,16 +10,6 @@ namespace nrms {
 //   T = tanh(C Wa^T + ba) on the MFMA, s = T.q reduced across the tile's columns in-register,
 //   w = softmax_S(s), out = sum_s w_s C_s.  T and w are saved for the backward.
 // =======================================================================================
-struct AddFwdArgs {
-    NTArgs g;              // A = ctx [M,d], W = w_add [q,d], bias = b_add, N = q, K = d
-    const float* qv;       // [q]
-    float* T;              // [M,q] or null
-    float* wout;           // [M]   or null
-    float* out;            // [n_seq, d]
-    int S, d;
-    const uint8_t* mask;   // optional [M]: masked_fill(mask == 0, -1e9) before the softmax (nrms_v1.py:100-101)
-};
-
 template <int NT>
 __global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (NT_BM + 16 * NT) * NT_BK];
@@ -96,13 +86,15 @@ static int launch_addfwd_inst(const AddFwdArgs& a, hipStream_t stream) {
 }
 
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
-                       const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, hipStream_t stream) {
+                       const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, int npass,
+                       void* wplanes, hipStream_t stream) {
     if (n_seq <= 0) return NRMS_OK;
     AddFwdArgs a{};
     a.g.M = n_seq * S; a.g.N = q; a.g.K = d;
     a.g.rows_per_tile = (NT_BM / S) * S;
     a.g.A = ctx; a.g.lda = d; a.g.W = w_add; a.g.bias = b_add;
     a.qv = q_vec; a.T = T; a.wout = wout; a.out = out; a.S = S; a.d = d; a.mask = mask;
+    if (npass != 0 && q <= 208) return launch_addattn_fwd_bf16(npass, a, wplanes, stream);
     if (q <= 32) return launch_addfwd_inst<2>(a, stream);
     if (q <= 64) return launch_addfwd_inst<4>(a, stream);
     if (q <= 128) return launch_addfwd_inst<8>(a, stream);
