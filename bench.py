@@ -198,6 +198,15 @@ def main():
         if dom.startswith("attn"):
             mfma_peak_note = "attention runs on exact f32 MFMA in every mode; it is HBM/latency-bound"
         achieved = (fl / 1e12 if bound == "mfma" else by / 1e9) / (dom_ms / args.steps * 1e-3)
+        # measured HBM bytes of the news-encoder launch of that kernel (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE,
+        # separate passes, collected at this workload and committed under profiles/): null if not on file
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_bf16x3_hbm_traffic.json")
+        if args.precision == "bf16x3" and B == 512 and os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile))["by_timer"].get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         total_users = B * world * args.steps
         out = {
             "metric": "users/sec (train step) NRMS MIND-small hist=50 cand=5",
@@ -211,7 +220,9 @@ def main():
                        "score_parity_vs_reference": {"fp32": "<=1.5e-7", "bf16x3": "<=5e-7", "bf16": "~3e-4 (fails 1e-4)"}[args.precision]},
             "loss": loss,
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": "bytes of the news-encoder launch (largest of the kernel's launches per step), "
+                                         "profiles/r01_bf16x3_hbm_traffic.json",
                          "peak_note": ("HBM3E spec 8 TB/s (6.3 TB/s measured achievable); algorithmic bytes = each "
                                        "activation tensor read/written once, fp32") if bound == "hbm" else
                                       {"fp32": "f32-input MFMA dense peak", "bf16": "bf16 MFMA dense peak",
