@@ -47,7 +47,7 @@ extern "C" {
 typedef struct nrms_encoder_desc {
     int32_t  n_seq;        /* titles (B*(H+C)) or users (B) */
     int32_t  seq_len;      /* L or H, 1..64 */
-    int32_t  d_model;      /* config.word_embed_size; multiple of 4; = n_heads * d_k */
+    int32_t  d_model;      /* config.word_embed_size; multiple of 4, <= 512; = n_heads * d_k */
     int32_t  n_heads;      /* config.num_attention_heads (v1 news encoder: title_heads_num);
                               d_k = d_model / n_heads even, <= 64 */
     int32_t  q_dim;        /* config.query_vector_dim, multiple of 4, <= 256 */

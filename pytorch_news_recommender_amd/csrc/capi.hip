@@ -69,8 +69,8 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d != nullptr, "%s: null desc", who);
     NRMS_REQUIRE(d->n_seq >= 0, "%s: n_seq=%d", who, d->n_seq);
     NRMS_REQUIRE(d->seq_len >= 1 && d->seq_len <= 64, "%s: seq_len=%d outside 1..64", who, d->seq_len);
-    NRMS_REQUIRE(d->d_model > 0 && (d->d_model & 3) == 0, "%s: d_model=%d must be a positive multiple of 4", who,
-                 d->d_model);
+    NRMS_REQUIRE(d->d_model > 0 && (d->d_model & 3) == 0 && d->d_model <= 512,
+                 "%s: d_model=%d must be a positive multiple of 4, <= 512", who, d->d_model);
     NRMS_REQUIRE(d->n_heads > 0 && d->d_model % d->n_heads == 0, "%s: d_model %% n_heads != 0", who);
     const int dk = d->d_model / d->n_heads;
     NRMS_REQUIRE(dk <= 64 && (dk & 1) == 0, "%s: d_k=%d must be even and <= 64", who, dk);

@@ -116,24 +116,48 @@ constexpr int ROWS_MAXQ = 256;
 __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
     int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w, const float* T, float* ds,
     float* dq_partial, const uint8_t* mask) {
-    __shared__ float dsl[ROWS_WPB][64];
+    // Four 16-lane groups take one row each: a row dot is ceil(d/64) independent float4 loads per lane
+    // and a 4-step xor reduction, so a whole sequence is ~S/4 * ceil(d/64) loads in flight per lane
+    // instead of S dependent (load, 6-step reduce) rounds.
+    __shared__ float dwl[ROWS_WPB][64], dsl[ROWS_WPB][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l16 = lane & 15, grp = lane >> 4;
     const long gw = (long)blockIdx.x * ROWS_WPB + wave, nw = (long)gridDim.x * ROWS_WPB;
-    float dq[ROWS_MAXQ / 64] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int MAXC = 8;                 // float4 chunks per lane: d <= 16 * 4 * MAXC = 512
+    const int d4 = d >> 2, nch = (d4 + 15) >> 4;
+    const bool qok = 4 * lane < q;
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
     for (long seq = gw; seq < n_seq; seq += nw) {
         const float* c = ctx + seq * S * d;
         const float* g = dout + seq * d;
-        float my_dw = 0.f;                 // lane s holds dw_s
-        for (int s = 0; s < S; ++s) {
-            float p = 0.f;
-            for (int k = lane * 4; k < d; k += 256) {
-                const f32x4 cv = *reinterpret_cast<const f32x4*>(c + (long)s * d + k);
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + k);
-                p += cv[0] * gv[0] + cv[1] * gv[1] + cv[2] * gv[2] + cv[3] * gv[3];
-            }
-            p = wave_sum(p);
-            if (lane == s) my_dw = p;
+        f32x4 gv[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c4 = l16 + 16 * i;
+            gv[i] = (i < nch && c4 < d4) ? *reinterpret_cast<const f32x4*>(g + 4 * min(c4, d4 - 1)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(i < nch && c4 < d4)) gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        for (int r0 = 0; r0 < S; r0 += 4) {
+            const int r = min(r0 + grp, S - 1);
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                if (i < nch) {
+                    const int c4 = min(l16 + 16 * i, d4 - 1);
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(c + (long)r * d + 4 * c4);
+                    p += cv[0] * gv[i][0] + cv[1] * gv[i][1] + cv[2] * gv[i][2] + cv[3] * gv[i][3];
+                }
+            }
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 4, 64);
+            p += __shfl_xor(p, 8, 64);
+            if (l16 == 0 && r0 + grp < S) dwl[wave][r0 + grp] = p;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float my_dw = lane < S ? dwl[wave][lane] : 0.f;
         const float my_w = lane < S ? w[seq * S + lane] : 0.f;
         const float dot = wave_sum(my_w * my_dw);
         float my_ds = my_w * (my_dw - dot);
@@ -144,22 +168,14 @@ __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float* t = T + seq * S * q;
-        for (int s = 0; s < S; ++s) {
-            const float dsv = dsl[wave][s];
-#pragma unroll
-            for (int j = 0; j < ROWS_MAXQ / 64; ++j) {
-                const int n = lane + 64 * j;
-                if (n < q) dq[j] += dsv * t[(long)s * q + n];
-            }
+        const float* t = T + seq * S * q + 4 * (qok ? lane : 0);
+        for (int s2 = 0; s2 < S; ++s2) {
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(t + (long)s2 * q);
+            dq += dsl[wave][s2] * tv;
         }
         __builtin_amdgcn_wave_barrier();
     }
-#pragma unroll
-    for (int j = 0; j < ROWS_MAXQ / 64; ++j) {
-        const int n = lane + 64 * j;
-        if (n < q) dq_partial[gw * q + n] = dq[j];
-    }
+    if (qok) *reinterpret_cast<f32x4*>(dq_partial + gw * q + 4 * lane) = dq;
 }
 
 __global__ __launch_bounds__(256) void colsum_add_kernel(const float* partial, int rows, int cols, float* out) {
