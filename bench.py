@@ -237,6 +237,35 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, sample_users=args.cpu_sample_users)
+    # secondary: evaluation path (SURVEY f-1): impressions padded to max_candidate_size=300 as data_handler.py:174-177
+    # does, ~37 shown candidates each; plain forward (all 350 slots encoded, as the reference does) vs the
+    # unique-title forward
+    if world == 1 and not args.no_cpu_baseline and rank == 0:
+        try:
+            ev_shape = synth.Shape(n_candidates=300, batch_size=128)
+            evb = synth.make_batch(ev_shape, seed=5, batch_size=128)
+            shown = np.random.default_rng(6).integers(5, 70, size=128)
+            evb["candidate_mask"] = (np.arange(300)[None, :] < shown[:, None]).astype(np.uint8)
+            evb["candidate_titles"] = np.where(evb["candidate_mask"][..., None] > 0, evb["candidate_titles"], 0)
+            evt = {k: torch.from_numpy(v).to(dev) for k, v in evb.items()}
+            model.eval()
+            ev = {}
+            with torch.no_grad():
+                for name, dd in (("unique_titles", True), ("all_slots", False)):
+                    model.dedup_inference = dd
+                    model(evt)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        model(evt)
+                    torch.cuda.synchronize()
+                    ev[name + "_impressions_per_s"] = 128 * 5 / (time.perf_counter() - t1)
+            ev["unique_title_fraction"] = model.last_unique_titles / float(128 * 350)
+            model.dedup_inference = True
+            model.train()
+            out["eval_path"] = ev
+        except Exception as e:       # secondary leg only: never lose the headline line
+            out["eval_path"] = {"error": repr(e)}
     # secondary: the other precision modes on the same batch (outside the timed region of `value`)
     if world == 1 and (args.also_fp32 or not args.no_cpu_baseline):
         modes = {}
