@@ -131,6 +131,8 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     shape = synth.BENCH
+    if os.environ.get("NRMS_BENCH_D"):            # diagnostics only: alignment experiments
+        shape = synth.Shape(word_embed_size=int(os.environ["NRMS_BENCH_D"]))
     B = args.users_per_gpu
     cfg = Config("nrms_hip")
     cfg.__nrms__()
@@ -140,6 +142,7 @@ def main():
     cfg.dropout = 0.2
     cfg.learning_rate = 1e-3
     cfg.precision = args.precision
+    cfg.word_embed_size = shape.word_embed_size
     params = synth.make_params(shape, seed=0)
     model = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})

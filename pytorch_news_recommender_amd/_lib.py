@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libnrms_hip.so")
+LIB_PATH = os.environ.get("NRMS_HIP_LIB") or os.path.join(PKG, "libnrms_hip.so")   # override: diagnostic builds only
 
 NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1

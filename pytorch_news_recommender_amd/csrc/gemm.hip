@@ -49,6 +49,7 @@ static int pick_nt(int N) {
     int best = 19;
     long best_pad = -1;
     for (int i = 0; i < 5; ++i) {
+        if (cand[i] < 8 && N > 128) continue;
         const int w = cand[i] * 16;
         const long pad = (long)cdiv(N, w) * w;
         if (best_pad < 0 || pad < best_pad) { best_pad = pad; best = cand[i]; }
@@ -110,7 +111,9 @@ static TNGeom tn_geom(int N, int K) {
     g.k_wg = cdiv(g.k_tiles, TN_WK * TN_NTK);
     // an XCD has 32 CUs and runs whole M-slices (all output tiles of a slice): make the number of
     // output tiles a divisor of 32 so a single round fills every CU
-    while (g.n_wg * g.k_wg < 32 && (32 % (g.n_wg * g.k_wg)) != 0 && g.n_wg < g.n_tiles) ++g.n_wg;
+    const int n0 = g.n_wg;
+    for (int n = n0; n <= 2 * n0 + 1 && n <= g.n_tiles; ++n)
+        if (n * g.k_wg <= 32 && 32 % (n * g.k_wg) == 0) { g.n_wg = n; break; }
     g.n_tpw = cdiv(g.n_tiles, g.n_wg);
     g.k_tpw = cdiv(g.k_tiles, g.k_wg);
     return g;

@@ -42,33 +42,38 @@ __device__ __forceinline__ Split8 split8(const f32x4& u, const f32x4& v) {
 // stored at 8 kq + 4 u + e.  The 16-byte chunk kq of a block then holds exactly the 8 k-values
 // {4 kq + e, 16 + 4 kq + e} that lane group kq of the MFMA consumes, and the matching A fragment is
 // two float4 global loads that are each 64 contiguous bytes per row across the four lane groups.
-__global__ void split_planes_kernel(const float* w, int rows, int cols, int cols_p, __bf16* hi, __bf16* lo) {
-    const long total = (long)rows * cols_p;
+__global__ void split_planes_kernel(const float* w, int rows, int rows_p, int cols, int cols_p, __bf16* hi, __bf16* lo) {
+    // K-BLOCK-MAJOR planes [cols_p/32][rows_p][32]: the weight tile of one K stage (all rows, 32 k) is a
+    // single contiguous region, so staging it is 1-KiB-contiguous wave loads (8 full 128-byte lines per
+    // instruction) instead of sixteen 64-byte row fragments -- the GEMMs are bound by the vector-memory
+    // request rate, not by bytes.  Rows >= `rows` and columns >= `cols` are zero.
+    const long total = (long)rows_p * cols_p;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / cols_p;
         const int c = (int)(i - r * cols_p);
-        const float x = c < cols ? w[r * cols + c] : 0.f;
+        const float x = (r < rows && c < cols) ? w[r * cols + c] : 0.f;
         const __bf16 h = (__bf16)x;
         const int t = c & 31, u = t >> 4, kq = (t >> 2) & 3, e = t & 3;
-        const long dst = r * cols_p + (c & ~31) + 8 * kq + 4 * u + e;
+        const long dst = ((long)(c >> 5) * rows_p + r) * 32 + 8 * kq + 4 * u + e;
         hi[dst] = h;
         lo[dst] = (__bf16)(x - (float)h);
     }
 }
 
-int launch_split_planes(const float* w, int rows, int cols, int cols_p, void* hi, void* lo, hipStream_t stream) {
-    const long total = (long)rows * cols_p;
+int launch_split_planes(const float* w, int rows, int rows_p, int cols, int cols_p, void* hi, void* lo,
+                        hipStream_t stream) {
+    const long total = (long)rows_p * cols_p;
     TimingScope ts("split_planes", stream);
     hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256)), dim3(256), 0, stream,
-                       w, rows, cols, cols_p, (__bf16*)hi, (__bf16*)lo);
+                       w, rows, rows_p, cols, cols_p, (__bf16*)hi, (__bf16*)lo);
     return check_launch("split_planes");
 }
 
 struct BFArgs {
     NTArgs g;                 // same meaning as the fp32 kernel; g.W is unused
-    const __bf16* whi;        // [N, Kp] bf16, zero padded
-    const __bf16* wlo;        // [N, Kp] (NPASS == 3)
-    int Kp;
+    const __bf16* whi;        // [Kp/32][Np][32] bf16, zero padded, K-permuted inside each block
+    const __bf16* wlo;        // same (NPASS == 3)
+    int Kp, Np;
 };
 
 // Main loop.  Only the weight tile is shared between waves, so only it goes through LDS
@@ -110,7 +115,7 @@ __device__ __forceinline__ void bf16_nt_mainloop(const BFArgs& a, int row0, int 
     for (int i = 0; i < B_IT; ++i) {
         const int idx = tid + BF_THREADS * i;
         const int r = idx >> 2, n = col0 + r;
-        b_src[i] = (idx < B_CH && n < g.N) ? (long)n * a.Kp + 8 * chunk : -1;
+        b_src[i] = (idx < B_CH && n < a.Np) ? (long)n * 32 + 8 * chunk : -1;       // rows >= N are zero in the planes
         b_off[i] = idx < B_CH ? (r * 4 + (chunk ^ nt_swz(r))) * 16 : -1;
     }
     const int b_frag = r16 * BF_ROWB + (kq ^ nt_swz(r16)) * 16;
@@ -143,7 +148,7 @@ __device__ __forceinline__ void bf16_nt_mainloop(const BFArgs& a, int row0, int 
 #pragma unroll
             for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
             bst[i] = z;
-            if (b_src[i] >= 0) bst[i] = *reinterpret_cast<const bf16x8*>(plane + b_src[i] + k0);
+            if (b_src[i] >= 0) bst[i] = *reinterpret_cast<const bf16x8*>(plane + b_src[i] + (long)(k0 >> 5) * a.Np * 32);
         }
     };
     auto store_b = [&](char* st) {
@@ -274,19 +279,20 @@ static int launch_bf_inst(const BFArgs& a, hipStream_t stream, const char* name)
 template <int AMODE, int EMODE, int NPASS>
 static int launch_bf_mode(const BFArgs& a, hipStream_t stream, const char* name) {
     const int N = a.g.N;
-    // widest tile that wastes least; 19 (304) and 13 (208) cover d = 300, 3d = 900, q = 200
+    // column-tile width: least padding among wide tiles (narrow tiles re-read A once per tile)
+    const int cand[6] = {19, 15, 13, 10, 8, 4};
     int nt = 19;
     long best = -1;
-    const int cand[4] = {19, 13, 8, 4};
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 6; ++i) {
+        if (cand[i] < 8 && N > 128) continue;
         const long pad = (long)cdiv(N, cand[i] * 16) * cand[i] * 16;
         if (best < 0 || pad < best) { best = pad; nt = cand[i]; }
     }
-    if (getenv("NRMS_NT15") && N > 600) nt = 15;
     switch (nt) {
-        case 15: return launch_bf_inst<15, AMODE, EMODE, NPASS>(a, stream, name);
         case 19: return launch_bf_inst<19, AMODE, EMODE, NPASS>(a, stream, name);
+        case 15: return launch_bf_inst<15, AMODE, EMODE, NPASS>(a, stream, name);
         case 13: return launch_bf_inst<13, AMODE, EMODE, NPASS>(a, stream, name);
+        case 10: return launch_bf_inst<10, AMODE, EMODE, NPASS>(a, stream, name);
         case 8: return launch_bf_inst<8, AMODE, EMODE, NPASS>(a, stream, name);
         default: return launch_bf_inst<4, AMODE, EMODE, NPASS>(a, stream, name);
     }
@@ -301,9 +307,10 @@ int launch_gemm_nt_bf16(int amode, int emode, int npass, const NTArgs& g_in, voi
     a.g = g_in;
     a.g.rows_per_tile = BF_BM;
     a.Kp = cdiv(g_in.K, BF_BK) * BF_BK;
+    a.Np = cdiv(g_in.N, 16) * 16;
     a.whi = (const __bf16*)wplanes;
-    a.wlo = a.whi + (long)g_in.N * a.Kp;
-    int rc = launch_split_planes(g_in.W, g_in.N, g_in.K, a.Kp, wplanes, (void*)(a.whi + (long)g_in.N * a.Kp), stream);
+    a.wlo = a.whi + (long)a.Np * a.Kp;
+    int rc = launch_split_planes(g_in.W, g_in.N, a.Np, g_in.K, a.Kp, wplanes, (void*)a.wlo, stream);
     if (rc) return rc;
     if (npass == 3) {
         if (amode == A_PLAIN && emode == E_STORE) return launch_bf_mode<A_PLAIN, E_STORE, 3>(a, stream, name);
@@ -410,16 +417,15 @@ static int launch_addfwd_bf_inst(const AddFwdArgs& a, const BFArgs& b, hipStream
     return check_launch("addattn_fwd");
 }
 
-int launch_split_planes(const float* w, int rows, int cols, int cols_p, void* hi, void* lo, hipStream_t stream);
-
 int launch_addattn_fwd_bf16(int npass, const AddFwdArgs& a, void* wplanes, hipStream_t stream) {
     BFArgs b;
     b.g = a.g;
     b.g.rows_per_tile = (BF_BM / a.S) * a.S;
     b.Kp = cdiv(a.g.K, BF_BK) * BF_BK;
+    b.Np = cdiv(a.g.N, 16) * 16;
     b.whi = (const __bf16*)wplanes;
-    b.wlo = b.whi + (long)a.g.N * b.Kp;
-    int rc = launch_split_planes(a.g.W, a.g.N, a.g.K, b.Kp, wplanes, (void*)b.wlo, stream);
+    b.wlo = b.whi + (long)b.Np * b.Kp;
+    int rc = launch_split_planes(a.g.W, a.g.N, b.Np, a.g.K, b.Kp, wplanes, (void*)b.wlo, stream);
     if (rc) return rc;
     const int q = a.g.N;
     if (npass == 3) {
@@ -462,7 +468,10 @@ static TNGeomB tnb_geom(int N, int K) {
     g.k_tiles = cdiv(K + 1, 16);
     g.n_wg = cdiv(g.n_tiles, TB_WN * 5);
     g.k_wg = cdiv(g.k_tiles, TB_WK * 5);
-    while (g.n_wg * g.k_wg < 32 && (32 % (g.n_wg * g.k_wg)) != 0 && g.n_wg < g.n_tiles) ++g.n_wg;
+    // prefer a tile count that divides an XCD's 32 CUs (one full round); give up if none is near
+    const int n0 = g.n_wg;
+    for (int n = n0; n <= 2 * n0 + 1 && n <= g.n_tiles; ++n)
+        if (n * g.k_wg <= 32 && 32 % (n * g.k_wg) == 0) { g.n_wg = n; break; }
     g.n_tpw = cdiv(g.n_tiles, g.n_wg);
     g.k_tpw = cdiv(g.k_tiles, g.k_wg);
     return g;
@@ -699,6 +708,8 @@ int launch_gemm_tn_bf16(int npass, const TNArgs& a_in, hipStream_t stream, const
     return check_launch("tn_reduce");
 }
 
-size_t gemm_nt_bf16_wplane_bytes(int N, int K) { return (size_t)2 * N * (cdiv(K, BF_BK) * BF_BK) * sizeof(__bf16); }
+size_t gemm_nt_bf16_wplane_bytes(int N, int K) {
+    return (size_t)2 * (cdiv(N, 16) * 16) * (cdiv(K, BF_BK) * BF_BK) * sizeof(__bf16);
+}
 
 }  // namespace nrms
