@@ -40,30 +40,33 @@ template <int NS, int ND>
 struct Prefetch {
     static constexpr int LPR = 16 * ND, RPI = 64 / LPR, IT = 32 * NS / RPI;
     float2 v[IT];
-    // Branch-free: every lane loads from a clamped (always valid) address and the out-of-range lanes
-    // are zeroed by a select afterwards.  A predicated load (`cond ? *p : 0`) makes hipcc branch
-    // around EACH load with an exec-mask save/restore and a wait, serialising the 32 loads of a unit.
+    // Branch-free: every lane loads from a clamped (always valid) address; the out-of-range lanes are
+    // zeroed by a select in store().  A predicated load (`cond ? *p : 0`) makes hipcc branch around
+    // EACH load with an exec-mask save/restore and a wait; a select placed HERE makes it wait for all
+    // the loads (vmcnt 31..0) before the unit's MFMAs start, i.e. no prefetch at all.  The raw values
+    // have no use until store(), so the loads stay in flight across the whole compute phase.
     __device__ __forceinline__ void load(const float* src, long ld, int S, int dk, int lane) {
         const int c2 = lane % LPR, rsub = lane / LPR;
-        const bool cok = 2 * c2 < dk;
-        const float* col = src + (cok ? 2 * c2 : 0);
+        const float* col = src + (2 * c2 < dk ? 2 * c2 : 0);
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = rsub + it * RPI;
-            const float2 t = *reinterpret_cast<const float2*>(col + (long)min(r, S - 1) * ld);
-            const bool ok = cok && r < S;
-            v[it].x = ok ? t.x : 0.f;
-            v[it].y = ok ? t.y : 0.f;
+            v[it] = *reinterpret_cast<const float2*>(col + (long)min(r, S - 1) * ld);
         }
     }
     // unconditional: out-of-range entries are zeros and land on the zero padding (rows < 32 NS,
     // columns < 32 ND are always inside the [SP][RS] image), which they thereby re-establish
     __device__ __forceinline__ void store(float* dst, int RS, int S, int dk, int lane) const {
         const int c2 = lane % LPR, rsub = lane / LPR;
+        const bool cok = 2 * c2 < dk;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = rsub + it * RPI;
-            *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = v[it];
+            const bool ok = cok && r < S;
+            float2 t;
+            t.x = ok ? v[it].x : 0.f;
+            t.y = ok ? v[it].y : 0.f;
+            *reinterpret_cast<float2*>(dst + r * RS + 2 * c2) = t;
         }
     }
 };

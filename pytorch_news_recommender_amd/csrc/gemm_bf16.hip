@@ -95,66 +95,77 @@ __device__ __forceinline__ void bf16_nt_mainloop(const BFArgs& a, int row0, int 
     const int r16 = lane & 15, kq = lane >> 4;
     const int chunk = tid & 3;
 
-    // ---- this lane's two A rows (one per 16-row MFMA tile)
+    // ---- this lane's two A rows (one per 16-row MFMA tile).  Rows past the tile's end alias its last
+    // valid row: their accumulators are computed and never stored, and every load stays unconditional.
+    // hipcc turns a conditional load into an exec-mask branch per load and, worse, waits (vmcnt 0) where
+    // the loaded value is first TOUCHED -- a zero-select or the tanh' factor next to the load therefore
+    // serialises the whole "prefetch" behind the memory latency.  Raw values only, selects at the split.
     const float* arow[2];
     float ascale[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int r = 32 * wave + 16 * mt + r16;
-        const long gr = (long)row0 + r;
-        arow[mt] = nullptr;
-        ascale[mt] = 0.f;
-        if (r < rows_valid) {
-            if (AMODE == A_PLAIN) arow[mt] = g.A + gr * g.lda;
-            else { arow[mt] = g.T + gr * (long)g.K; ascale[mt] = g.ds[gr]; }
-        }
+        const long gr = (long)row0 + min(32 * wave + 16 * mt + r16, rows_valid - 1);
+        if (AMODE == A_PLAIN) { arow[mt] = g.A + gr * g.lda; ascale[mt] = 0.f; }
+        else { arow[mt] = g.T + gr * (long)g.K; ascale[mt] = g.ds[gr]; }
     }
     long b_src[B_IT];
     int b_off[B_IT];
+    bool b_zero[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int idx = tid + BF_THREADS * i;
         const int r = idx >> 2, n = col0 + r;
-        b_src[i] = (idx < B_CH && n < a.Np) ? (long)n * 32 + 8 * chunk : -1;       // rows >= N are zero in the planes
+        b_src[i] = (long)min(n, a.Np - 1) * 32 + 8 * chunk;     // clamped: always a valid plane address
+        b_zero[i] = n >= a.Np;                                  // (rows N..Np-1 are zero in the planes)
         b_off[i] = idx < B_CH ? (r * 4 + (chunk ^ nt_swz(r))) * 16 : -1;
     }
     const int b_frag = r16 * BF_ROWB + (kq ^ nt_swz(r16)) * 16;
 
-    // A prefetch depth: 2 stages ahead where the accumulators leave room, 1 for the 304-wide tile
-    // (152 accumulator registers; depth 2 spilled ~50 VGPRs there)
-    constexpr int DEPTH = NT > 16 ? 1 : 2;
-    f32x4 ar[2][2][2];                 // [prefetch slot][m tile][k half]
+    f32x4 ar[2][2], qr[2];             // raw A fragment of the NEXT stage [m tile][k half] (+ q slice, A_DZ)
     bf16x8 bst[B_IT];                  // weight staging registers: ONE plane at a time (see the loop)
-    auto load_a = [&](int slot, int k0) {
+    const int k_last = g.K - 4;        // K % 4 == 0 (checked by the launcher)
+    auto load_a = [&](int k0) {
         const int k = k0 + 4 * kq;
+        const int ka = min(k, k_last), kb = min(k + 16, k_last);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-            if (arow[mt] != nullptr) {
-                if (k < g.K) u = *reinterpret_cast<const f32x4*>(arow[mt] + k);
-                if (k + 16 < g.K) v = *reinterpret_cast<const f32x4*>(arow[mt] + k + 16);
-                if (AMODE == A_DZ) {
-                    if (k < g.K) u = ascale[mt] * *reinterpret_cast<const f32x4*>(g.qv + k) * (1.0f - u * u);
-                    if (k + 16 < g.K) v = ascale[mt] * *reinterpret_cast<const f32x4*>(g.qv + k + 16) * (1.0f - v * v);
-                }
-            }
-            ar[slot][mt][0] = u; ar[slot][mt][1] = v;
+            ar[mt][0] = *reinterpret_cast<const f32x4*>(arow[mt] + ka);
+            ar[mt][1] = *reinterpret_cast<const f32x4*>(arow[mt] + kb);
         }
+        if (AMODE == A_DZ) {
+            qr[0] = *reinterpret_cast<const f32x4*>(g.qv + ka);
+            qr[1] = *reinterpret_cast<const f32x4*>(g.qv + kb);
+        }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto split_a = [&](int k0, Split8& a0, Split8& a1) {
+        const int k = k0 + 4 * kq;
+        const bool ok0 = k < g.K, ok1 = k + 16 < g.K;
+        Split8 out[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 u = ar[mt][0], v = ar[mt][1];
+            if (AMODE == A_DZ) {
+                u = ascale[mt] * qr[0] * (1.0f - u * u);
+                v = ascale[mt] * qr[1] * (1.0f - v * v);
+            }
+            out[mt] = split8(ok0 ? u : zero4, ok1 ? v : zero4);
+        }
+        a0 = out[0]; a1 = out[1];
     };
     auto load_b = [&](const __bf16* plane, int k0) {
+        const __bf16* blk = plane + (long)(k0 >> 5) * a.Np * 32;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            bf16x8 z;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
-            bst[i] = z;
-            if (b_src[i] >= 0) bst[i] = *reinterpret_cast<const bf16x8*>(plane + b_src[i] + (long)(k0 >> 5) * a.Np * 32);
-        }
+        for (int i = 0; i < B_IT; ++i) bst[i] = *reinterpret_cast<const bf16x8*>(blk + b_src[i]);
     };
     auto store_b = [&](char* st) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (b_off[i] >= 0) *reinterpret_cast<bf16x8*>(st + b_off[i]) = bst[i];
+            if ((i + 1) * BF_THREADS <= B_CH || b_off[i] >= 0)
+                *reinterpret_cast<bf16x8*>(st + b_off[i]) = b_zero[i] ? z : bst[i];
     };
     auto read_b = [&](const char* cur, int nt, bf16x8& hi, bf16x8& lo) {
         hi = *reinterpret_cast<const bf16x8*>(cur + b_frag + nt * 16 * BF_ROWB);
@@ -172,11 +183,10 @@ __device__ __forceinline__ void bf16_nt_mainloop(const BFArgs& a, int row0, int 
     };
 
     const int n_stage = (g.K + BF_BK - 1) / BF_BK;
-    load_a(0, 0);
-    if (DEPTH == 2 && n_stage > 1) load_a(1, BF_BK);
     load_b(a.whi, 0);
     store_b(smem);
     if (NPASS == 3) { load_b(a.wlo, 0); store_b(smem + B_PLANE); }
+    load_a(0);
     __syncthreads();
     constexpr int HALF = (NT + 1) / 2;
 #pragma unroll 2
@@ -185,12 +195,15 @@ __device__ __forceinline__ void bf16_nt_mainloop(const BFArgs& a, int row0, int 
         char* nxt = smem + ((s + 1) & 1) * STAGE;
         const bool more = s + 1 < n_stage;
         const int kn = (s + 1) * BF_BK;
-        if (more) load_b(a.whi, kn);                           // hi plane of the next stage flies during half 1
-        const int slot = s & 1;
-        if (DEPTH == 1 && more) load_a(slot ^ 1, kn);
-        const Split8 a0 = split8(ar[slot][0][0], ar[slot][0][1]);
-        const Split8 a1 = split8(ar[slot][1][0], ar[slot][1][1]);
-        if (DEPTH == 2 && s + 2 < n_stage) load_a(slot, (s + 2) * BF_BK);
+        // the raw registers die at the split, so the next stage's fragment is loaded straight back into
+        // them and stays in flight for the whole stage (no slot array: a run-time slot index makes hipcc
+        // address the registers through movrel, behind a full vmcnt(0))
+        Split8 a0, a1;
+        split_a(s * BF_BK, a0, a1);
+        if (more) {
+            load_b(a.whi, kn);                                 // hi plane of the next stage flies during half 1
+            load_a(kn);
+        }
         // fragment reads run one tile ahead of the MFMAs that consume them (6 MFMAs = 96 cycles per
         // tile would otherwise expose the full LDS latency every iteration)
         bf16x8 bh0, bl0, bh1, bl1;
