@@ -532,12 +532,20 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
 
-    int a_r[TB_A_IT], a_c[TB_A_IT], b_r[TB_B_IT], b_c[TB_B_IT];
+    // Staging slots of this thread.  Every global load is unconditional from a clamped (valid) address;
+    // validity is applied when the registers are split into the LDS planes, a whole stage later (a
+    // predicate next to the load costs an exec-mask branch per load and drags the wait up to it).
+    int a_r[TB_A_IT], a_c[TB_A_IT], a_n[TB_A_IT], b_r[TB_B_IT], b_c[TB_B_IT], b_k[TB_B_IT];
+    bool a_ok[TB_A_IT], b_ok[TB_B_IT], b_one[TB_B_IT];
+    f32x4 qv_r[TB_A_IT];
 #pragma unroll
     for (int i = 0; i < TB_A_IT; ++i) {
         const int sl = tid + TB_THREADS * i;
         a_r[i] = sl / (TB_AW / 4);
         a_c[i] = (sl - a_r[i] * (TB_AW / 4)) * 4;
+        a_ok[i] = a_c[i] < n_cols && ncol0 + a_c[i] < a.N;
+        a_n[i] = min(ncol0 + a_c[i], a.N - 4);
+        if (AMODE == A_DZ) qv_r[i] = *reinterpret_cast<const f32x4*>(a.qv + a_n[i]);
     }
 #pragma unroll
     for (int i = 0; i < TB_B_IT; ++i) {
@@ -545,35 +553,28 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
         b_r[i] = sl / (TB_BW / 4);
         b_c[i] = (sl - b_r[i] * (TB_BW / 4)) * 4;
         if (b_r[i] >= TB_MC) { b_r[i] = 0; b_c[i] = TB_BW; }
+        const int k = kcol0 + b_c[i];
+        b_ok[i] = b_c[i] < k_cols && k < a.K;
+        b_one[i] = b_c[i] < k_cols && k == a.K;            // the ones column that yields the bias gradient
+        b_k[i] = min(k, a.K - 4);
     }
 
-    f32x4 av[TB_A_IT], bv[TB_B_IT];
-    auto load_stage = [&](int m0) {
+    struct Regs { f32x4 a[TB_A_IT], b[TB_B_IT]; float ds[TB_A_IT]; };
+    auto load_stage = [&](Regs& R, int m0) {
 #pragma unroll
         for (int i = 0; i < TB_A_IT; ++i) {
-            const long m = (long)m0 + a_r[i];
-            const int n = ncol0 + a_c[i];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && a_c[i] < n_cols && n < a.N) {
-                if (AMODE == A_PLAIN) {
-                    v = *reinterpret_cast<const f32x4*>(a.A + m * a.lda + n);
-                } else {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(a.T + m * (long)a.N + n);
-                    v = a.ds[m] * *reinterpret_cast<const f32x4*>(a.qv + n) * (1.0f - t * t);
-                }
+            const long m = min(m0 + a_r[i], m_end - 1);
+            if (AMODE == A_PLAIN) {
+                R.a[i] = *reinterpret_cast<const f32x4*>(a.A + m * a.lda + a_n[i]);
+            } else {
+                R.a[i] = *reinterpret_cast<const f32x4*>(a.T + m * (long)a.N + a_n[i]);
+                R.ds[i] = a.ds[m];
             }
-            av[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < TB_B_IT; ++i) {
-            const long m = (long)m0 + b_r[i];
-            const int k = kcol0 + b_c[i];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && b_c[i] < k_cols) {
-                if (k < a.K) v = *reinterpret_cast<const f32x4*>(a.B + m * a.ldb + k);
-                else if (k == a.K) v[0] = 1.0f;
-            }
-            bv[i] = v;
+            const long m = min(m0 + b_r[i], m_end - 1);
+            R.b[i] = *reinterpret_cast<const f32x4*>(a.B + m * a.ldb + b_k[i]);
         }
     };
     auto split4 = [](const f32x4& v, bf16x4& hi, bf16x4& lo) {
@@ -584,11 +585,15 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
             lo[e] = (__bf16)(v[e] - (float)h);
         }
     };
-    auto store_stage = [&](char* st) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto store_stage = [&](const Regs& R, int m0, char* st) {
 #pragma unroll
         for (int i = 0; i < TB_A_IT; ++i) {
+            f32x4 v = R.a[i];
+            if (AMODE == A_DZ) v = R.ds[i] * qv_r[i] * (1.0f - v * v);
+            v = (a_ok[i] && m0 + a_r[i] < m_end) ? v : zero4;
             bf16x4 hi, lo;
-            split4(av[i], hi, lo);
+            split4(v, hi, lo);
             const int off = (a_r[i] * TB_PA + a_c[i]) * 2;
             *reinterpret_cast<bf16x4*>(st + off) = hi;
             if (NPASS == 3) *reinterpret_cast<bf16x4*>(st + TB_A_PLANE + off) = lo;
@@ -596,8 +601,11 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
 #pragma unroll
         for (int i = 0; i < TB_B_IT; ++i) {
             if (b_c[i] >= TB_BW) continue;
+            const bool mok = m0 + b_r[i] < m_end;
+            f32x4 v = (b_ok[i] && mok) ? R.b[i] : zero4;
+            if (b_one[i] && mok) v[0] = 1.0f;
             bf16x4 hi, lo;
-            split4(bv[i], hi, lo);
+            split4(v, hi, lo);
             const int off = P * TB_A_PLANE + (b_r[i] * TB_PB + b_c[i]) * 2;
             *reinterpret_cast<bf16x4*>(st + off) = hi;
             if (NPASS == 3) *reinterpret_cast<bf16x4*>(st + TB_B_PLANE + off) = lo;
@@ -610,16 +618,9 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
 #pragma unroll
         for (int jj = 0; jj < NTK; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int n_stage = (m_end - m_begin + TB_MC - 1) / TB_MC;
-    if (n_stage > 0) {
-        load_stage(m_begin);
-        store_stage(smem);
-    }
-    __syncthreads();
-    for (int s = 0; s < n_stage; ++s) {
+    auto compute = [&](int s) {
         const char* As = smem + (s & 1) * STAGE;
         const char* Bs = As + P * TB_A_PLANE;
-        if (s + 1 < n_stage) load_stage(m_begin + (s + 1) * TB_MC);
         bf16x8 bh[NTK], bl[NTK];
 #pragma unroll
         for (int jj = 0; jj < NTK; ++jj) {
@@ -640,8 +641,45 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[jj], acc[i][jj], 0, 0, 0);
             }
         }
-        if (s + 1 < n_stage) store_stage(smem + ((s + 1) & 1) * STAGE);
+    };
+
+    // A stage is only ~1k cycles of MFMA per wave, less than one HBM round trip, and all 8 waves move
+    // in lockstep: where the accumulators leave room the raw rows are prefetched TWO stages ahead in
+    // two register sets (named statically: the loop is unrolled by two, a run-time set index would
+    // go through movrel).  At the top of stage s the set holding stage s+1 (issued a whole stage
+    // ago) is split into the free LDS buffer while the loads of stage s+2 are already in flight.
+    // The stage body is branch-free on purpose: loads past the split's end read its last row (clamped)
+    // and are zeroed at the split, the odd stage count is rounded up to even (one all-zero stage).
+    // With an `if (more)` around the loads, hipcc's waitcnt pass merges the two paths and then waits
+    // for the loads it has JUST issued (vmcnt(7) after 8 loads) -- again no prefetch.
+    constexpr bool DEEP = NTN * NTK <= 20;
+    int n_stage = (m_end - m_begin + TB_MC - 1) / TB_MC;
+    Regs R0, R1;
+    if (n_stage <= 0) return;
+    load_stage(R1, m_begin);
+    store_stage(R1, m_begin, smem);
+    if (DEEP) {
+        n_stage = (n_stage + 1) & ~1;
+        load_stage(R0, m_begin + TB_MC);
         __syncthreads();
+        auto body = [&](const Regs& Rs, Regs& Rl, int s) {
+            load_stage(Rl, m_begin + (s + 2) * TB_MC);
+            store_stage(Rs, m_begin + (s + 1) * TB_MC, smem + ((s + 1) & 1) * STAGE);
+            compute(s);
+            __syncthreads();
+        };
+        for (int s = 0; s < n_stage; s += 2) {
+            body(R0, R1, s);
+            body(R1, R0, s + 1);
+        }
+    } else {
+        __syncthreads();
+        for (int s = 0; s < n_stage; ++s) {
+            load_stage(R0, m_begin + (s + 1) * TB_MC);
+            compute(s);
+            store_stage(R0, m_begin + (s + 1) * TB_MC, smem + ((s + 1) & 1) * STAGE);
+            __syncthreads();
+        }
     }
     const long n_pad = (long)g.n_tiles * 16, k_pad = (long)g.k_tiles * 16;
     float* slab = a.partial + (long)split * n_pad * k_pad;
