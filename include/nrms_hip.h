@@ -96,7 +96,7 @@ typedef struct nrms_encoder_acts {
     float* ctx;            /* [M, d]   head-concatenated attention output AFTER dropout */
     float* t;              /* [M, q]   tanh(linear(ctx))            (nrms_v0.py:108) */
     float* w;              /* [M]      additive-attention softmax weights (nrms_v0.py:110-112) */
-    void*  scratch;        /* nrms_encoder_fwd_scratch_bytes(desc) bytes (bf16 weight planes); NULL if that is 0 */
+    void*  scratch;        /* nrms_encoder_fwd_scratch_bytes(desc) bytes: head-major W_qkv copy + bf16 weight planes */
 } nrms_encoder_acts;
 
 /* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V

@@ -17,11 +17,13 @@ namespace nrms {
 struct AttnArgs {
     int n_seq, S, d, h, dk;
     float scale;            // 1/sqrt(d_k)
-    const float* qkv;       // [M, 3d]
+    const float* qkv;       // [M, 3d] HEAD-MAJOR columns: [head][Q | K | V][d_k]  (see HeadPerm, common.h)
     float* ctx;             // fwd out [M, d]
     Dropout drop;           // fwd: site 1 on ctx
     const float* dctx;      // bwd in  [M, d] gradient w.r.t. the pre-dropout context (mask already applied)
-    float* dqkv;            // bwd out [M, 3d]
+    float* dqkv;            // bwd out [M, 3d], same head-major column order
+    int w2, hw;             // float2 per row of one head block (3 d_k / 2) and of one operand (d_k / 2)
+    uint32_t magic;         // ceil(2^20 / w2): idx / w2 == (idx * magic) >> 20 for idx < 2^20 / w2
     const uint8_t* mask;    // optional [n_seq, S]: v1's pairwise mask mask_i*mask_j -> masked_fill(-1e9)
                             // (model/nrms_v1.py:27-33); null = v0 (no mask at all)
 };
@@ -70,6 +72,80 @@ struct Prefetch {
         }
     }
 };
+
+// The Q, K and V slices of one head are ONE contiguous [S x 3 d_k] block per row (head-major columns,
+// 360 bytes at d_k = 30): lanes walk it densely, 64 consecutive float2 per instruction, so a wave
+// instruction touches ~5 cache lines instead of the 8 that four separate 120-byte row slices straddle
+// (these kernels are bound by the line-touch rate of the vector memory path, not by bytes).
+template <int NS, int ND>
+struct PrefetchQKV {
+    static constexpr int IT = 24 * NS * ND;         // >= 32 NS * 48 ND / 64
+    // Where the registers allow (32x32 tiles) each iteration's block position is computed ONCE per wave
+    // and kept packed in one register: bits 0-15 global offset in float2 (row * ld/2 + c), 16-27 offset
+    // inside the operand image in float2 (row * RS/2 + c'), 28-29 operand (0 Q, 1 K, 2 V), 31 = out of
+    // range.  Recomputing it per unit costs ~20 VALU per iteration -- a fifth of the forward kernel.
+    static constexpr bool PACKED = NS * ND == 1;
+    float2 v[IT];
+    uint32_t pos[PACKED ? IT : 1];
+
+    __device__ __forceinline__ static uint32_t pack(int idx, long ld, int RS, int total, int w2, int hw, uint32_t magic) {
+        const int ic = min(idx, total - 1);
+        const int row = (int)(((uint32_t)ic * magic) >> 20);
+        const int c = ic - row * w2;
+        const int which = (c >= hw ? 1 : 0) + (c >= 2 * hw ? 1 : 0);
+        return (uint32_t)(row * (int)(ld >> 1) + c) | ((uint32_t)(row * (RS >> 1) + c - which * hw) << 16) |
+               ((uint32_t)which << 28) | (idx < total ? 0u : 0x80000000u);
+    }
+    __device__ __forceinline__ void init(long ld, int RS, int total, int w2, int hw, uint32_t magic, int lane) {
+        if (PACKED) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) pos[it] = pack(lane + 64 * it, ld, RS, total, w2, hw, magic);
+        }
+    }
+    // called at the top of every unit: makes the packed words opaque again, otherwise the compiler hoists
+    // their three unpacked forms (global offset, LDS address, predicate) out of the unit loop
+    __device__ __forceinline__ void touch() {
+        if (PACKED) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) asm volatile("" : "+v"(pos[it]));
+        }
+    }
+    __device__ __forceinline__ uint32_t at(int it, long ld, int RS, int total, int w2, int hw, uint32_t magic,
+                                           int lane) const {
+        return PACKED ? pos[it] : pack(lane + 64 * it, ld, RS, total, w2, hw, magic);
+    }
+    __device__ __forceinline__ void load(const float* src, long ld, int RS, int total, int w2, int hw, uint32_t magic,
+                                         int lane) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const uint32_t p = at(it, ld, RS, total, w2, hw, magic, lane);     // clamped: raw values only (see Prefetch)
+            v[it] = *reinterpret_cast<const float2*>(src + 2 * (p & 0xffffu));
+        }
+    }
+    // img: the three [SP][RS] images Q, K, V, contiguous
+    __device__ __forceinline__ void store(float* img, int SPRS, long ld, int RS, int total, int w2, int hw,
+                                          uint32_t magic, int lane) const {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const uint32_t p = at(it, ld, RS, total, w2, hw, magic, lane);
+            if ((int32_t)p >= 0)
+                *reinterpret_cast<float2*>(img + ((p >> 28) & 3u) * SPRS + 2 * ((p >> 16) & 0xfffu)) = v[it];
+        }
+    }
+};
+
+// Re-establish the zero padding of `n_img` contiguous [SP][RS] images (rows S.., columns d_k..DKP-1):
+// the staged outputs and the transpose image of the previous unit have dirtied it.
+__device__ __forceinline__ void zero_padding(float* img, int n_img, int SP, int RS, int DKP, int S, int dk, int lane) {
+    const float2 z = {0.f, 0.f};
+    const int wpad = (DKP - dk) >> 1;              // wave-uniform
+    for (int r = lane; r < n_img * SP; r += 64)
+        for (int j = 0; j < wpad; ++j) *reinterpret_cast<float2*>(img + r * RS + dk + 2 * j) = z;
+    const int per = (SP - S) * RS / 2;
+    for (int i = 0; i < n_img; ++i)
+        for (int idx = lane; idx < per; idx += 64)
+            *reinterpret_cast<float2*>(img + (i * SP + S) * RS + 2 * idx) = z;
+}
 
 // S^T (or dP^T) tiles: out[jt][it] += sum_d A[j][d] B[i][d]
 template <int NS, int ND>
@@ -223,29 +299,29 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
     const long total = (long)a.n_seq * a.h;
     const long ld = 3L * a.d;
     const long ustride = (long)gridDim.x * WPB;
-    Prefetch<NS, ND> pq, pk, pv;
+    PrefetchQKV<NS, ND> pf;
+    const int blk = a.S * a.w2;                 // float2 in one head block
     long u = (long)blockIdx.x * WPB + wave;
     if (u < total) {
         const long seq = u / a.h;
-        const float* base = a.qkv + seq * a.S * ld + (int)(u - seq * a.h) * a.dk;
-        pq.load(base, ld, a.S, a.dk, lane);
-        pk.load(base + a.d, ld, a.S, a.dk, lane);
-        pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+        pf.init(ld, RS, blk, a.w2, a.hw, a.magic, lane);
+        pf.load(a.qkv + seq * a.S * ld + (int)(u - seq * a.h) * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
     }
     for (; u < total; u += ustride) {
         const long seq = u / a.h;
         const int head = (int)(u - seq * a.h);
-        pq.store(Qs, RS, a.S, a.dk, lane);
-        pk.store(Ks, RS, a.S, a.dk, lane);
-        pv.store(Vs, RS, a.S, a.dk, lane);
+        // opaque copy of the lane id: where the positions are not kept packed (big tiles) they are
+        // recomputed for every unit instead of being hoisted out of the loop into ~100 live registers
+        int lv = lane;
+        asm volatile("" : "+v"(lv));
+        pf.touch();
+        pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+        zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
         if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
         wave_sync();
-        if (u + ustride < total) {            // next unit's operands fly while this one computes
-            const long un = u + ustride, sn = un / a.h;
-            const float* base = a.qkv + sn * a.S * ld + (int)(un - sn * a.h) * a.dk;
-            pq.load(base, ld, a.S, a.dk, lane);
-            pk.load(base + a.d, ld, a.S, a.dk, lane);
-            pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+        {                                        // next unit's operands fly while this one computes
+            const long un = min(u + ustride, total - 1), sn = un / a.h;
+            pf.load(a.qkv + sn * a.S * ld + (int)(un - sn * a.h) * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
         }
 
         f32x16 st[NS][NS];
@@ -310,33 +386,32 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
     const long total = (long)a.n_seq * a.h;
     const long ld = 3L * a.d;
     const long ustride = (long)gridDim.x * WPB;
-    Prefetch<NS, ND> pq, pk, pv, pg;
+    PrefetchQKV<NS, ND> pf;
+    Prefetch<NS, ND> pg;
+    const int blk = a.S * a.w2;
     long u = (long)blockIdx.x * WPB + wave;
     if (u < total) {
         const long seq = u / a.h;
         const int head = (int)(u - seq * a.h);
-        const float* base = a.qkv + seq * a.S * ld + head * a.dk;
-        pq.load(base, ld, a.S, a.dk, lane);
-        pk.load(base + a.d, ld, a.S, a.dk, lane);
-        pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+        pf.init(ld, RS, blk, a.w2, a.hw, a.magic, lane);
+        pf.load(a.qkv + seq * a.S * ld + head * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
         pg.load(a.dctx + seq * a.S * a.d + head * a.dk, a.d, a.S, a.dk, lane);
     }
     for (; u < total; u += ustride) {
         const long seq = u / a.h;
         const int head = (int)(u - seq * a.h);
-        pq.store(Qs, RS, a.S, a.dk, lane);
-        pk.store(Ks, RS, a.S, a.dk, lane);
-        pv.store(Vs, RS, a.S, a.dk, lane);
+        int lv = lane;                           // opaque: see attn_fwd_kernel
+        asm volatile("" : "+v"(lv));
+        pf.touch();
+        pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+        zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
         pg.store(Gs, RS, a.S, a.dk, lane);      // dctx arrives already masked (dctx GEMM epilogue)
         if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
         wave_sync();
-        if (PF && u + ustride < total) {
-            const long un = u + ustride, sn = un / a.h;
+        if (PF) {                                // unconditional (clamped): see gemm_bf16.hip on `if (more)`
+            const long un = min(u + ustride, total - 1), sn = un / a.h;
             const int hn = (int)(un - sn * a.h);
-            const float* base = a.qkv + sn * a.S * ld + hn * a.dk;
-            pq.load(base, ld, a.S, a.dk, lane);
-            pk.load(base + a.d, ld, a.S, a.dk, lane);
-            pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+            pf.load(a.qkv + sn * a.S * ld + hn * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
             pg.load(a.dctx + sn * a.S * a.d + hn * a.dk, a.d, a.S, a.dk, lane);
         }
 
@@ -389,24 +464,25 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
         stage_out<NS, ND>(Vs, RS, dv, a.S, a.dk, l32, hh);     // transpose image is dead now
         wave_sync();
 
-        constexpr int LPR = 16 * ND, RPI = 64 / LPR;
-        const int c2 = lane % LPR, rsub = lane / LPR;
-        if (2 * c2 < a.dk) {
-            float* ob = a.dqkv + seq * a.S * ld + head * a.dk + 2 * c2;
-            for (int r = rsub; r < a.S; r += RPI) {
-                *reinterpret_cast<float2*>(ob + r * ld) = *reinterpret_cast<const float2*>(Ks + r * RS + 2 * c2);
-                *reinterpret_cast<float2*>(ob + r * ld + a.d) = *reinterpret_cast<const float2*>(Gs + r * RS + 2 * c2);
-                *reinterpret_cast<float2*>(ob + r * ld + 2 * a.d) = *reinterpret_cast<const float2*>(Vs + r * RS + 2 * c2);
+        // dQ | dK | dV of this head: one contiguous block per row again, written densely
+        {
+            float* ob = a.dqkv + seq * a.S * ld + head * 3 * a.dk;
+            constexpr int OIT = 24 * NS * ND;
+#pragma unroll                                   // full: a run-time `it` would push pos[] into scratch
+            for (int it = 0; it < OIT; ++it) {
+                const uint32_t p = pf.at(it, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+                const uint32_t which = (p >> 28) & 3u;
+                const float* img = which == 0 ? Ks : (which == 1 ? Gs : Vs);       // dQ, dK, dV staging images
+                if ((int32_t)p >= 0)
+                    *reinterpret_cast<float2*>(ob + 2 * (p & 0xffffu)) =
+                        *reinterpret_cast<const float2*>(img + 2 * ((p >> 16) & 0xfffu));
             }
         }
         wave_sync();
-        if (!PF && u + ustride < total) {     // big tiles: no registers to spare, load after the compute
-            const long un = u + ustride, sn = un / a.h;
+        if (!PF) {                            // big tiles: no registers to spare, load after the compute
+            const long un = min(u + ustride, total - 1), sn = un / a.h;
             const int hn = (int)(un - sn * a.h);
-            const float* base = a.qkv + sn * a.S * ld + hn * a.dk;
-            pq.load(base, ld, a.S, a.dk, lane);
-            pk.load(base + a.d, ld, a.S, a.dk, lane);
-            pv.load(base + 2 * a.d, ld, a.S, a.dk, lane);
+            pf.load(a.qkv + sn * a.S * ld + hn * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
             pg.load(a.dctx + sn * a.S * a.d + hn * a.dk, a.d, a.S, a.dk, lane);
         }
     }
@@ -449,6 +525,8 @@ int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv,
     a.n_seq = n_seq; a.S = S; a.d = d; a.h = h; a.dk = d / h;
     a.scale = 1.0f / sqrtf((float)a.dk);
     a.qkv = qkv; a.ctx = ctx; a.drop = drop; a.dctx = dctx; a.dqkv = dqkv;
+    a.hw = a.dk / 2; a.w2 = 3 * a.hw;
+    a.magic = a.w2 > 0 ? (uint32_t)(((1u << 20) + a.w2 - 1) / a.w2) : 0;
     if (n_seq <= 0) return NRMS_OK;
     if (S < 1 || S > 64 || a.dk > 64 || (a.dk & 1)) {
         set_error("attention: unsupported S=%d d_k=%d (need 1<=S<=64, even d_k<=64)", S, a.dk);

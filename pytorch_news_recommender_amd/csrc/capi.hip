@@ -140,6 +140,18 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
 
 using namespace nrms;
 
+// forward scratch: head-major copies of W_qkv / b_qkv (HeadPerm, common.h), then the bf16 weight planes
+struct FwdScratch { size_t wq, bq, planes, total; };
+static FwdScratch fwd_scratch(const nrms_encoder_desc* d) {
+    FwdScratch f;
+    const size_t dm = (size_t)d->d_model;
+    f.wq = 0;
+    f.bq = align_up(3 * dm * dm * sizeof(float), 256);
+    f.planes = f.bq + align_up(3 * dm * sizeof(float), 256);
+    f.total = f.planes + wplane_bytes(d);
+    return f;
+}
+
 extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
                                 const float* x, const uint8_t* mask, const nrms_encoder_acts* acts, float* out,
                                 void* stream) {
@@ -169,12 +181,19 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
         if (rc) return rc;
         xin = acts->x;
     }
+    NRMS_REQUIRE(acts->scratch != nullptr, "encoder_fwd: acts.scratch (nrms_encoder_fwd_scratch_bytes) is required");
+    const FwdScratch fs = fwd_scratch(desc);
+    float* wq_hm = (float*)((char*)acts->scratch + fs.wq);
+    float* bq_hm = (float*)((char*)acts->scratch + fs.bq);
+    void* wplanes = (char*)acts->scratch + fs.planes;
+    const HeadPerm perm{d / desc->n_heads, desc->n_heads};
+    rc = launch_permute_rows(w->w_qkv, w->b_qkv, wq_hm, bq_hm, 3 * d, d, perm, s);
+    if (rc) return rc;
     NTArgs g{};
     g.M = M; g.N = 3 * d; g.K = d; g.rows_per_tile = NT_BM;
     g.A = xin; g.lda = d;
-    g.W = w->w_qkv; g.bias = w->b_qkv; g.C = acts->qkv; g.ldc = 3 * d;
-    NRMS_REQUIRE(wplane_bytes(desc) == 0 || acts->scratch != nullptr, "encoder_fwd: acts.scratch is required for this precision");
-    rc = nt_gemm(desc, A_PLAIN, E_STORE, g, acts->scratch, s, "qkv_proj_fwd");
+    g.W = wq_hm; g.bias = bq_hm; g.C = acts->qkv; g.ldc = 3 * d;
+    rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "qkv_proj_fwd");
     if (rc) return rc;
     // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
     // concatenation, the output projection follows and carries the dropout in its epilogue.
@@ -185,17 +204,17 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
         NTArgs o{};
         o.M = M; o.N = d; o.K = d; o.rows_per_tile = NT_BM;
         o.A = acts->attn; o.lda = d; o.W = w->w_o; o.bias = w->b_o; o.C = acts->ctx; o.ldc = d; o.drop = drop_c;
-        rc = nt_gemm(desc, A_PLAIN, E_STORE, o, acts->scratch, s, "out_proj_fwd");
+        rc = nt_gemm(desc, A_PLAIN, E_STORE, o, wplanes, s, "out_proj_fwd");
         if (rc) return rc;
     }
     const int npass = desc->precision == NRMS_PRECISION_FP32 ? 0 : (desc->precision == NRMS_PRECISION_BF16X3 ? 3 : 1);
     return launch_addattn_fwd(desc->n_seq, S, d, q, acts->ctx, w->w_add, w->b_add, w->q_vec, acts->t, acts->w, out,
-                              pmask, npass, acts->scratch, s);
+                              pmask, npass, wplanes, s);
 }
 
 extern "C" size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc) {
     if (validate_desc(desc, "encoder_fwd_scratch_bytes")) return 0;
-    return wplane_bytes(desc);
+    return fwd_scratch(desc).total;
 }
 
 extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc) {
@@ -300,12 +319,13 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN;
         t.A = dqkv; t.lda = 3 * d; t.B = xin; t.ldb = d;
         t.dW = grads->w_qkv; t.dbias = grads->b_qkv; t.partial = tn_partial;
+        t.perm = HeadPerm{d / desc->n_heads, desc->n_heads};       // dQKV columns are head-major
         rc = tn_gemm(desc, t, s, "dwqkv_bwd");
         if (rc) return rc;
     }
     // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: dX goes to the (now dead)
     //    dctx buffer and is scatter-added through the embedding-dropout mask into the table gradient.
-    rc = launch_transpose(w->w_qkv, wqkv_t, 3 * d, d, s);
+    rc = launch_transpose(w->w_qkv, wqkv_t, 3 * d, d, s, HeadPerm{d / desc->n_heads, desc->n_heads});
     if (rc) return rc;
     {
         NTArgs g{};

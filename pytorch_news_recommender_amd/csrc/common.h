@@ -89,6 +89,22 @@ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint32_t site, ui
     return r[elem & 3] >= thresh ? inv_keep : 0.f;
 }
 
+// Head-major column order of the Q/K/V projection.  The reference's W_Q, W_K, W_V stack gives output
+// column n = which * d + head * d_k + j (which = 0,1,2 for Q,K,V; model/nrms_v0.py:53-58 splits the heads
+// afterwards).  The HIP path stores the projection as n' = head * 3 d_k + which * d_k + j, so that one
+// head's Q, K and V slices are a single contiguous 3 d_k block per row (attention.hip).  It is a pure
+// relabelling of GEMM columns: the weight rows are permuted when they are staged, the weight gradient
+// rows are permuted back when the partial sums are reduced.  dk == 0: identity.
+struct HeadPerm {
+    int dk, h;
+    __host__ __device__ __forceinline__ int src(int np) const {       // n' -> n
+        if (dk == 0) return np;
+        const int head = np / (3 * dk), r = np - head * 3 * dk;
+        const int which = r / dk, j = r - which * dk;
+        return which * h * dk + head * dk + j;
+    }
+};
+
 struct Dropout {
     uint64_t seed;
     uint32_t thresh;     // 0 => disabled

@@ -213,11 +213,16 @@ struct TNArgs {
     float* partial;           // workspace: [splits][n_pad][k_pad]
     int splits;
     int rows_per_split;
+    HeadPerm perm;            // row n' of the product is accumulated into dW / dbias row perm.src(n')
 };
 size_t gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int launch_gemm_tn(const TNArgs& a, hipStream_t stream, const char* name);
 
-int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t stream);
+// out[c][r'] = in[perm.src(r')][c]  (perm.dk == 0: plain transpose)
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t stream, HeadPerm perm = HeadPerm{0, 0});
+// w2[r'] = w[perm.src(r')] (rows of `cols` floats), b2[r'] = b[perm.src(r')]
+int launch_permute_rows(const float* w, const float* b, float* w2, float* b2, int rows, int cols, HeadPerm perm,
+                        hipStream_t stream);
 
 // gemm_bf16.hip: same NT contract with split-bf16 (npass 3) / bf16 (npass 1) MFMAs; wplanes is a
 // scratch of gemm_nt_bf16_wplane_bytes(N, K) bytes that receives the bf16 planes of W

@@ -265,14 +265,15 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
 }
 
 __global__ void tn_reduce_kernel(const float* partial, int splits, int N, int K, long n_pad, long k_pad,
-                                 float* dW, float* dbias) {
+                                 float* dW, float* dbias, HeadPerm perm) {
     const long total = (long)N * (K + 1);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long n = idx / (K + 1), k = idx - n * (K + 1);
         float s = 0.f;
         for (int sp = 0; sp < splits; ++sp) s += partial[(long)sp * n_pad * k_pad + n * k_pad + k];
-        if (k < K) dW[n * K + k] += s;
-        else if (dbias != nullptr) dbias[n] += s;
+        const long nd = perm.src((int)n);
+        if (k < K) dW[nd * K + k] += s;
+        else if (dbias != nullptr) dbias[nd] += s;
     }
 }
 
@@ -328,17 +329,17 @@ int launch_gemm_tn(const TNArgs& a_in, hipStream_t stream, const char* name) {
     const long total = (long)a.N * (a.K + 1);
     TimingScope ts("tn_reduce", stream);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a.partial, a.splits, a.N, a.K,
-                       (long)g.n_tiles * 16, (long)g.k_tiles * 16, a.dW, a.dbias);
+                       (long)g.n_tiles * 16, (long)g.k_tiles * 16, a.dW, a.dbias, a.perm);
     return check_launch("tn_reduce");
 }
 
 // =======================================================================================
-__global__ void transpose_kernel(const float* in, float* out, int rows, int cols) {
+__global__ void transpose_kernel(const float* in, float* out, int rows, int cols, HeadPerm perm) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += 8) {
         const int r = by + j, c = bx + threadIdx.x;
-        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(long)perm.src(r) * cols + c] : 0.f;
     }
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += 8) {
@@ -347,11 +348,27 @@ __global__ void transpose_kernel(const float* in, float* out, int rows, int cols
     }
 }
 
-int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t stream) {
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t stream, HeadPerm perm) {
     TimingScope ts("transpose", stream);
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, stream, in, out, rows,
-                       cols);
+                       cols, perm);
     return check_launch("transpose");
+}
+
+__global__ void permute_rows_kernel(const float* w, const float* b, float* w2, float* b2, int rows, int cols,
+                                    HeadPerm perm) {
+    const int r = blockIdx.x, rs = perm.src(r);
+    for (int c = threadIdx.x * 4; c < cols; c += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(w2 + (long)r * cols + c) = *reinterpret_cast<const f32x4*>(w + (long)rs * cols + c);
+    if (threadIdx.x == 0) b2[r] = b[rs];
+}
+
+int launch_permute_rows(const float* w, const float* b, float* w2, float* b2, int rows, int cols, HeadPerm perm,
+                        hipStream_t stream) {
+    if ((cols & 3) != 0) { set_error("permute_rows: cols=%d must be a multiple of 4", cols); return NRMS_EINVAL; }
+    TimingScope ts("permute_rows", stream);
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(rows), dim3(128), 0, stream, w, b, w2, b2, rows, cols, perm);
+    return check_launch("permute_rows");
 }
 
 }  // namespace nrms

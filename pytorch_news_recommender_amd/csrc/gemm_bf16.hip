@@ -700,14 +700,15 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
 }
 
 __global__ void tnb_reduce_kernel(const float* partial, int splits, int N, int K, long n_pad, long k_pad, float* dW,
-                                  float* dbias) {
+                                  float* dbias, HeadPerm perm) {
     const long total = (long)N * (K + 1);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long n = idx / (K + 1), k = idx - n * (K + 1);
         float s = 0.f;
         for (int sp = 0; sp < splits; ++sp) s += partial[(long)sp * n_pad * k_pad + n * k_pad + k];
-        if (k < K) dW[n * K + k] += s;
-        else if (dbias != nullptr) dbias[n] += s;
+        const long nd = perm.src((int)n);
+        if (k < K) dW[nd * K + k] += s;
+        else if (dbias != nullptr) dbias[nd] += s;
     }
 }
 
@@ -755,7 +756,7 @@ int launch_gemm_tn_bf16(int npass, const TNArgs& a_in, hipStream_t stream, const
     const long total = (long)a.N * (a.K + 1);
     TimingScope ts("tn_reduce", stream);
     hipLaunchKernelGGL(tnb_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a.partial, a.splits, a.N, a.K,
-                       (long)g.n_tiles * 16, (long)g.k_tiles * 16, a.dW, a.dbias);
+                       (long)g.n_tiles * 16, (long)g.k_tiles * 16, a.dW, a.dbias, a.perm);
     return check_launch("tn_reduce");
 }
 

@@ -158,7 +158,8 @@ class NRMSEngine:
         ctx = self._buf(tag + ".ctx", M * d)
         t = self._buf(tag + ".t", M * q) if need_bwd else None
         w = self._buf(tag + ".w", M) if need_bwd else None
-        scratch = self._buf("fwd_scratch", 1 << 20) if self.precision != "fp32" else None     # 4 MB >= any weight planes
+        # head-major W_qkv / b_qkv copies + bf16 weight planes: an upper bound of nrms_encoder_fwd_scratch_bytes
+        scratch = self._buf("fwd_scratch", 3 * d * d + 3 * d + 256 + (3 * d + 32) * (d + 32))
         dp = lambda z: None if z is None else z.data_ptr()
         return _lib.EncoderActs(x=dp(x), qkv=dp(qkv), attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
 
