@@ -159,9 +159,40 @@ __device__ __forceinline__ void gemm_nt_mainloop(const NTArgs& a, int row0, int 
 template <int NT, int EMODE>
 __device__ __forceinline__ void nt_epilogue(const NTArgs& g, const f32x4 (&acc)[2][NT], int row0, int rows_valid,
                                             int col0, int wave, int lane, float* wave_lds) {
+    // One store instruction = one whole row (or 64 / LPR rows of a narrow tile): with a row per
+    // instruction the row index is wave-uniform, so the C address is scalar arithmetic, and a lane's
+    // column -- hence its bias slice and its validity -- is fixed for the whole tile.  (The first version
+    // walked a flat index over the strip: a division, a 64-bit mad and a bias load per float4, ~2.6k
+    // VALU instructions per wave and tile, a fifth of the QKV GEMM.)
     constexpr int S = 16 * NT + 8;
     constexpr int F4_ROW = 4 * NT;               // float4 per row of the tile
+    constexpr int LPR = F4_ROW >= 64 ? 64 : F4_ROW;
+    constexpr int RPI = 64 / LPR;                // rows per store instruction: 1, 2 (NT = 8) or 4 (NT = 4)
+    constexpr int REM = F4_ROW - LPR * (RPI == 1 ? 1 : 0) > 0 && F4_ROW > 64 ? F4_ROW - 64 : 0;
+    static_assert(8 % RPI == 0, "strip rows must divide into store instructions");
     const int r16 = lane & 15, kq = lane >> 4;
+    const int sub = RPI == 1 ? 0 : lane / LPR;   // which of the RPI rows this lane stores
+    const int c4a = RPI == 1 ? lane : lane - sub * LPR;
+    const int na = col0 + 4 * c4a;
+    const bool ok_a = c4a < F4_ROW && sub < RPI && na < g.N;
+    f32x4 bias_a = {0.f, 0.f, 0.f, 0.f};
+    if (EMODE == E_STORE && g.bias != nullptr && ok_a) bias_a = *reinterpret_cast<const f32x4*>(g.bias + na);
+    const float inv_S = EMODE == E_STORE ? 0.f : 1.0f / (float)g.S;
+
+    // bias / w_s * dout of one float4 of row gr at column n
+    auto fix = [&](f32x4 v, long gr, int n, const f32x4& bias4) {
+        if (EMODE == E_STORE) return v + bias4;
+        const long seq = (long)(((float)gr + 0.5f) * inv_S);               // exact for gr < 2^22
+        return v + g.wrow[gr] * *reinterpret_cast<const f32x4*>(g.dout + seq * (long)g.N + n);
+    };
+    const bool dropped = g.drop.thresh != 0u;                              // uniform
+    auto rem_pos = [&](int idx, int rbase, int& sr, int& c4, int& rl, int& n) {
+        sr = idx / REM; c4 = 64 + idx - sr * REM;
+        rl = rbase + 4 * (sr >> 1) + (sr & 1);
+        n = col0 + 4 * c4;
+        return rl < rows_valid && n < g.N;
+    };
+
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -174,21 +205,63 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, const f32x4 (&acc)[
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int idx = lane; idx < 8 * F4_ROW; idx += 64) {
-                const int sr = idx / F4_ROW, c4 = idx - sr * F4_ROW;
-                const int rl = 32 * wave + 16 * mt + 4 * (sr >> 1) + 2 * h + (sr & 1);
-                const int n = col0 + 4 * c4;
-                if (rl >= rows_valid || n >= g.N) continue;
-                const long gr = (long)row0 + rl;
-                f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + sr * S + 4 * c4);
-                if (EMODE == E_STORE) {
-                    if (g.bias != nullptr) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-                } else {
-                    v += g.wrow[gr] * *reinterpret_cast<const f32x4*>(g.dout + (gr / g.S) * (long)g.N + n);
+            const int rbase = 32 * wave + 16 * mt + 2 * h;                   // wave-uniform
+            if (dropped) {
+                // dropout pass, in place in the strip (each lane rewrites exactly the float4s it stores
+                // below): kept out of the unrolled store pass so the Philox code exists once per strip
+#pragma unroll 1
+                for (int it = 0; it < 8 / RPI; ++it) {
+                    const int sr = it * RPI + sub;
+                    const int rl = rbase + 4 * (sr >> 1) + (sr & 1);
+                    if (ok_a && rl < rows_valid) {
+                        const long gr = (long)row0 + rl;
+                        f32x4* q = reinterpret_cast<f32x4*>(wave_lds + sr * S + 4 * c4a);
+                        *q = fix(*q, gr, na, bias_a) *
+                             dropout_scale4(g.drop.seed, 1u, (uint64_t)(gr * g.N + na) >> 2, g.drop.thresh, g.drop.inv_keep);
+                    }
                 }
-                if (g.drop.thresh != 0u)
-                    v *= dropout_scale4(g.drop.seed, 1u, (uint64_t)(gr * g.N + n) >> 2, g.drop.thresh, g.drop.inv_keep);
-                *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + n) = v;
+                if (REM > 0) {
+                    for (int idx = lane; idx < 8 * REM; idx += 64) {
+                        int sr, c4, rl, n;
+                        if (!rem_pos(idx, rbase, sr, c4, rl, n)) continue;
+                        const long gr = (long)row0 + rl;
+                        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                        if (EMODE == E_STORE && g.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+                        f32x4* q = reinterpret_cast<f32x4*>(wave_lds + sr * S + 4 * c4);
+                        *q = fix(*q, gr, n, b4) *
+                             dropout_scale4(g.drop.seed, 1u, (uint64_t)(gr * g.N + n) >> 2, g.drop.thresh, g.drop.inv_keep);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // store pass: unrolled, so the 8 strip reads (and the dout loads) are all in flight together
+#pragma unroll
+            for (int it = 0; it < 8 / RPI; ++it) {
+                const int sr = it * RPI + sub;                               // compile-time when RPI == 1
+                const int rl = rbase + 4 * (sr >> 1) + (sr & 1);
+                if (ok_a && rl < rows_valid) {
+                    const long gr = (long)row0 + rl;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + sr * S + 4 * c4a);
+                    if (!dropped) v = fix(v, gr, na, bias_a);
+                    *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + na) = v;
+                }
+            }
+            if (REM > 0) {
+                // columns 64.. of the wide tile: REM float4 per row, 8 rows, packed densely over the lanes
+                for (int idx = lane; idx < 8 * REM; idx += 64) {
+                    int sr, c4, rl, n;
+                    if (!rem_pos(idx, rbase, sr, c4, rl, n)) continue;
+                    const long gr = (long)row0 + rl;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + sr * S + 4 * c4);
+                    if (!dropped) {
+                        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                        if (EMODE == E_STORE && g.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+                        v = fix(v, gr, n, b4);
+                    }
+                    *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + n) = v;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
