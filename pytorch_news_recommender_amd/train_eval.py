@@ -73,9 +73,25 @@ def _save(config, model, total_batch, auc):
     return name
 
 
+def warmup_lr(base_lr, i, warm_up_steps):
+    """Learning rate the reference's warm-up phase applies to iteration ``i`` (0-based): its
+    GradualWarmupScheduler(multiplier=1, total_epoch=warm_up_steps) starts at 0 and is stepped with
+    ``scheduler.step(i)`` AFTER iteration i (train_eval.py:66-71,99; lr_scheduler.py:41-42), so iteration
+    i runs at base_lr * max(i - 1, 0) / warm_up_steps, capped at base_lr."""
+    return base_lr * min(max(i - 1, 0) / float(warm_up_steps), 1.0)
+
+
+def warmup_iterations(warm_up_steps=500):
+    """The reference leaves the warm-up loop with ``if i > 500: break`` after running iteration i
+    (train_eval.py:97-98): iterations 0..501 whatever warm_up_steps is."""
+    return 502
+
+
 def train(config, model, train_iter, dev_iter=None, dev_labels=None, use_autograd=False, max_batches=None,
           verbose=True):
-    """Returns dict(losses=[...per batch...], aucs=[(batch, auc), ...], ckpts=[...])."""
+    """Returns dict(losses=[...per batch...], aucs=[(batch, auc), ...], ckpts=[...]).
+    With config.warm_up the epochs are preceded by the reference's warm-up pass over the first
+    batches of train_iter with a linearly increasing learning rate (train_eval.py:64-99)."""
     net = _inner(model)
     rank, _, world = parallel.env_world()
     reduce = parallel.GradAllReduce() if world > 1 and torch.distributed.is_initialized() else None
@@ -86,9 +102,35 @@ def train(config, model, train_iter, dev_iter=None, dev_labels=None, use_autogra
         optimizer = torch.optim.Adam(model.parameters(), lr=config.learning_rate)
         criterion = nn.CrossEntropyLoss()
     total_batch, AUC_best, STEP_SIZE = 0, 0.56, 100          # train_eval.py:59,61
-    hist = dict(losses=[], aucs=[], ckpts=[])
+    hist = dict(losses=[], aucs=[], ckpts=[], warmup_losses=[])
     window = []
     done = False
+    if getattr(config, 'warm_up', False):
+        if verbose:
+            print('warm-up training...')
+        wlosses = []
+        for i, datas in enumerate(train_iter):
+            lr_i = warmup_lr(config.learning_rate, i, config.warm_up_steps)
+            if use_autograd:
+                for grp in optimizer.param_groups:
+                    grp['lr'] = lr_i
+                outputs = model(datas)
+                model.zero_grad()
+                loss = criterion(outputs, torch.zeros(len(outputs), dtype=torch.long, device=outputs.device))
+                loss.backward()
+                optimizer.step()
+                wlosses.append(loss.detach())
+            else:
+                wlosses.append(net.train_step(datas, lr=lr_i, world_size=world, all_reduce=reduce) /
+                               len(datas['browsed_titles']))
+            if i % 100 == 0 and verbose:
+                print('Warm-up Steps: {0:>6},  Train Loss: {1:>5.6}'.format(i, float(wlosses[-1])))
+            if i + 1 >= warmup_iterations(config.warm_up_steps) or (max_batches is not None and i + 1 >= max_batches):
+                break
+        hist['warmup_losses'] = [float(v) for v in wlosses]
+        if use_autograd:
+            for grp in optimizer.param_groups:
+                grp['lr'] = config.learning_rate
     for epoch in range(config.num_epochs):
         if verbose:
             print('Epoch [{}/{}]'.format(epoch + 1, config.num_epochs))

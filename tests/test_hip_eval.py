@@ -105,3 +105,37 @@ def test_train_evaluate_checkpoint_loop(tmp_path):
     # the reference's literal loop (autograd + torch.optim.Adam) drives the same kernels
     h2 = train_eval.train(cfg, m2, tl, None, None, use_autograd=True, max_batches=3, verbose=False)
     assert len(h2["losses"]) == 3 and np.isfinite(h2["losses"]).all()
+
+
+def test_warmup_phase_against_oracle():
+    """config.warm_up: the first batches run at the reference's linearly increasing learning rate
+    (train_eval.py:64-99); 5 warm-up iterations on the G1 shape against the oracle stepped with the
+    same per-iteration rate (iterations 0 and 1 run at lr = 0, so warm_up_steps is shrunk to 4)."""
+    from oracle import nrms_oracle as orc
+    from pytorch_news_recommender_amd import train_eval
+    from tests.test_hip_parity import tbatch, assert_params_close
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=61)
+    model = _model(shape, params)
+    cfg = model.config
+    cfg.warm_up, cfg.warm_up_steps, cfg.learning_rate, cfg.num_epochs = True, 4, 2e-3, 0
+    batches = [synth.make_batch(shape, seed=70 + t, ragged=True, min_title=1) for t in range(5)]
+    hist = train_eval.train(cfg, model, [tbatch(b) for b in batches], max_batches=5, verbose=False)
+    assert len(hist["warmup_losses"]) == 5 and not hist["losses"]
+    # oracle with the same schedule
+    p = {k: v.astype(np.float32).copy() for k, v in params.items()}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v_ = {k: np.zeros_like(v) for k, v in p.items()}
+    ref_losses = []
+    for t, b in enumerate(batches):
+        _, loss, grads, _ = orc.loss_and_grads(p, b, shape.num_attention_heads)
+        ref_losses.append(loss)
+        for k in p:
+            orc.adam_step(p[k], grads[k].astype(np.float32), m[k], v_[k], t + 1,
+                          lr=train_eval.warmup_lr(2e-3, t, 4))
+    np.testing.assert_allclose(hist["warmup_losses"], ref_losses, atol=2e-6)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for n in synth.param_names():
+        if n.endswith("W_K.bias"):
+            continue
+        assert_params_close(sd[n], p[n], n)

@@ -165,3 +165,33 @@ def test_synthetic_batch_layout():
     nz = t != 0
     assert (np.diff(nz.astype(int), axis=-1) <= 0).all()          # once padded, stays padded
     assert t.max() < shape.n_words
+
+
+def test_warmup_schedule_matches_reference_scheduler():
+    """train_eval.py:64-99 + lr_scheduler.py:41-42: linear ramp from 0, stepped after each iteration."""
+    import torch
+    from pytorch_news_recommender_amd.train_eval import warmup_lr, warmup_iterations
+
+    class Ramp(torch.optim.lr_scheduler.LRScheduler):          # the reference's multiplier == 1 branch
+        def __init__(self, opt, total):
+            self.total = total
+            super().__init__(opt)
+
+        def get_lr(self):
+            return [b * min(float(self.last_epoch) / self.total, 1.0) for b in self.base_lrs]
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = Ramp(opt, 500)
+    opt.zero_grad(); opt.step()
+    used = []
+    for i in range(warmup_iterations(500)):
+        used.append(opt.param_groups[0]['lr'])
+        p.grad = torch.ones(1); opt.step()
+        if i > 500:
+            break
+        sch.last_epoch = i - 1; sch.step()                      # == scheduler.step(i) of the reference
+    assert len(used) == 502
+    for i, lr in enumerate(used):
+        assert abs(lr - warmup_lr(1e-3, i, 500)) < 1e-12, (i, lr)
+    assert used[0] == 0.0 and used[1] == 0.0 and abs(used[501] - 1e-3) < 1e-15
