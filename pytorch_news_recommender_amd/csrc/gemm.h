@@ -62,29 +62,32 @@ __device__ __forceinline__ void gemm_nt_mainloop(const NTArgs& a, int row0, int 
 
     // ---- staging assignment: A rows (tid>>2) and (tid>>2)+64, 16-byte chunk tid&3
     const int chunk = tid & 3;
+    // Every load is unconditional from a clamped address and keeps the RAW value; row / column / K-tail
+    // validity and the tanh' factor are applied when the registers are written to LDS, a stage later
+    // (see gemm_bf16.hip: a predicate or arithmetic next to the load drags the wait up to it).
     const float* arow[2];
     float ascale[2];
+    bool a_ok[2];
     int a_lds[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (tid >> 2) + 64 * i;
-        const long g = (long)row0 + r;
-        arow[i] = nullptr;
-        ascale[i] = 0.f;
+        const long g = (long)row0 + min(r, rows_valid - 1);
+        a_ok[i] = r < rows_valid;
         a_lds[i] = (r * 4 + (chunk ^ nt_swz(r))) * 4;
-        if (r < rows_valid) {
-            if (AMODE == A_PLAIN) arow[i] = a.A + g * a.lda;
-            else { arow[i] = a.T + g * (long)a.K; ascale[i] = a.ds[g]; }
-        }
+        if (AMODE == A_PLAIN) { arow[i] = a.A + g * a.lda; ascale[i] = 0.f; }
+        else { arow[i] = a.T + g * (long)a.K; ascale[i] = a.ds[g]; }
     }
     const float* brow[B_IT];
+    bool b_ok[B_IT];
     int b_lds[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int idx = tid + 256 * i;
         const int r = idx >> 2;
         const int n = col0 + r;
-        brow[i] = (idx < B_F4 && n < a.N) ? a.W + (long)n * a.K : nullptr;
+        b_ok[i] = idx < B_F4 && n < a.N;
+        brow[i] = a.W + (long)min(n, a.N - 1) * a.K;
         b_lds[i] = idx < B_F4 ? NT_STAGE_A + (r * 4 + (chunk ^ nt_swz(r))) * 4 : -1;
     }
     // fragment read offsets (floats) inside a stage
@@ -93,44 +96,37 @@ __device__ __forceinline__ void gemm_nt_mainloop(const NTArgs& a, int row0, int 
     const int a_frag1 = ((32 * wave + 16 + r16) * 4 + fsw) * 4;
     const int b_frag = NT_STAGE_A + (r16 * 4 + fsw) * 4;
 
-    f32x4 av[2], bv[B_IT];
+    f32x4 av[2], bv[B_IT], qv4;
+    const int k_last = a.K - 4;                  // K % 4 == 0 (checked by the launcher)
     auto load_stage = [&](int k0) {
-        const int k = k0 + chunk * 4;
-        const bool kok = k < a.K;
+        const int k = min(k0 + chunk * 4, k_last);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const f32x4*>(arow[i] + k);
+        if (AMODE == A_DZ) qv4 = *reinterpret_cast<const f32x4*>(a.qv + k);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) bv[i] = *reinterpret_cast<const f32x4*>(brow[i] + k);
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto store_stage = [&](int k0, float* st) {
+        const bool kok = k0 + chunk * 4 < a.K;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (arow[i] != nullptr && kok) {
-                v = *reinterpret_cast<const f32x4*>(arow[i] + k);
-                if (AMODE == A_DZ) {
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(a.qv + k);
-                    v = ascale[i] * q * (1.0f - v * v);
-                }
-            }
-            av[i] = v;
+            f32x4 v = av[i];
+            if (AMODE == A_DZ) v = ascale[i] * qv4 * (1.0f - v * v);
+            *reinterpret_cast<f32x4*>(st + a_lds[i]) = (a_ok[i] && kok) ? v : zero4;
         }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (brow[i] != nullptr && kok) v = *reinterpret_cast<const f32x4*>(brow[i] + k);
-            bv[i] = v;
-        }
-    };
-    auto store_stage = [&](float* st) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(st + a_lds[i]) = av[i];
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (b_lds[i] >= 0) *reinterpret_cast<f32x4*>(st + b_lds[i]) = bv[i];
+            if (b_lds[i] >= 0) *reinterpret_cast<f32x4*>(st + b_lds[i]) = (b_ok[i] && kok) ? bv[i] : zero4;
     };
 
     const int n_stage = (a.K + NT_BK - 1) / NT_BK;
     load_stage(0);
-    store_stage(lds);
+    store_stage(0, lds);
     __syncthreads();
     for (int s = 0; s < n_stage; ++s) {
         const float* cur = lds + (s & 1) * STAGE;
-        if (s + 1 < n_stage) load_stage((s + 1) * NT_BK);
+        load_stage((s + 1) * NT_BK);             // branch-free: past K the address is clamped, the store writes zeros
         // K permutation: lane quarter kq takes k = 4 kq + e for MFMA e (A and B agree)
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(cur + a_frag0);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(cur + a_frag1);
@@ -143,7 +139,7 @@ __device__ __forceinline__ void gemm_nt_mainloop(const NTArgs& a, int row0, int 
                 acc[1][nt] = mfma16(a1[e], b[e], acc[1][nt]);
             }
         }
-        if (s + 1 < n_stage) store_stage(lds + ((s + 1) & 1) * STAGE);
+        store_stage((s + 1) * NT_BK, lds + ((s + 1) & 1) * STAGE);
         __syncthreads();
     }
 }

@@ -154,13 +154,20 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
 
-    // ---- fixed staging slots of this thread
-    int a_r[TN_A_IT], a_c[TN_A_IT], b_r[TN_B_IT], b_c[TN_B_IT];
+    // ---- fixed staging slots of this thread.  Loads are unconditional from clamped addresses and keep
+    // RAW values; validity and the tanh' factor are applied when the registers go to LDS, a stage later
+    // (a predicate or arithmetic next to the load makes hipcc wait for the load right there).
+    int a_r[TN_A_IT], a_c[TN_A_IT], a_n[TN_A_IT], b_r[TN_B_IT], b_c[TN_B_IT], b_k[TN_B_IT];
+    bool a_ok[TN_A_IT], b_ok[TN_B_IT], b_one[TN_B_IT];
+    f32x4 qv_r[TN_A_IT];
 #pragma unroll
     for (int i = 0; i < TN_A_IT; ++i) {
         const int sl = tid + TN_THREADS * i;
         a_r[i] = sl / (TN_AW / 4);
         a_c[i] = (sl - a_r[i] * (TN_AW / 4)) * 4;
+        a_ok[i] = a_c[i] < n_cols && ncol0 + a_c[i] < a.N;
+        a_n[i] = min(ncol0 + a_c[i], a.N - 4);
+        if (AMODE == A_DZ) qv_r[i] = *reinterpret_cast<const f32x4*>(a.qv + a_n[i]);
     }
 #pragma unroll
     for (int i = 0; i < TN_B_IT; ++i) {
@@ -168,45 +175,47 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
         b_r[i] = sl / (TN_BW / 4);
         b_c[i] = (sl - b_r[i] * (TN_BW / 4)) * 4;
         if (b_r[i] >= TN_MC) { b_r[i] = 0; b_c[i] = TN_BW; }     // unused slot
+        const int k = kcol0 + b_c[i];
+        b_ok[i] = b_c[i] < k_cols && k < a.K;
+        b_one[i] = b_c[i] < k_cols && k == a.K;                   // ones column -> bias gradient
+        b_k[i] = min(k, a.K - 4);
     }
 
     f32x4 av[TN_A_IT], bv[TN_B_IT];
+    float dsv[TN_A_IT];
     auto load_stage = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < TN_A_IT; ++i) {
-            const long m = (long)m0 + a_r[i];
-            const int n = ncol0 + a_c[i];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && a_c[i] < n_cols && n < a.N) {
-                if (AMODE == A_PLAIN) {
-                    v = *reinterpret_cast<const f32x4*>(a.A + m * a.lda + n);
-                } else {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(a.T + m * (long)a.N + n);
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(a.qv + n);
-                    v = a.ds[m] * q * (1.0f - t * t);
-                }
+            const long m = min(m0 + a_r[i], m_end - 1);
+            if (AMODE == A_PLAIN) {
+                av[i] = *reinterpret_cast<const f32x4*>(a.A + m * a.lda + a_n[i]);
+            } else {
+                av[i] = *reinterpret_cast<const f32x4*>(a.T + m * (long)a.N + a_n[i]);
+                dsv[i] = a.ds[m];
             }
-            av[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < TN_B_IT; ++i) {
-            const long m = (long)m0 + b_r[i];
-            const int k = kcol0 + b_c[i];
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && b_c[i] < k_cols) {
-                if (k < a.K) v = *reinterpret_cast<const f32x4*>(a.B + m * a.ldb + k);
-                else if (k == a.K) v[0] = 1.0f;                    // ones column -> bias gradient
-            }
-            bv[i] = v;
+            const long m = min(m0 + b_r[i], m_end - 1);
+            bv[i] = *reinterpret_cast<const f32x4*>(a.B + m * a.ldb + b_k[i]);
         }
     };
-    auto store_stage = [&](float* st) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto store_stage = [&](int m0, float* st) {
 #pragma unroll
-        for (int i = 0; i < TN_A_IT; ++i)
-            *reinterpret_cast<f32x4*>(st + a_r[i] * TN_SA + a_c[i]) = av[i];
+        for (int i = 0; i < TN_A_IT; ++i) {
+            f32x4 v = av[i];
+            if (AMODE == A_DZ) v = dsv[i] * qv_r[i] * (1.0f - v * v);
+            *reinterpret_cast<f32x4*>(st + a_r[i] * TN_SA + a_c[i]) = (a_ok[i] && m0 + a_r[i] < m_end) ? v : zero4;
+        }
 #pragma unroll
-        for (int i = 0; i < TN_B_IT; ++i)
-            if (b_c[i] < TN_BW) *reinterpret_cast<f32x4*>(st + TN_MC * TN_SA + b_r[i] * TN_SB + b_c[i]) = bv[i];
+        for (int i = 0; i < TN_B_IT; ++i) {
+            if (b_c[i] >= TN_BW) continue;
+            const bool mok = m0 + b_r[i] < m_end;
+            f32x4 v = (b_ok[i] && mok) ? bv[i] : zero4;
+            if (b_one[i] && mok) v[0] = 1.0f;
+            *reinterpret_cast<f32x4*>(st + TN_MC * TN_SA + b_r[i] * TN_SB + b_c[i]) = v;
+        }
     };
 
     f32x4 acc[NTN][NTK];
@@ -216,15 +225,15 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
         for (int jj = 0; jj < NTK; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int n_stage = (m_end - m_begin + TN_MC - 1) / TN_MC;
-    if (n_stage > 0) {
-        load_stage(m_begin);
-        store_stage(lds);
-    }
+    if (n_stage <= 0) return;
+    load_stage(m_begin);
+    store_stage(m_begin, lds);
     __syncthreads();
     for (int s = 0; s < n_stage; ++s) {
         const float* As = lds + (s & 1) * TN_STAGE;
         const float* Bs = As + TN_MC * TN_SA;
-        if (s + 1 < n_stage) load_stage(m_begin + (s + 1) * TN_MC);
+        // branch-free: past the split's end the loads re-read its last row and are zeroed at the store
+        load_stage(m_begin + (s + 1) * TN_MC);
         // 32 rows of M = 2 sub-chunks x 4 MFMA k-steps (m = 16 sub + 4 kq + e)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
                     for (int jj = 0; jj < NTK; ++jj) acc[i][jj] = mfma16(af[i], bf[jj], acc[i][jj]);
             }
         }
-        if (s + 1 < n_stage) store_stage(lds + ((s + 1) & 1) * TN_STAGE);
+        store_stage(m_begin + (s + 1) * TN_MC, lds + ((s + 1) & 1) * TN_STAGE);
         __syncthreads();
     }
     // ---- partial slab: [split][n_pad][k_pad]
