@@ -111,7 +111,7 @@ static size_t wplane_bytes(const nrms_encoder_desc* d) {
 }
 
 struct BwdWorkspace {
-    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, total;   // byte offsets
+    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, live, n_live, total;   // byte offsets
 };
 
 static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
@@ -132,6 +132,8 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     w.tn_partial = take(p1 > p2 ? (p1 > p3 ? p1 : p3) : (p2 > p3 ? p2 : p3));
     w.dq_partial = take((size_t)addattn_bwd_rows_waves(d->n_seq) * q);
     w.wplanes = take(wplane_bytes(d) / sizeof(float));
+    w.live = take(d->vocab > 0 ? M : 0);          // int32 positions of the non-padding tokens (news encoder)
+    w.n_live = take(d->vocab > 0 ? 64 : 0);
     w.total = off;
     return w;
 }
@@ -323,19 +325,29 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = tn_gemm(desc, t, s, "dwqkv_bwd");
         if (rc) return rc;
     }
-    // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: dX goes to the (now dead)
-    //    dctx buffer and is scatter-added through the embedding-dropout mask into the table gradient.
+    // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: dX is consumed only by the
+    //    embedding scatter, which skips padding tokens (padding_idx = 0, nrms_v0.py:134-136) -- in a
+    //    MIND-shaped batch about two thirds of the token rows.  Those rows of dX are dead values, so
+    //    the live token positions are compacted once and the GEMM (row-indirect A) and the scatter run
+    //    on them only; the compact dX goes to the (now dead) dctx buffer.
     rc = launch_transpose(w->w_qkv, wqkv_t, 3 * d, d, s, HeadPerm{d / desc->n_heads, desc->n_heads});
     if (rc) return rc;
+    int* live = (int*)(base + L.live);
+    int* n_live = (int*)(base + L.n_live);
+    if (gather) {
+        rc = launch_compact_live_rows((long)M, ids, live, n_live, s);
+        if (rc) return rc;
+    }
     {
         NTArgs g{};
         g.M = M; g.N = d; g.K = 3 * d; g.rows_per_tile = NT_BM;
         g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t;
         g.C = gather ? dctx : dx; g.ldc = d;
+        if (gather) { g.a_rows = live; g.m_dev = n_live; }
         rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "dx_bwd");
         if (rc) return rc;
     }
-    if (gather) rc = launch_scatter_dropout((long)M, d, ids, dctx, drop_e, grads->table, s);
+    if (gather) rc = launch_scatter_dropout_compact((long)M, d, ids, live, n_live, dctx, drop_e, grads->table, s);
     return rc;
 }
 

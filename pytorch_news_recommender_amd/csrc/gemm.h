@@ -39,6 +39,10 @@ struct NTArgs {
     int S;                    // E_DCTX: rows per sequence
     Dropout drop;             // optional epilogue dropout (thresh != 0), Philox site 1, element index
                               // g*N + n -- only the output-projection topology (nrms_v1) needs it here
+    // Row compaction (A_PLAIN only; both null = dense): row r of the product is row a_rows[r] of A, and
+    // the number of rows is read from device memory (*m_dev <= M; M sizes the grid).  C rows stay compact.
+    const int* a_rows;
+    const int* m_dev;
 };
 
 // LDS image of a K-stage: [rows][4 chunks of 16 B], the chunk index XOR-swizzled per 4-row group
@@ -75,7 +79,7 @@ __device__ __forceinline__ void gemm_nt_mainloop(const NTArgs& a, int row0, int 
         const long g = (long)row0 + min(r, rows_valid - 1);
         a_ok[i] = r < rows_valid;
         a_lds[i] = (r * 4 + (chunk ^ nt_swz(r))) * 4;
-        if (AMODE == A_PLAIN) { arow[i] = a.A + g * a.lda; ascale[i] = 0.f; }
+        if (AMODE == A_PLAIN) { arow[i] = a.A + (a.a_rows != nullptr ? (long)a.a_rows[g] : g) * a.lda; ascale[i] = 0.f; }
         else { arow[i] = a.T + g * (long)a.K; ascale[i] = a.ds[g]; }
     }
     const float* brow[B_IT];
@@ -317,5 +321,10 @@ int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table,
                           hipStream_t stream);
 int launch_scatter_dropout(long M, int d, const int64_t* ids, const float* dx, const Dropout& drop, float* dtable,
                            hipStream_t stream);
+// live[0 .. *n_live) = the token positions m with ids[m] != 0 (any order); *n_live is written by the kernel
+int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* n_live, hipStream_t stream);
+// same as launch_scatter_dropout for a COMPACT dx: row r of dx belongs to token live[r], r < *n_live
+int launch_scatter_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
+                                   const Dropout& drop, float* dtable, hipStream_t stream);
 
 }  // namespace nrms

@@ -17,8 +17,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs a) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int rt = (j / n_ct) * 8 + xcd;
     const int row0 = rt * a.rows_per_tile;
-    if (row0 >= a.M) return;
-    const int rows_valid = min(a.rows_per_tile, a.M - row0);
+    const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
+    if (row0 >= M) return;
+    const int rows_valid = min(a.rows_per_tile, M - row0);
     const int col0 = (j % n_ct) * (NT * 16);
 
     f32x4 acc[2][NT];

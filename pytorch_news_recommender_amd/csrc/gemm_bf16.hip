@@ -105,7 +105,7 @@ __device__ __forceinline__ void bf16_nt_mainloop(const BFArgs& a, int row0, int 
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const long gr = (long)row0 + min(32 * wave + 16 * mt + r16, rows_valid - 1);
-        if (AMODE == A_PLAIN) { arow[mt] = g.A + gr * g.lda; ascale[mt] = 0.f; }
+        if (AMODE == A_PLAIN) { arow[mt] = g.A + (g.a_rows != nullptr ? (long)g.a_rows[gr] : gr) * g.lda; ascale[mt] = 0.f; }
         else { arow[mt] = g.T + gr * (long)g.K; ascale[mt] = g.ds[gr]; }
     }
     long b_src[B_IT];
@@ -256,8 +256,9 @@ __global__ __launch_bounds__(BF_THREADS, 2) void gemm_nt_bf16_kernel(BFArgs a) {
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int rt = (jb / n_ct) * 8 + xcd;
     const int row0 = rt * g.rows_per_tile;
-    if (row0 >= g.M) return;
-    const int rows_valid = min(g.rows_per_tile, g.M - row0);
+    const int M = g.m_dev != nullptr ? *g.m_dev : g.M;
+    if (row0 >= M) return;
+    const int rows_valid = min(g.rows_per_tile, M - row0);
     const int col0 = (jb % n_ct) * (NT * 16);
 
     f32x4 acc[2][NT];
