@@ -221,6 +221,40 @@ def test_shape_sweep_against_oracle(shape):
         np.testing.assert_allclose(grads[n], o_grads[n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
 
 
+@pytest.mark.parametrize("case", ["all_padding", "no_padding", "one_live_token", "nonzero_pad_row"])
+def test_live_row_compaction_edges(case):
+    """The X-gradient GEMM and the embedding scatter run on the compacted non-padding token rows
+    (padding_idx rows get no gradient, nrms_v0.py:134-136): empty list, full list, a single live row,
+    and a table whose row 0 is NOT zero (from_pretrained keeps it: pad tokens then carry signal forward
+    but still receive no gradient)."""
+    from oracle import nrms_oracle as orc
+    shape = synth.Shape(n_words=300, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
+                        batch_size=5, history_len=9, n_candidates=4, n_words_title=11)
+    params = synth.make_params(shape, seed=111, pad_row_zero=(case != "nonzero_pad_row"))
+    batch = synth.make_batch(shape, seed=112, ragged=(case != "no_padding"), min_title=1)
+    if case == "all_padding":
+        batch["browsed_titles"][:] = 0
+        batch["candidate_titles"][:] = 0
+    if case == "one_live_token":
+        batch["browsed_titles"][:] = 0
+        batch["candidate_titles"][:] = 0
+        batch["candidate_titles"][3, 2, 0] = 17
+    if case == "no_padding":
+        assert (batch["candidate_titles"] != 0).all() and (batch["browsed_titles"] != 0).all()
+    model = make_model(shape, params)
+    scores, loss, grads = fwd_bwd(model, batch)
+    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads)
+    np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
+    for n in synth.param_names():
+        np.testing.assert_allclose(grads[n], o_grads[n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+    table_grad = grads["news_encoder.word_embedding.0.weight"]
+    assert (table_grad[0] == 0).all()                       # padding_idx row
+    if case == "all_padding":
+        assert (table_grad == 0).all()
+    if case == "one_live_token":
+        assert (np.abs(table_grad).sum(axis=1) != 0).sum() <= 1
+
+
 @pytest.mark.parametrize("precision,score_tol,grad_rtol", [("bf16x3", 1e-4, 2e-3), ("bf16", 5e-3, 6e-2)])
 def test_reduced_precision_modes(golden_dir, precision, score_tol, grad_rtol):
     """Split-bf16 projections must stay inside north_star's 1e-4 score bar against the REFERENCE fixture
