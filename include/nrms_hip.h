@@ -39,6 +39,15 @@ extern "C" {
                                    attention, softmaxes, pooling, loss, optimizer and all HBM tensors stay fp32 */
 #define NRMS_PRECISION_BF16   2 /* same kernels, hi*hi only: plain bf16 inputs, fp32 accumulate */
 
+/* nrms_encoder_desc.flags */
+/* The caller guarantees that row 0 of `table` (the padding row, nn.Embedding padding_idx=0,
+ * nrms_v0.py:134-136) is all zeros.  A padding token's embedding is then exactly zero (also under
+ * dropout), so its Q|K|V row is exactly the bias and it adds nothing to d(w_qkv): the projection and its
+ * weight-gradient GEMM run on the non-padding tokens only.  Results are identical to the dense path.
+ * The row keeps its value under training (its gradient is identically zero), so the flag is a property
+ * of the loaded weights.  Ignored when vocab == 0. */
+#define NRMS_FLAG_PAD_ROW_ZERO 1
+
 /* One self-attention + additive-pooling encoder pass over n_seq sequences of seq_len rows.
  * vocab > 0  : news encoder -- input is `ids` [n_seq, seq_len] int64, rows gathered from
  *              `table` (NewsEncoder.forward, model/nrms_v0.py:154-176).
@@ -58,7 +67,7 @@ typedef struct nrms_encoder_desc {
     int32_t  use_output_proj; /* 1: nrms_v1 topology, MHSA ends in output_linear W_O (nrms_v1.py:55,80) */
     int32_t  mask_mode;    /* bit 0: pairwise attention mask mask_i*mask_j -> -1e9 (nrms_v1.py:27-33);
                               bit 1: additive-attention mask -> -1e9 (nrms_v1.py:100-101); 0 = nrms_v0 */
-    int32_t  reserved;
+    int32_t  flags;        /* NRMS_FLAG_*; 0 = none */
     uint64_t seed;         /* counter-based RNG key for the dropout masks (per step) */
 } nrms_encoder_desc;
 

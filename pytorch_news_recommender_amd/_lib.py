@@ -11,6 +11,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRMS_HIP_LIB") or os.path.join(PKG, "libnrms_hip.so")   # override: diagnostic builds only
 
+NRMS_FLAG_PAD_ROW_ZERO = 1
 NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1
 NRMS_PRECISION_BF16 = 2
@@ -25,7 +26,7 @@ class EncoderDesc(C.Structure):
     _fields_ = [("n_seq", C.c_int32), ("seq_len", C.c_int32), ("d_model", C.c_int32),
                 ("n_heads", C.c_int32), ("q_dim", C.c_int32), ("vocab", C.c_int32),
                 ("p_drop_embed", C.c_float), ("p_drop_ctx", C.c_float), ("precision", C.c_int32),
-                ("use_output_proj", C.c_int32), ("mask_mode", C.c_int32), ("reserved", C.c_int32),
+                ("use_output_proj", C.c_int32), ("mask_mode", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64)]
 
 

@@ -46,6 +46,9 @@ class Config(object):
         self.warm_up = False
         # HIP path only: "fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections) or "bf16"
         self.precision = "fp32"
+        # HIP path only: when embedding row 0 (padding_idx) is all zeros, skip the padding tokens in the
+        # Q|K|V projection and its weight gradient (identical results; include/nrms_hip.h NRMS_FLAG_PAD_ROW_ZERO)
+        self.skip_padding_tokens = True
 
     def __nrms__(self):
         self.query_vector_dim = 200

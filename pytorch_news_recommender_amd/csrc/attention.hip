@@ -14,6 +14,8 @@
 
 namespace nrms {
 
+constexpr int PADSUM_STRIDE = 192;     // >= 3 d_k (d_k <= 64)
+
 struct AttnArgs {
     int n_seq, S, d, h, dk;
     float scale;            // 1/sqrt(d_k)
@@ -22,6 +24,11 @@ struct AttnArgs {
     Dropout drop;           // fwd: site 1 on ctx
     const float* dctx;      // bwd in  [M, d] gradient w.r.t. the pre-dropout context (mask already applied)
     float* dqkv;            // bwd out [M, 3d], same head-major column order
+    // COMPACT backward (NRMS_FLAG_PAD_ROW_ZERO): row m of dQKV goes to row pos[m] of a compact dqkv, rows with
+    // pos[m] < 0 (padding tokens) are not written; their column sums -- their whole contribution to the
+    // bias gradient -- are accumulated per wave into padsum[wave][PADSUM_STRIDE]
+    const int* pos;
+    float* padsum;
     int w2, hw;             // float2 per row of one head block (3 d_k / 2) and of one operand (d_k / 2)
     uint32_t magic;         // ceil(2^20 / w2): idx / w2 == (idx * magic) >> 20 for idx < 2^20 / w2
     const uint8_t* mask;    // optional [n_seq, S]: v1's pairwise mask mask_i*mask_j -> masked_fill(-1e9)
@@ -77,49 +84,67 @@ struct Prefetch {
 // 360 bytes at d_k = 30): lanes walk it densely, 64 consecutive float2 per instruction, so a wave
 // instruction touches ~5 cache lines instead of the 8 that four separate 120-byte row slices straddle
 // (these kernels are bound by the line-touch rate of the vector memory path, not by bytes).
+struct BlockPos { uint32_t goff, inimg, which, row; bool ok; };   // float2 units; which: 0 Q, 1 K, 2 V
+
 template <int NS, int ND>
 struct PrefetchQKV {
     static constexpr int IT = 24 * NS * ND;         // >= 32 NS * 48 ND / 64
     // Where the registers allow (32x32 tiles) each iteration's block position is computed ONCE per wave
-    // and kept packed in one register: bits 0-15 global offset in float2 (row * ld/2 + c), 16-27 offset
-    // inside the operand image in float2 (row * RS/2 + c'), 28-29 operand (0 Q, 1 K, 2 V), 31 = out of
-    // range.  Recomputing it per unit costs ~20 VALU per iteration -- a fifth of the forward kernel.
+    // and kept packed in one register: bits 0-14 global offset in float2 (row * ld/2 + c), 15-24 offset
+    // inside the operand image in float2 (row * RS/2 + c'), 25-26 operand (0 Q, 1 K, 2 V; 3 = out of
+    // range), 27-31 row.  Recomputing it per unit costs ~20 VALU per iteration -- a fifth of the forward.
     static constexpr bool PACKED = NS * ND == 1;
     float2 v[IT];
     uint32_t pos[PACKED ? IT : 1];
 
-    __device__ __forceinline__ static uint32_t pack(int idx, long ld, int RS, int total, int w2, int hw, uint32_t magic) {
+    __device__ __forceinline__ static BlockPos locate(int idx, long ld, int RS, int total, int w2, int hw, uint32_t magic) {
         const int ic = min(idx, total - 1);
         const int row = (int)(((uint32_t)ic * magic) >> 20);
         const int c = ic - row * w2;
         const int which = (c >= hw ? 1 : 0) + (c >= 2 * hw ? 1 : 0);
-        return (uint32_t)(row * (int)(ld >> 1) + c) | ((uint32_t)(row * (RS >> 1) + c - which * hw) << 16) |
-               ((uint32_t)which << 28) | (idx < total ? 0u : 0x80000000u);
+        BlockPos b;
+        b.goff = (uint32_t)(row * (int)(ld >> 1) + c);
+        b.inimg = (uint32_t)(row * (RS >> 1) + c - which * hw);
+        b.which = (uint32_t)which;
+        b.row = (uint32_t)row;
+        b.ok = idx < total;
+        return b;
     }
     __device__ __forceinline__ void init(long ld, int RS, int total, int w2, int hw, uint32_t magic, int lane) {
         if (PACKED) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it) pos[it] = pack(lane + 64 * it, ld, RS, total, w2, hw, magic);
+            for (int it = 0; it < IT; ++it) {
+                const BlockPos b = locate(lane + 64 * it, ld, RS, total, w2, hw, magic);
+                pos[it] = b.goff | (b.inimg << 15) | ((b.ok ? b.which : 3u) << 25) | (b.row << 27);
+            }
         }
     }
     // called at the top of every unit: makes the packed words opaque again, otherwise the compiler hoists
-    // their three unpacked forms (global offset, LDS address, predicate) out of the unit loop
+    // their unpacked forms (global offset, LDS address, predicate) out of the unit loop
     __device__ __forceinline__ void touch() {
         if (PACKED) {
 #pragma unroll
             for (int it = 0; it < IT; ++it) asm volatile("" : "+v"(pos[it]));
         }
     }
-    __device__ __forceinline__ uint32_t at(int it, long ld, int RS, int total, int w2, int hw, uint32_t magic,
+    __device__ __forceinline__ BlockPos at(int it, long ld, int RS, int total, int w2, int hw, uint32_t magic,
                                            int lane) const {
-        return PACKED ? pos[it] : pack(lane + 64 * it, ld, RS, total, w2, hw, magic);
+        if (!PACKED) return locate(lane + 64 * it, ld, RS, total, w2, hw, magic);
+        const uint32_t p = pos[it];
+        BlockPos b;
+        b.goff = p & 0x7fffu;
+        b.inimg = (p >> 15) & 0x3ffu;
+        b.which = (p >> 25) & 3u;
+        b.row = p >> 27;
+        b.ok = b.which != 3u;
+        return b;
     }
     __device__ __forceinline__ void load(const float* src, long ld, int RS, int total, int w2, int hw, uint32_t magic,
                                          int lane) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const uint32_t p = at(it, ld, RS, total, w2, hw, magic, lane);     // clamped: raw values only (see Prefetch)
-            v[it] = *reinterpret_cast<const float2*>(src + 2 * (p & 0xffffu));
+            const BlockPos b = at(it, ld, RS, total, w2, hw, magic, lane);    // clamped: raw values only (see Prefetch)
+            v[it] = *reinterpret_cast<const float2*>(src + 2 * b.goff);
         }
     }
     // img: the three [SP][RS] images Q, K, V, contiguous
@@ -127,9 +152,8 @@ struct PrefetchQKV {
                                           uint32_t magic, int lane) const {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const uint32_t p = at(it, ld, RS, total, w2, hw, magic, lane);
-            if ((int32_t)p >= 0)
-                *reinterpret_cast<float2*>(img + ((p >> 28) & 3u) * SPRS + 2 * ((p >> 16) & 0xfffu)) = v[it];
+            const BlockPos b = at(it, ld, RS, total, w2, hw, magic, lane);
+            if (b.ok) *reinterpret_cast<float2*>(img + b.which * SPRS + 2 * b.inimg) = v[it];
         }
     }
 };
@@ -362,15 +386,17 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 //   dV^T = dO^T P ; dQ^T = K^T dS^T ; dK^T = Q^T dS
 // The two products that sum over the query index need P / dS with queries in rows: one
 // 32x32 transpose through a wave-private LDS image each.
-template <int NS, int ND, int WPB, bool MASKED>
-__global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
+// (second launch bound: the 32x32 instantiations must stay at two waves per SIMD, i.e. <= 256 registers; the
+// COMPACT variants would otherwise settle at 260 and lose half their occupancy)
+template <int NS, int ND, int WPB, bool MASKED, bool COMPACT>
+__global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kernel(AttnArgs a) {
     constexpr bool PF = NS == 1;      // prefetch across the compute only where registers allow
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1;
     // the 32x32 transpose image fits inside the V region once V is dead (after dP^T): no LDS of its
     // own -> 18.7 KB per wave instead of 22.9 KB, i.e. 8 waves per CU instead of 6 (this kernel is a
     // long chain of LDS round trips, so it lives off occupancy)
     constexpr bool ALIAS = SP * TS <= SP * RS;
-    constexpr int WF = 4 * SP * RS + (ALIAS ? 0 : SP * TS) + 64;
+    constexpr int WF = 4 * SP * RS + (ALIAS ? 0 : SP * TS) + 64 + (COMPACT ? 64 + 3 * DKP : 0);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
@@ -380,6 +406,9 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
     float* Gs = Vs + SP * RS;
     float* Tb = ALIAS ? Vs : Gs + SP * RS;
     float* Ms = Gs + SP * RS + (ALIAS ? 0 : SP * TS);
+    int* Ps = reinterpret_cast<int*>(Ms + 64);          // COMPACT: compact row of each row of the unit (-1 = padding)
+    float* Acc = reinterpret_cast<float*>(Ps + 64);    // COMPACT: [3][DKP] column sums of the padding rows of dQ, dK, dV
+                                                        // (kept in LDS: three more registers would cost a wave per SIMD)
     for (int i = lane; i < WF; i += 64) Qs[i] = 0.f;
     wave_sync();
 
@@ -407,6 +436,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
         zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
         pg.store(Gs, RS, a.S, a.dk, lane);      // dctx arrives already masked (dctx GEMM epilogue)
         if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
+        if (COMPACT) Ps[lane] = lane < a.S ? a.pos[seq * a.S + lane] : 0;
         wave_sync();
         if (PF) {                                // unconditional (clamped): see gemm_bf16.hip on `if (more)`
             const long un = min(u + ustride, total - 1), sn = un / a.h;
@@ -466,16 +496,49 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
 
         // dQ | dK | dV of this head: one contiguous block per row again, written densely
         {
-            float* ob = a.dqkv + seq * a.S * ld + head * 3 * a.dk;
+            float* ob = a.dqkv + (COMPACT ? 0 : seq * a.S * ld) + head * 3 * a.dk;
             constexpr int OIT = 24 * NS * ND;
 #pragma unroll                                   // full: a run-time `it` would push pos[] into scratch
             for (int it = 0; it < OIT; ++it) {
-                const uint32_t p = pf.at(it, ld, RS, blk, a.w2, a.hw, a.magic, lv);
-                const uint32_t which = (p >> 28) & 3u;
-                const float* img = which == 0 ? Ks : (which == 1 ? Gs : Vs);       // dQ, dK, dV staging images
-                if ((int32_t)p >= 0)
-                    *reinterpret_cast<float2*>(ob + 2 * (p & 0xffffu)) =
-                        *reinterpret_cast<const float2*>(img + 2 * ((p >> 16) & 0xfffu));
+                // (the scheduler would otherwise hoist all 24 strip reads ahead of the stores: +8 live registers,
+                // which is one wave per SIMD at this kernel's 256)
+                if (COMPACT && (it & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                const BlockPos b = pf.at(it, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+                const float* img = b.which == 0 ? Ks : (b.which == 1 ? Gs : Vs);   // dQ, dK, dV staging images
+                if (COMPACT) {
+                    // same block, but row r of the unit lives in row Ps[r] of the compact dqkv
+                    const int crow = Ps[b.ok ? b.row : 0];
+                    if (b.ok && crow >= 0)
+                        *reinterpret_cast<float2*>(ob + 2 * ((long)b.goff + ((long)crow - (long)b.row) * (ld >> 1))) =
+                            *reinterpret_cast<const float2*>(img + 2 * b.inimg);
+                } else if (b.ok) {
+                    *reinterpret_cast<float2*>(ob + 2 * b.goff) = *reinterpret_cast<const float2*>(img + 2 * b.inimg);
+                }
+            }
+            if (COMPACT) {
+                // padding rows: accumulate their dQ | dK | dV column sums (this wave always works on the same
+                // head: the launcher makes the unit stride a multiple of h).  Lane = one column of the staged
+                // images (and, for 32-column tiles, one half of the rows): independent LDS reads, no chain.
+                constexpr int RG = ND == 1 ? 2 : 1;
+                const int col = ND == 1 ? l32 : lane, rg = ND == 1 ? hh : 0;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+                for (int r = rg; r < a.S; r += RG) {
+                    const float m = Ps[r] < 0 ? 1.0f : 0.0f;
+                    s0 += m * Ks[r * RS + col];
+                    s1 += m * Gs[r * RS + col];
+                    s2 += m * Vs[r * RS + col];
+                }
+                if (ND == 1) {
+                    s0 += __shfl_xor(s0, 32, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                }
+                if (ND != 1 || hh == 0) {
+                    Acc[col] += s0;
+                    Acc[DKP + col] += s1;
+                    Acc[2 * DKP + col] += s2;
+                }
             }
         }
         wave_sync();
@@ -486,45 +549,83 @@ __global__ __launch_bounds__(64 * WPB) void attn_bwd_kernel(AttnArgs a) {
             pg.load(a.dctx + sn * a.S * a.d + hn * a.dk, a.d, a.S, a.dk, lane);
         }
     }
+    if (COMPACT) {
+        float* out = a.padsum + ((long)blockIdx.x * WPB + wave) * PADSUM_STRIDE;
+        const int col = ND == 1 ? l32 : lane;
+        if (col < a.dk && (ND != 1 || hh == 0)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) out[i * a.dk + col] = Acc[i * DKP + col];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
-template <int NS, int ND, int WPB, bool BWD, bool MASKED>
-static int launch_attn_inst2(const AttnArgs& a, hipStream_t stream) {
+// dbias[perm.src(n')] += sum over the waves of head(n') of their padding-row column sums (fixed order)
+__global__ void padsum_reduce_kernel(const float* padsum, int n_waves, int h, int dk, HeadPerm perm, float* dbias) {
+    const int np = blockIdx.x * blockDim.x + threadIdx.x;
+    if (np >= 3 * h * dk) return;
+    const int head = np / (3 * dk), cc = np - head * 3 * dk;
+    float s = 0.f;
+    for (int w = head; w < n_waves; w += h) s += padsum[(long)w * PADSUM_STRIDE + cc];
+    dbias[perm.src(np)] += s;
+}
+
+size_t attention_padsum_floats() { return (size_t)(256 * 16 + 64) * 4 * PADSUM_STRIDE; }
+
+template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT>
+static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream) {
     constexpr int SP = 32 * NS, RS = 32 * ND + 4;
     constexpr bool ALIAS = SP * (SP + 1) <= SP * RS;
-    constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : SP * (SP + 1)) + 64) : (3 * SP * RS + 64);
+    constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : SP * (SP + 1)) + 64 + (COMPACT ? 64 + 3 * 32 * ND : 0)) : (3 * SP * RS + 64);
     constexpr size_t bytes = wf * WPB * sizeof(float);
     const long total = (long)a.n_seq * a.h;
     int blocks = (int)((total + WPB - 1) / WPB);
     const int cap = 256 * 16;               // persistent-ish: waves walk units with a grid stride
     if (blocks > cap) blocks = cap;
+    if (COMPACT)                            // every wave keeps one head: unit stride = multiple of h
+        while ((blocks * WPB) % a.h != 0) ++blocks;
     const char* name = BWD ? "attn_bwd" : "attn_fwd";
     hipError_t e;
-    if (BWD) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NS, ND, WPB, MASKED>,
+    if (BWD) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     else e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NS, ND, WPB, MASKED>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
-    TimingScope ts(name, stream);
-    if (BWD) hipLaunchKernelGGL((attn_bwd_kernel<NS, ND, WPB, MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB, MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
-    return check_launch(name);
+    {
+        TimingScope ts(name, stream);
+        if (BWD) hipLaunchKernelGGL((attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB, MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
+        const int rc = check_launch(name);
+        if (rc) return rc;
+    }
+    if (COMPACT) {
+        TimingScope ts("padsum_reduce", stream);
+        hipLaunchKernelGGL(padsum_reduce_kernel, dim3(cdiv(3 * a.d, 256)), dim3(256), 0, stream, a.padsum, blocks * WPB, a.h,
+                           a.dk, HeadPerm{a.dk, a.h}, dbias);
+        return check_launch("padsum_reduce");
+    }
+    return NRMS_OK;
 }
 
 template <int NS, int ND, int WPB, bool BWD>
-static int launch_attn_inst(const AttnArgs& a, hipStream_t stream) {
-    return a.mask != nullptr ? launch_attn_inst2<NS, ND, WPB, BWD, true>(a, stream)
-                             : launch_attn_inst2<NS, ND, WPB, BWD, false>(a, stream);
+static int launch_attn_inst(const AttnArgs& a, float* dbias, hipStream_t stream) {
+    if (BWD && a.pos != nullptr)
+        return a.mask != nullptr ? launch_attn_inst3<NS, ND, WPB, BWD, true, BWD>(a, dbias, stream)
+                                 : launch_attn_inst3<NS, ND, WPB, BWD, false, BWD>(a, dbias, stream);
+    return a.mask != nullptr ? launch_attn_inst3<NS, ND, WPB, BWD, true, false>(a, dbias, stream)
+                             : launch_attn_inst3<NS, ND, WPB, BWD, false, false>(a, dbias, stream);
 }
 
+// pos / padsum / dbias_hm (backward only, all three or none): compact dQKV, see AttnArgs
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
-                     const float* dctx, float* dqkv, const uint8_t* mask, hipStream_t stream) {
+                     const float* dctx, float* dqkv, const uint8_t* mask, const int* pos, float* padsum, float* dbias,
+                     hipStream_t stream) {
     AttnArgs a;
     a.mask = mask;
     a.n_seq = n_seq; a.S = S; a.d = d; a.h = h; a.dk = d / h;
     a.scale = 1.0f / sqrtf((float)a.dk);
     a.qkv = qkv; a.ctx = ctx; a.drop = drop; a.dctx = dctx; a.dqkv = dqkv;
+    a.pos = pos; a.padsum = padsum;
     a.hw = a.dk / 2; a.w2 = 3 * a.hw;
     a.magic = a.w2 > 0 ? (uint32_t)(((1u << 20) + a.w2 - 1) / a.w2) : 0;
     if (n_seq <= 0) return NRMS_OK;
@@ -534,15 +635,15 @@ int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv,
     }
     const int ns = S <= 32 ? 1 : 2, nd = a.dk <= 32 ? 1 : 2;
     if (!bwd) {
-        if (ns == 1 && nd == 1) return launch_attn_inst<1, 1, 4, false>(a, stream);
-        if (ns == 2 && nd == 1) return launch_attn_inst<2, 1, 2, false>(a, stream);
-        if (ns == 1 && nd == 2) return launch_attn_inst<1, 2, 2, false>(a, stream);
-        return launch_attn_inst<2, 2, 1, false>(a, stream);
+        if (ns == 1 && nd == 1) return launch_attn_inst<1, 1, 4, false>(a, dbias, stream);
+        if (ns == 2 && nd == 1) return launch_attn_inst<2, 1, 2, false>(a, dbias, stream);
+        if (ns == 1 && nd == 2) return launch_attn_inst<1, 2, 2, false>(a, dbias, stream);
+        return launch_attn_inst<2, 2, 1, false>(a, dbias, stream);
     }
-    if (ns == 1 && nd == 1) return launch_attn_inst<1, 1, 2, true>(a, stream);
-    if (ns == 2 && nd == 1) return launch_attn_inst<2, 1, 1, true>(a, stream);
-    if (ns == 1 && nd == 2) return launch_attn_inst<1, 2, 1, true>(a, stream);
-    return launch_attn_inst<2, 2, 1, true>(a, stream);
+    if (ns == 1 && nd == 1) return launch_attn_inst<1, 1, 2, true>(a, dbias, stream);
+    if (ns == 2 && nd == 1) return launch_attn_inst<2, 1, 1, true>(a, dbias, stream);
+    if (ns == 1 && nd == 2) return launch_attn_inst<1, 2, 1, true>(a, dbias, stream);
+    return launch_attn_inst<2, 2, 1, true>(a, dbias, stream);
 }
 
 }  // namespace nrms

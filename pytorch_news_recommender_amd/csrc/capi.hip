@@ -10,7 +10,9 @@
 namespace nrms {
 
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
-                     const float* dctx, float* dqkv, const uint8_t* mask, hipStream_t stream);
+                     const float* dctx, float* dqkv, const uint8_t* mask, const int* pos, float* padsum, float* dbias,
+                     hipStream_t stream);
+size_t attention_padsum_floats();
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
                        const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, int npass,
                        void* wplanes, hipStream_t stream);
@@ -83,6 +85,7 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d->precision >= NRMS_PRECISION_FP32 && d->precision <= NRMS_PRECISION_BF16,
                  "%s: unsupported precision %d", who, d->precision);
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
+    NRMS_REQUIRE((d->flags & ~NRMS_FLAG_PAD_ROW_ZERO) == 0, "%s: unknown flags 0x%x", who, d->flags);
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
     return NRMS_OK;
 }
@@ -111,7 +114,7 @@ static size_t wplane_bytes(const nrms_encoder_desc* d) {
 }
 
 struct BwdWorkspace {
-    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, live, n_live, total;   // byte offsets
+    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, live, pos, n_live, cscr, padsum, total;   // byte offsets
 };
 
 static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
@@ -132,8 +135,12 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     w.tn_partial = take(p1 > p2 ? (p1 > p3 ? p1 : p3) : (p2 > p3 ? p2 : p3));
     w.dq_partial = take((size_t)addattn_bwd_rows_waves(d->n_seq) * q);
     w.wplanes = take(wplane_bytes(d) / sizeof(float));
+    const bool pz = d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO) != 0;
     w.live = take(d->vocab > 0 ? M : 0);          // int32 positions of the non-padding tokens (news encoder)
+    w.pos = take(pz ? M : 0);                     // inverse map
     w.n_live = take(d->vocab > 0 ? 64 : 0);
+    w.cscr = take(d->vocab > 0 ? compact_scratch_ints((long)M) : 0);
+    w.padsum = take(pz ? attention_padsum_floats() : 0);
     w.total = off;
     return w;
 }
@@ -143,14 +150,18 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
 using namespace nrms;
 
 // forward scratch: head-major copies of W_qkv / b_qkv (HeadPerm, common.h), then the bf16 weight planes
-struct FwdScratch { size_t wq, bq, planes, total; };
+struct FwdScratch { size_t wq, bq, planes, live, n_live, cscr, total; };
+static bool skip_pad_rows(const nrms_encoder_desc* d) { return d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO) != 0; }
 static FwdScratch fwd_scratch(const nrms_encoder_desc* d) {
     FwdScratch f;
     const size_t dm = (size_t)d->d_model;
     f.wq = 0;
     f.bq = align_up(3 * dm * dm * sizeof(float), 256);
     f.planes = f.bq + align_up(3 * dm * sizeof(float), 256);
-    f.total = f.planes + wplane_bytes(d);
+    f.live = f.planes + wplane_bytes(d);                 // wplane_bytes is 256-aligned
+    f.n_live = f.live + (skip_pad_rows(d) ? align_up((size_t)d->n_seq * d->seq_len * sizeof(int), 256) : 0);
+    f.cscr = f.n_live + (skip_pad_rows(d) ? 256 : 0);
+    f.total = f.cscr + (skip_pad_rows(d) ? align_up(compact_scratch_ints((long)d->n_seq * d->seq_len) * sizeof(int), 256) : 0);
     return f;
 }
 
@@ -176,13 +187,6 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     const uint8_t* amask = (desc->mask_mode & 1) ? mask : nullptr;
     const uint8_t* pmask = (desc->mask_mode & 2) ? mask : nullptr;
 
-    const float* xin = x;
-    if (gather) {
-        NRMS_REQUIRE(acts->x != nullptr, "encoder_fwd: acts.x (gathered embeddings) is required for the news encoder");
-        rc = launch_gather_dropout((long)M, d, ids, w->table, drop_e, acts->x, s);
-        if (rc) return rc;
-        xin = acts->x;
-    }
     NRMS_REQUIRE(acts->scratch != nullptr, "encoder_fwd: acts.scratch (nrms_encoder_fwd_scratch_bytes) is required");
     const FwdScratch fs = fwd_scratch(desc);
     float* wq_hm = (float*)((char*)acts->scratch + fs.wq);
@@ -191,16 +195,41 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     const HeadPerm perm{d / desc->n_heads, desc->n_heads};
     rc = launch_permute_rows(w->w_qkv, w->b_qkv, wq_hm, bq_hm, 3 * d, d, perm, s);
     if (rc) return rc;
+
     NTArgs g{};
     g.M = M; g.N = 3 * d; g.K = d; g.rows_per_tile = NT_BM;
-    g.A = xin; g.lda = d;
     g.W = wq_hm; g.bias = bq_hm; g.C = acts->qkv; g.ldc = 3 * d;
+    const float* xin = x;
+    if (gather) {
+        NRMS_REQUIRE(acts->x != nullptr, "encoder_fwd: acts.x (gathered embeddings) is required for the news encoder");
+        if (skip_pad_rows(desc)) {
+            // NRMS_FLAG_PAD_ROW_ZERO: a padding token's embedding is exactly zero, so its Q|K|V row is exactly
+            // the bias.  acts.x holds ONLY the non-padding tokens (compact, ascending token order), the GEMM
+            // runs on those rows and scatters its C rows back to the token positions; the padding rows of
+            // qkv are filled with the bias.
+            int* live = (int*)((char*)acts->scratch + fs.live);
+            int* n_live = (int*)((char*)acts->scratch + fs.n_live);
+            int* cscr = (int*)((char*)acts->scratch + fs.cscr);
+            rc = launch_compact_live_rows((long)M, ids, live, nullptr, n_live, cscr, s);
+            if (rc) return rc;
+            rc = launch_gather_dropout_compact((long)M, d, ids, live, n_live, w->table, drop_e, acts->x, s);
+            if (rc) return rc;
+            rc = launch_fill_pad_rows((long)M, 3 * d, ids, bq_hm, acts->qkv, s);
+            if (rc) return rc;
+            g.c_rows = live; g.m_dev = n_live;
+        } else {
+            rc = launch_gather_dropout((long)M, d, ids, w->table, drop_e, acts->x, s);
+            if (rc) return rc;
+        }
+        xin = acts->x;
+    }
+    g.A = xin; g.lda = d;
     rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "qkv_proj_fwd");
     if (rc) return rc;
     // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
     // concatenation, the output projection follows and carries the dropout in its epilogue.
     rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
-                          wo ? no_drop : drop_c, nullptr, nullptr, amask, s);
+                          wo ? no_drop : drop_c, nullptr, nullptr, amask, nullptr, nullptr, nullptr, s);
     if (rc) return rc;
     if (wo) {
         NTArgs o{};
@@ -311,8 +340,24 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         if (rc) return rc;
         dattn_in = dattn;
     }
+    // Token compaction (news encoder).  dX is consumed only by the embedding scatter, which skips padding
+    // tokens (padding_idx = 0, nrms_v0.py:134-136) -- in a MIND-shaped batch about two thirds of the
+    // token rows -- so the dX GEMM and the scatter run on the non-padding rows only.  With
+    // NRMS_FLAG_PAD_ROW_ZERO the same holds for d(w_qkv): acts.x is compact already and the attention
+    // backward writes dQKV compact, handing the padding rows' share of d(b_qkv) over as column sums.
+    int* live = (int*)(base + L.live);
+    int* pos = (int*)(base + L.pos);
+    int* n_live = (int*)(base + L.n_live);
+    const bool compact = skip_pad_rows(desc);
+    const HeadPerm perm{d / desc->n_heads, desc->n_heads};
+    if (gather) {
+        rc = launch_compact_live_rows((long)M, ids, live, compact ? pos : nullptr, n_live, (int*)(base + L.cscr), s);
+        if (rc) return rc;
+    }
     // 4. attention backward
-    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask, s);
+    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask,
+                          compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
+                          compact ? grads->b_qkv : nullptr, s);
     if (rc) return rc;
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings)
     const float* xin = gather ? acts->x : x;
@@ -321,29 +366,21 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN;
         t.A = dqkv; t.lda = 3 * d; t.B = xin; t.ldb = d;
         t.dW = grads->w_qkv; t.dbias = grads->b_qkv; t.partial = tn_partial;
-        t.perm = HeadPerm{d / desc->n_heads, desc->n_heads};       // dQKV columns are head-major
+        t.perm = perm;                                            // dQKV columns are head-major
+        if (compact) t.m_dev = n_live;
         rc = tn_gemm(desc, t, s, "dwqkv_bwd");
         if (rc) return rc;
     }
-    // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: dX is consumed only by the
-    //    embedding scatter, which skips padding tokens (padding_idx = 0, nrms_v0.py:134-136) -- in a
-    //    MIND-shaped batch about two thirds of the token rows.  Those rows of dX are dead values, so
-    //    the live token positions are compacted once and the GEMM (row-indirect A) and the scatter run
-    //    on them only; the compact dX goes to the (now dead) dctx buffer.
-    rc = launch_transpose(w->w_qkv, wqkv_t, 3 * d, d, s, HeadPerm{d / desc->n_heads, desc->n_heads});
+    // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: compact dX into the (now
+    //    dead) dctx buffer, then the compact scatter.
+    rc = launch_transpose(w->w_qkv, wqkv_t, 3 * d, d, s, perm);
     if (rc) return rc;
-    int* live = (int*)(base + L.live);
-    int* n_live = (int*)(base + L.n_live);
-    if (gather) {
-        rc = launch_compact_live_rows((long)M, ids, live, n_live, s);
-        if (rc) return rc;
-    }
     {
         NTArgs g{};
         g.M = M; g.N = d; g.K = 3 * d; g.rows_per_tile = NT_BM;
         g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t;
         g.C = gather ? dctx : dx; g.ldc = d;
-        if (gather) { g.a_rows = live; g.m_dev = n_live; }
+        if (gather) { g.a_rows = compact ? nullptr : live; g.m_dev = n_live; }
         rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "dx_bwd");
         if (rc) return rc;
     }

@@ -153,6 +153,6 @@ struct TimingScope {
         }                                               \
     } while (0)
 
-inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+__host__ __device__ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace nrms

@@ -20,6 +20,34 @@ __global__ __launch_bounds__(256) void gather_dropout_kernel(unsigned total4, un
     }
 }
 
+// compact variant: row r of x is token live[r] (the dropout counter stays the token's own element index,
+// so the mask is the one the dense layout would draw)
+__global__ __launch_bounds__(256) void gather_dropout_compact_kernel(unsigned d4, const int64_t* ids, const int* live,
+                                                                     const int* n_live, const float* table, Dropout drop,
+                                                                     float* x) {
+    const unsigned long total4 = (unsigned long)(*n_live) * d4;
+    const unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const unsigned long r = i / d4;
+        const unsigned c4 = (unsigned)(i - r * d4);
+        const long t = live[r];
+        f32x4 v = *reinterpret_cast<const f32x4*>(table + ids[t] * (long)(4 * d4) + 4 * c4);
+        if (drop.thresh != 0u) v *= dropout_scale4(drop.seed, 0u, (uint64_t)(t * d4 + c4), drop.thresh, drop.inv_keep);
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    }
+}
+
+int launch_gather_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live,
+                                  const float* table, const Dropout& drop, float* x, hipStream_t stream) {
+    if (M <= 0) return NRMS_OK;
+    int blocks = cdiv(M * (d / 4), 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    TimingScope ts("gather_dropout", stream);
+    hipLaunchKernelGGL(gather_dropout_compact_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)(d / 4), ids, live,
+                       n_live, table, drop, x);
+    return check_launch("gather_dropout");
+}
+
 // dtable[ids[m], :] += dx[m, :] * keep(m, :) / (1 - p), rows with id 0 skipped (padding_idx).
 // One float per lane so that a wave-instruction adds 256 contiguous bytes of one table row (the
 // shape global_atomic_add_f32 runs at full rate on gfx950); float atomics are order-dependent in
@@ -38,15 +66,105 @@ __global__ __launch_bounds__(256) void scatter_dropout_kernel(unsigned long tota
     }
 }
 
-// Token positions whose id is not the padding id.  Their order is irrelevant (rows of dX are
-// independent and the scatter is a sum), so each 1024-token block just claims a range of the output
-// with one atomic; inside a block positions stay ascending (wave ballots), which keeps neighbouring
-// rows of the compact dX neighbouring in dQKV.
-__global__ __launch_bounds__(256) void compact_live_rows_kernel(long M, const int64_t* ids, int* live, int* n_live) {
+// qkv[m, :] = bias for padding tokens: with an all-zero embedding row 0 their x row is exactly zero
+// (also under dropout), so the projection of a padding token IS the bias and the GEMM skips them.
+__global__ __launch_bounds__(256) void fill_pad_rows_kernel(unsigned total4, unsigned n4, const int64_t* ids,
+                                                            const float* row, float* out) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const unsigned m = i / n4, c4 = i - m * n4;
+        if (ids[m] == 0) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(row)[c4];
+    }
+}
+
+int launch_fill_pad_rows(long M, int n, const int64_t* ids, const float* row, float* out, hipStream_t stream) {
+    if (M <= 0) return NRMS_OK;
+    const long total4 = M * (n / 4);
+    if ((n & 3) != 0 || total4 >= (1L << 32)) { set_error("fill_pad_rows: n=%d M=%ld unsupported", n, M); return NRMS_EINVAL; }
+    int blocks = cdiv(total4, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    TimingScope ts("fill_pad_rows", stream);
+    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)total4, (unsigned)(n / 4), ids, row, out);
+    return check_launch("fill_pad_rows");
+}
+
+// Column sums of the padding-token rows of x [M, n]: their share of the bias gradient (the weight
+// gradient GEMM only visits the non-padding rows).  A block owns a contiguous range of rows; thread t
+// accumulates float4 column t of the rows whose id is 0 (a block-uniform test), then adds its sums once.
+__global__ __launch_bounds__(256) void colsum_pad_rows_kernel(long M, int n4, int rows_per_block, const int64_t* ids,
+                                                              const float* x, HeadPerm perm, float* dbias) {
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    for (int c4 = threadIdx.x; c4 < n4; c4 += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (long r = r0; r < r1; ++r)
+            if (ids[r] == 0) s += *reinterpret_cast<const f32x4*>(x + r * (4L * n4) + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dbias + perm.src(4 * c4 + e), s[e]);
+    }
+}
+
+int launch_colsum_pad_rows(long M, int n, const int64_t* ids, const float* x, HeadPerm perm, float* dbias,
+                           hipStream_t stream) {
+    if (M <= 0) return NRMS_OK;
+    if ((n & 3) != 0) { set_error("colsum_pad_rows: n=%d must be a multiple of 4", n); return NRMS_EINVAL; }
+    const int rows_per_block = 256;
+    TimingScope ts("colsum_pad_rows", stream);
+    hipLaunchKernelGGL(colsum_pad_rows_kernel, dim3(cdiv(M, rows_per_block)), dim3(256), 0, stream, M, n / 4, rows_per_block,
+                       ids, x, perm, dbias);
+    return check_launch("colsum_pad_rows");
+}
+
+// Token positions whose id is not the padding id, in ASCENDING order (deterministic: the order fixes the
+// summation order of the weight-gradient GEMM that runs over the compact rows), plus the inverse map.
+// Three small passes: per-block counts, one-block exclusive scan, ordered write.
+//   live[0 .. *n_live) = positions m with ids[m] != 0;  pos[m] = index of m in live, or -1 (may be null)
+constexpr int CP_BLOCK = 1024;         // tokens per block
+__global__ __launch_bounds__(256) void compact_count_kernel(long M, const int64_t* ids, int* counts) {
+    __shared__ int wsum[4];
+    const long m0 = (long)blockIdx.x * CP_BLOCK;
+    int c = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long m = m0 + p * 256 + threadIdx.x;
+        c += (m < M && ids[m] != 0) ? 1 : 0;
+    }
+    c = (int)wave_sum((float)c);        // <= 256 per wave: exact in fp32
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int n_blocks, int* counts, int* n_live) {
+    // exclusive scan of counts[0 .. n_blocks) in place (one block, serial over chunks of 1024)
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_blocks ? counts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) counts[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_live = carry;
+}
+
+__global__ __launch_bounds__(256) void compact_write_kernel(long M, const int64_t* ids, const int* offsets, int* live,
+                                                            int* pos) {
     __shared__ int wave_cnt[4][4];
-    __shared__ int base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long m0 = (long)blockIdx.x * 1024;
+    const long m0 = (long)blockIdx.x * CP_BLOCK;
     bool flag[4];
     int pre[4];
 #pragma unroll
@@ -62,19 +180,28 @@ __global__ __launch_bounds__(256) void compact_live_rows_kernel(long M, const in
         int tot = 0;
         for (int p = 0; p < 4; ++p)
             for (int w = 0; w < 4; ++w) { const int c = wave_cnt[p][w]; wave_cnt[p][w] = tot; tot += c; }
-        base = atomicAdd(n_live, tot);
     }
     __syncthreads();
+    const int base = offsets[blockIdx.x];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-        if (flag[p]) live[base + wave_cnt[p][wave] + pre[p]] = (int)(m0 + p * 256 + threadIdx.x);
+    for (int p = 0; p < 4; ++p) {
+        const long m = m0 + p * 256 + threadIdx.x;
+        const int r = base + wave_cnt[p][wave] + pre[p];
+        if (flag[p]) live[r] = (int)m;
+        if (pos != nullptr && m < M) pos[m] = flag[p] ? r : -1;
+    }
 }
 
-int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* n_live, hipStream_t stream) {
+size_t compact_scratch_ints(long M) { return (size_t)cdiv(M, CP_BLOCK) + 64; }
+
+int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* pos, int* n_live, int* scratch,
+                             hipStream_t stream) {
     if (M <= 0) return NRMS_OK;
-    if (hipMemsetAsync(n_live, 0, sizeof(int), stream) != hipSuccess) { set_error("compact_live_rows: memset failed"); return NRMS_ELAUNCH; }
+    const int nb = cdiv(M, CP_BLOCK);
     TimingScope ts("compact_rows", stream);
-    hipLaunchKernelGGL(compact_live_rows_kernel, dim3(cdiv(M, 1024)), dim3(256), 0, stream, M, ids, live, n_live);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, stream, M, ids, scratch);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, nb, scratch, n_live);
+    hipLaunchKernelGGL(compact_write_kernel, dim3(nb), dim3(256), 0, stream, M, ids, scratch, live, pos);
     return check_launch("compact_live_rows");
 }
 

@@ -43,6 +43,7 @@ struct NTArgs {
     // the number of rows is read from device memory (*m_dev <= M; M sizes the grid).  C rows stay compact.
     const int* a_rows;
     const int* m_dev;
+    const int* c_rows;        // optional: row r of the product is stored to row c_rows[r] of C
 };
 
 // LDS image of a K-stage: [rows][4 chunks of 16 B], the chunk index XOR-swizzled per 4-row group
@@ -187,7 +188,8 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, const f32x4 (&acc)[
     };
     const bool dropped = g.drop.thresh != 0u;                              // uniform
     auto rem_pos = [&](int idx, int rbase, int& sr, int& c4, int& rl, int& n) {
-        sr = idx / REM; c4 = 64 + idx - sr * REM;
+        constexpr int REMD = REM > 0 ? REM : 1;
+        sr = idx / REMD; c4 = 64 + idx - sr * REMD;
         rl = rbase + 4 * (sr >> 1) + (sr & 1);
         n = col0 + 4 * c4;
         return rl < rows_valid && n < g.N;
@@ -245,7 +247,7 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, const f32x4 (&acc)[
                     const long gr = (long)row0 + rl;
                     f32x4 v = *reinterpret_cast<const f32x4*>(wave_lds + sr * S + 4 * c4a);
                     if (!dropped) v = fix(v, gr, na, bias_a);
-                    *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + na) = v;
+                    *reinterpret_cast<f32x4*>(g.C + (g.c_rows != nullptr ? (long)g.c_rows[gr] : gr) * g.ldc + na) = v;
                 }
             }
             if (REM > 0) {
@@ -260,7 +262,7 @@ __device__ __forceinline__ void nt_epilogue(const NTArgs& g, const f32x4 (&acc)[
                         if (EMODE == E_STORE && g.bias != nullptr) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
                         v = fix(v, gr, n, b4);
                     }
-                    *reinterpret_cast<f32x4*>(g.C + gr * g.ldc + n) = v;
+                    *reinterpret_cast<f32x4*>(g.C + (g.c_rows != nullptr ? (long)g.c_rows[gr] : gr) * g.ldc + n) = v;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -287,6 +289,8 @@ struct TNArgs {
     int splits;
     int rows_per_split;
     HeadPerm perm;            // row n' of the product is accumulated into dW / dbias row perm.src(n')
+    // Compacted operands: the sum runs over m < *m_dev (<= M, which sizes the grid and the slabs); null = M
+    const int* m_dev;
 };
 size_t gemm_tn_workspace_floats(int M, int N, int K, int* splits_out);
 int launch_gemm_tn(const TNArgs& a, hipStream_t stream, const char* name);
@@ -321,8 +325,19 @@ int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table,
                           hipStream_t stream);
 int launch_scatter_dropout(long M, int d, const int64_t* ids, const float* dx, const Dropout& drop, float* dtable,
                            hipStream_t stream);
-// live[0 .. *n_live) = the token positions m with ids[m] != 0 (any order); *n_live is written by the kernel
-int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* n_live, hipStream_t stream);
+// x[r, :] = table[ids[live[r]], :] * keep(live[r], :) / (1 - p) for the compact rows r < *n_live
+int launch_gather_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live,
+                                  const float* table, const Dropout& drop, float* x, hipStream_t stream);
+// out[m, :] = row[:] for every token m with ids[m] == 0 (n % 4 == 0)
+int launch_fill_pad_rows(long M, int n, const int64_t* ids, const float* row, float* out, hipStream_t stream);
+// dbias[perm.src(c)] += sum over the tokens m with ids[m] == 0 of x[m, c]   (n % 4 == 0)
+int launch_colsum_pad_rows(long M, int n, const int64_t* ids, const float* x, HeadPerm perm, float* dbias,
+                           hipStream_t stream);
+// live[0 .. *n_live) = the token positions m with ids[m] != 0 in ascending order; pos (optional) = inverse map
+// (-1 for padding tokens); scratch: compact_scratch_ints(M) ints
+size_t compact_scratch_ints(long M);
+int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* pos, int* n_live, int* scratch,
+                             hipStream_t stream);
 // same as launch_scatter_dropout for a COMPACT dx: row r of dx belongs to token live[r], r < *n_live
 int launch_scatter_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
                                    const Dropout& drop, float* dtable, hipStream_t stream);

@@ -152,8 +152,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
 
     const int n_cols = nt_cnt * 16, k_cols = kt_cnt * 16;       // staged widths
     const int ncol0 = nt0 * 16, kcol0 = kt0 * 16;
-    const int m_begin = split * a.rows_per_split;
-    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
+    const int rps = a.m_dev != nullptr ? cdiv(cdiv(M, a.splits), TN_MC) * TN_MC : a.rows_per_split;
+    const int m_begin = split * rps;
+    const int m_end = min(M, m_begin + rps);
 
     // ---- fixed staging slots of this thread.  Loads are unconditional from clamped addresses and keep
     // RAW values; validity and the tanh' factor are applied when the registers go to LDS, a stage later
@@ -226,10 +228,11 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TNArgs a, TNGeom
         for (int jj = 0; jj < NTK; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int n_stage = (m_end - m_begin + TN_MC - 1) / TN_MC;
-    if (n_stage <= 0) return;
+    if (n_stage > 0) {                 // an empty split (compacted M) still writes its all-zero slab below
     load_stage(m_begin);
     store_stage(m_begin, lds);
     __syncthreads();
+    }
     for (int s = 0; s < n_stage; ++s) {
         const float* As = lds + (s & 1) * TN_STAGE;
         const float* Bs = As + TN_MC * TN_SA;

@@ -530,8 +530,10 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
     const int my_kt0 = wk * k_h, my_ktn = max(0, min(k_h, kt_cnt - my_kt0));
     const int n_cols = nt_cnt * 16, k_cols = kt_cnt * 16;
     const int ncol0 = nt0 * 16, kcol0 = kt0 * 16;
-    const int m_begin = split * a.rows_per_split;
-    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
+    const int rps = a.m_dev != nullptr ? cdiv(cdiv(M, a.splits), TB_MC) * TB_MC : a.rows_per_split;
+    const int m_begin = split * rps;
+    const int m_end = min(M, m_begin + rps);
 
     // Staging slots of this thread.  Every global load is unconditional from a clamped (valid) address;
     // validity is applied when the registers are split into the LDS planes, a whole stage later (a
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
     constexpr bool DEEP = NTN * NTK <= 20;
     int n_stage = (m_end - m_begin + TB_MC - 1) / TB_MC;
     Regs R0, R1;
-    if (n_stage <= 0) return;
+    if (n_stage > 0) {                 // an empty split (compacted M) still writes its all-zero slab below
     load_stage(R1, m_begin);
     store_stage(R1, m_begin, smem);
     if (DEEP) {
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(TB_THREADS, 2) void gemm_tn_bf16_kernel(TNArgs a, T
             store_stage(R0, m_begin + (s + 1) * TB_MC, smem + ((s + 1) & 1) * STAGE);
             __syncthreads();
         }
+    }
     }
     const long n_pad = (long)g.n_tiles * 16, k_pad = (long)g.k_tiles * 16;
     float* slab = a.partial + (long)split * n_pad * k_pad;

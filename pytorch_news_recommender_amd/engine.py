@@ -120,6 +120,9 @@ class NRMSEngine:
         if precision not in _lib.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self.precision = precision
+        # NRMS_FLAG_PAD_ROW_ZERO: set by the owner of the parameters when embedding row 0 is all zeros
+        # (include/nrms_hip.h); False = dense path
+        self.pad_row_zero = False
 
     # ---- buffers ----------------------------------------------------------------------
     def _buf(self, key, numel, dtype=torch.float32):
@@ -135,7 +138,9 @@ class NRMSEngine:
                                 q_dim=d.query_vector_dim, vocab=d.n_words if enc == "news_encoder" else 0,
                                 p_drop_embed=float(p_embed), p_drop_ctx=float(p_ctx),
                                 precision=_lib.PRECISIONS[self.precision], use_output_proj=int(d.output_proj),
-                                mask_mode=int(mask_mode), reserved=0, seed=int(seed))
+                                mask_mode=int(mask_mode),
+                                flags=(_lib.NRMS_FLAG_PAD_ROW_ZERO if (self.pad_row_zero and enc == "news_encoder") else 0),
+                                seed=int(seed))
 
     def _ptrs(self, cls, flat, enc):
         b = self.layout.blocks[enc]
@@ -159,7 +164,7 @@ class NRMSEngine:
         t = self._buf(tag + ".t", M * q) if need_bwd else None
         w = self._buf(tag + ".w", M) if need_bwd else None
         # head-major W_qkv / b_qkv copies + bf16 weight planes: an upper bound of nrms_encoder_fwd_scratch_bytes
-        scratch = self._buf("fwd_scratch", 3 * d * d + 3 * d + 256 + (3 * d + 32) * (d + 32))
+        scratch = self._buf("fwd_scratch", 3 * d * d + 3 * d + 256 + (3 * d + 32) * (d + 32) + (M + M // 1024 + 512 if gather else 0))
         dp = lambda z: None if z is None else z.data_ptr()
         return _lib.EncoderActs(x=dp(x), qkv=dp(qkv), attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
 

@@ -113,6 +113,7 @@ class Model(nn.Module):
         missing = [n for n in self._names if n not in named]
         assert not missing and len(named) == len(self._names), (missing, sorted(named))
         self._flat = None
+        self._pad_zero = None
         self._engine = None
         self._opt = None
         self._calls = 0
@@ -138,6 +139,18 @@ class Model(nn.Module):
             named[n].data = v
         self._flat = flat
         self._opt = None
+        self._pad_zero = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._pad_zero = None                      # the embedding table may have changed
+        return out
+
+    def refresh_pad_row_flag(self):
+        """Re-evaluate NRMS_FLAG_PAD_ROW_ZERO (include/nrms_hip.h) after writing into the embedding table by
+        hand.  Training never needs it: row 0 has an identically zero gradient (padding_idx), so Adam leaves
+        it where it was when the weights were loaded."""
+        self._pad_zero = None
 
     def _views_intact(self):
         base = self._flat.data_ptr()
@@ -162,6 +175,11 @@ class Model(nn.Module):
             self._engine = NRMSEngine(self._dims, self._flat.device, precision=prec)
         elif self._engine.precision != prec:
             self._engine.set_precision(prec)
+        if getattr(self, "_pad_zero", None) is None:
+            # one host sync per weight load: is the padding row of the embedding table all zeros?
+            tname = [n for n in self._names if n.endswith("word_embedding.0.weight") or n.endswith("word_embedding.weight")][0]
+            self._pad_zero = bool((self._layout.view(self._flat, tname)[0] == 0).all().item())
+        self._engine.pad_row_zero = self._pad_zero and bool(getattr(self.config, "skip_padding_tokens", True))
         return self._flat.device
 
     def _next_seed(self):
