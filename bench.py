@@ -39,7 +39,7 @@ DTYPES = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA inputs hi+lo, fp32 a
           "bf16": "bf16 (MFMA inputs), fp32 accumulate, fp32 storage"}
 
 
-def kernel_work(shape, B, live_frac=1.0):
+def kernel_work(shape, B, live_frac=1.0, compact_qkv=False):
     """Per kernel: (declared bound, algorithmic flop per step, algorithmic HBM bytes per step), summed over
     the news-encoder and user-encoder launches.  flop = 2mnk of the contractions; bytes =
     every activation tensor the kernel must read or write once, fp32 (weights are negligible).
@@ -54,19 +54,23 @@ def kernel_work(shape, B, live_frac=1.0):
     add = 2.0 * M * d * q
     att = sum(n * 2.0 * 2 * S * S * d for n, S in seqs)        # QK^T + PV over all heads
     Md, Mq = 4.0 * M * d, 4.0 * M * q
+    Mlx = Ms[0] * live_frac + Ms[1]           # token rows that are not padding (user-encoder rows all count)
+    Ml = Mlx if compact_qkv else M            # rows the Q|K|V projection / d(w_qkv) / compact dQKV touch
     n_params = shape.n_words * d + 2 * (3 * d * d + 3 * d + q * d + 2 * q)
     Mn_d = 4.0 * Ms[0] * d
     return {
-        "qkv_proj_fwd": ("mfma", qkv, Md + 3 * Md),
-        "dwqkv_bwd": ("mfma", qkv, 3 * Md + Md),
-        "dx_bwd": ("mfma", 2.0 * (Ms[0] * live_frac + Ms[1]) * d * 3 * d, 16.0 * (Ms[0] * live_frac + Ms[1]) * d),
+        # padding tokens skipped (NRMS_FLAG_PAD_ROW_ZERO): the projection reads the live x rows and still writes
+        # every qkv row; d(w_qkv) reads the live rows of dQKV and x
+        "qkv_proj_fwd": ("mfma", 2.0 * Ml * d * 3 * d, 4.0 * Ml * d + 3 * Md),
+        "dwqkv_bwd": ("mfma", 2.0 * Ml * d * 3 * d, 16.0 * Ml * d),
+        "dx_bwd": ("mfma", 2.0 * Mlx * d * 3 * d, 16.0 * Mlx * d),
         "addattn_fwd": ("mfma", add, Md + Mq),
         "dctx_bwd": ("mfma", add, Mq + Md),
         "dwadd_bwd": ("mfma", add, Mq + Md),
         "attn_fwd": ("hbm", att, 3 * Md + Md),
-        "attn_bwd": ("hbm", 2.5 * att, 3 * Md + Md + 3 * Md),
+        "attn_bwd": ("hbm", 2.5 * att, 3 * Md + Md + 12.0 * Ml * d),
         "addattn_bwd_rows": ("hbm", 0.0, Md + Mq),
-        "gather_dropout": ("hbm", 0.0, 2 * Mn_d),
+        "gather_dropout": ("hbm", 0.0, 2 * Mn_d * (live_frac if compact_qkv else 1.0)),
         "scatter_dropout": ("hbm", 0.0, 2 * Mn_d * live_frac),
         "adam": ("hbm", 0.0, 28.0 * n_params),
     }
@@ -185,7 +189,8 @@ def main():
     if rank == 0:
         live = float((batch_np["browsed_titles"] != 0).sum() + (batch_np["candidate_titles"] != 0).sum())
         live_frac = live / float(B * (shape.history_len + shape.n_candidates) * shape.n_words_title)
-        work = kernel_work(shape, B, live_frac)
+        compact_qkv = bool(eng.pad_row_zero)
+        work = kernel_work(shape, B, live_frac, compact_qkv)
         kernels = {}
         for name, (bound, fl, by) in work.items():
             ms, n = eng.timing_read(name)
@@ -224,6 +229,9 @@ def main():
                                    "cand=5, title_len=30, d=300, h=10, q=200, V=45800, dropout=0.2, Adam(lr=1e-3)" % B,
                        "users_per_gpu": B, "global_batch": B * world,
                        "non_padding_token_fraction": round(live_frac, 4),
+                       "padding_tokens_skipped": ("dX + embedding scatter (dead values); Q|K|V projection and d(w_qkv) too: "
+                                                  "embedding row 0 is zero" if compact_qkv else
+                                                  "dX + embedding scatter (dead values)"),
                        "parallelism": "dp%d" % world, "precision": args.precision,
                        "score_parity_vs_reference": {"fp32": "<=1.5e-7", "bf16x3": "<=5e-7", "bf16": "~3e-4 (fails 1e-4)"}[args.precision]},
             "loss": loss,

@@ -255,6 +255,40 @@ def test_live_row_compaction_edges(case):
         assert (np.abs(table_grad).sum(axis=1) != 0).sum() <= 1
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_padding_token_skip_equals_dense_path(precision):
+    """NRMS_FLAG_PAD_ROW_ZERO (embedding row 0 all zeros): the compact path (Q|K|V projection and d(w_qkv) on
+    the non-padding tokens only) must reproduce the dense path -- forward bit for bit (row-independent
+    arithmetic; a padding row is 0.w + b = b exactly), gradients up to summation order -- also in train mode
+    with both dropouts on (same seed => same masks)."""
+    shape = synth.Shape(n_words=500, word_embed_size=120, num_attention_heads=6, query_vector_dim=64,
+                        batch_size=12, history_len=20, n_candidates=4, n_words_title=17)
+    params = synth.make_params(shape, seed=131)            # row 0 of the table is zero
+    batch = synth.make_batch(shape, seed=132, ragged=True, min_title=1, all_pad_title=True, empty_history_user=True)
+    out = {}
+    for skip in (True, False):
+        model = make_model(shape, params, dropout=0.2)
+        model.config.precision = precision
+        model.config.skip_padding_tokens = skip
+        model.train()
+        torch.manual_seed(7)
+        model._calls = 0
+        scores, loss, grads = fwd_bwd(model, batch)
+        assert model.engine.pad_row_zero is skip
+        out[skip] = (scores, grads)
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    for n in synth.param_names():
+        if n.endswith("W_K.bias"):                 # analytically zero: rounding noise only
+            continue
+        a, b = out[True][1][n], out[False][1][n]
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * max(1e-12, float(np.abs(b).max())), err_msg=n)
+    # a table with a non-zero padding row never takes the compact path
+    params2 = synth.make_params(shape, seed=131, pad_row_zero=False)
+    model = make_model(shape, params2)
+    fwd_bwd(model, batch)
+    assert model.engine.pad_row_zero is False
+
+
 @pytest.mark.parametrize("precision,score_tol,grad_rtol", [("bf16x3", 1e-4, 2e-3), ("bf16", 5e-3, 6e-2)])
 def test_reduced_precision_modes(golden_dir, precision, score_tol, grad_rtol):
     """Split-bf16 projections must stay inside north_star's 1e-4 score bar against the REFERENCE fixture
