@@ -561,13 +561,17 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
 
 // ---------------------------------------------------------------------------------------
 // dbias[perm.src(n')] += sum over the waves of head(n') of their padding-row column sums (fixed order)
-__global__ void padsum_reduce_kernel(const float* padsum, int n_waves, int h, int dk, HeadPerm perm, float* dbias) {
-    const int np = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void padsum_reduce_kernel(const float* padsum, int n_waves, int h, int dk, HeadPerm perm,
+                                                            float* dbias) {
+    // one wave per output column: lanes stride over the waves of that head, fixed-order tree at the end
+    const int lane = threadIdx.x & 63;
+    const int np = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (np >= 3 * h * dk) return;
     const int head = np / (3 * dk), cc = np - head * 3 * dk;
     float s = 0.f;
-    for (int w = head; w < n_waves; w += h) s += padsum[(long)w * PADSUM_STRIDE + cc];
-    dbias[perm.src(np)] += s;
+    for (int w = head + lane * h; w < n_waves; w += 64 * h) s += padsum[(long)w * PADSUM_STRIDE + cc];
+    s = wave_sum(s);
+    if (lane == 0) dbias[perm.src(np)] += s;
 }
 
 size_t attention_padsum_floats() { return (size_t)(256 * 16 + 64) * 4 * PADSUM_STRIDE; }
@@ -600,7 +604,7 @@ static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream
     }
     if (COMPACT) {
         TimingScope ts("padsum_reduce", stream);
-        hipLaunchKernelGGL(padsum_reduce_kernel, dim3(cdiv(3 * a.d, 256)), dim3(256), 0, stream, a.padsum, blocks * WPB, a.h,
+        hipLaunchKernelGGL(padsum_reduce_kernel, dim3(cdiv(3 * a.d, 4)), dim3(256), 0, stream, a.padsum, blocks * WPB, a.h,
                            a.dk, HeadPerm{a.dk, a.h}, dbias);
         return check_launch("padsum_reduce");
     }

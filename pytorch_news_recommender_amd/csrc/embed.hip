@@ -68,23 +68,32 @@ __global__ __launch_bounds__(256) void scatter_dropout_kernel(unsigned long tota
 
 // qkv[m, :] = bias for padding tokens: with an all-zero embedding row 0 their x row is exactly zero
 // (also under dropout), so the projection of a padding token IS the bias and the GEMM skips them.
-__global__ __launch_bounds__(256) void fill_pad_rows_kernel(unsigned total4, unsigned n4, const int64_t* ids,
-                                                            const float* row, float* out) {
-    const unsigned stride = gridDim.x * blockDim.x;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        const unsigned m = i / n4, c4 = i - m * n4;
-        if (ids[m] == 0) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(row)[c4];
+constexpr int FILL_SLICES = 6;          // 64 lanes x 6 float4 = 1536 floats >= 3 d_model (d_model <= 512)
+__global__ __launch_bounds__(256) void fill_pad_rows_kernel(long M, int n4, const int64_t* ids, const float* row,
+                                                            float* out) {
+    // one wave per token row: the id test is wave-uniform, a lane's slices of the bias stay in registers
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long)gridDim.x * 4;
+    f32x4 b[FILL_SLICES];
+#pragma unroll
+    for (int i = 0; i < FILL_SLICES; ++i)
+        b[i] = (lane + 64 * i < n4) ? reinterpret_cast<const f32x4*>(row)[lane + 64 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long m = wave; m < M; m += n_waves) {
+        if (ids[m] != 0) continue;
+        f32x4* o = reinterpret_cast<f32x4*>(out) + m * n4;
+#pragma unroll
+        for (int i = 0; i < FILL_SLICES; ++i)
+            if (lane + 64 * i < n4) o[lane + 64 * i] = b[i];
     }
 }
 
 int launch_fill_pad_rows(long M, int n, const int64_t* ids, const float* row, float* out, hipStream_t stream) {
     if (M <= 0) return NRMS_OK;
-    const long total4 = M * (n / 4);
-    if ((n & 3) != 0 || total4 >= (1L << 32)) { set_error("fill_pad_rows: n=%d M=%ld unsupported", n, M); return NRMS_EINVAL; }
-    int blocks = cdiv(total4, 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if ((n & 3) != 0 || n > 256 * FILL_SLICES) { set_error("fill_pad_rows: n=%d unsupported", n); return NRMS_EINVAL; }
+    int blocks = cdiv(M, 4);
+    if (blocks > 256 * 32) blocks = 256 * 32;
     TimingScope ts("fill_pad_rows", stream);
-    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)total4, (unsigned)(n / 4), ids, row, out);
+    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3(blocks), dim3(256), 0, stream, M, n / 4, ids, row, out);
     return check_launch("fill_pad_rows");
 }
 
