@@ -29,6 +29,12 @@ struct AttnArgs {
     // bias gradient -- are accumulated per wave into padsum[wave][PADSUM_STRIDE]
     const int* pos;
     float* padsum;
+    // All-padding sequences (NRMS_FLAG_PAD_ROW_ZERO, no attention mask): every Q|K|V row equals the bias, the
+    // attention is uniform, ctx = b_v; dS = 0, dQ = dK = 0 and every dV row is the mean of the dO rows.  The
+    // forward (ids + bias_hm given) writes dropout(b_v); the COMPACT backward only adds the column sum of dO
+    // to the padding-row sums of dV.
+    const int64_t* ids;
+    const float* bias_hm;
     int w2, hw;             // float2 per row of one head block (3 d_k / 2) and of one operand (d_k / 2)
     uint32_t magic;         // ceil(2^20 / w2): idx / w2 == (idx * magic) >> 20 for idx < 2^20 / w2
     const uint8_t* mask;    // optional [n_seq, S]: v1's pairwise mask mask_i*mask_j -> masked_fill(-1e9)
@@ -307,7 +313,7 @@ __device__ __forceinline__ void stage_out(float* dst, int RS, const f32x16 (&o)[
 }
 
 // ---------------------------------------------------------------------------------------
-template <int NS, int ND, int WPB, bool MASKED>
+template <int NS, int ND, int WPB, bool MASKED, bool APAD>
 __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, WF = 3 * SP * RS + 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -326,10 +332,23 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
     PrefetchQKV<NS, ND> pf;
     const int blk = a.S * a.w2;                 // float2 in one head block
     long u = (long)blockIdx.x * WPB + wave;
+    // APAD: all-padding units neither load nor compute.  `ap_cur` / `ap_next` = this / the next unit is all
+    // padding; idv = this lane's token id two units ahead (in flight for a whole unit before its ballot).
+    bool ap_cur = false, ap_next = false;
+    long idv = 1;
+    auto seq_of = [&](long uu) { return min(uu, total - 1) / a.h; };
     if (u < total) {
         const long seq = u / a.h;
+        if (APAD) {
+            const long id0 = lane < a.S ? a.ids[seq * a.S + lane] : 0;
+            const long id1 = lane < a.S ? a.ids[seq_of(u + ustride) * a.S + lane] : 0;
+            idv = lane < a.S ? a.ids[seq_of(u + 2 * ustride) * a.S + lane] : 0;
+            ap_cur = __ballot(id0 != 0) == 0ull;
+            ap_next = __ballot(id1 != 0) == 0ull;
+        }
         pf.init(ld, RS, blk, a.w2, a.hw, a.magic, lane);
-        pf.load(a.qkv + seq * a.S * ld + (int)(u - seq * a.h) * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
+        if (!ap_cur)
+            pf.load(a.qkv + seq * a.S * ld + (int)(u - seq * a.h) * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
     }
     for (; u < total; u += ustride) {
         const long seq = u / a.h;
@@ -339,22 +358,40 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
         int lv = lane;
         asm volatile("" : "+v"(lv));
         pf.touch();
-        pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
-        zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
-        if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
+        const bool allpad = ap_cur;
+        if (!allpad) {
+            pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
+            if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
+        }
         wave_sync();
         {                                        // next unit's operands fly while this one computes
             const long un = min(u + ustride, total - 1), sn = un / a.h;
-            pf.load(a.qkv + sn * a.S * ld + (int)(un - sn * a.h) * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            if (!ap_next)
+                pf.load(a.qkv + sn * a.S * ld + (int)(un - sn * a.h) * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            if (APAD) {
+                ap_cur = ap_next;
+                ap_next = __ballot(idv != 0) == 0ull;            // ids of unit u + 2 ustride, loaded a unit ago
+                idv = lane < a.S ? a.ids[seq_of(u + 3 * ustride) * a.S + lane] : 0;
+            }
         }
 
-        f32x16 st[NS][NS];
-        abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
-        softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, Ms);
-        f32x16 o[ND][NS];
-        at_x_tiles<NS, ND>(Vs, RS, l32, hh, st, o);
-        wave_sync();
-        stage_out<NS, ND>(Qs, RS, o, a.S, a.dk, l32, hh);
+        if (!allpad) {
+            f32x16 st[NS][NS];
+            abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
+            softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, Ms);
+            f32x16 o[ND][NS];
+            at_x_tiles<NS, ND>(Vs, RS, l32, hh, st, o);
+            wave_sync();
+            stage_out<NS, ND>(Qs, RS, o, a.S, a.dk, l32, hh);
+        } else {
+            // uniform attention over identical rows: every context row is the V bias of this head
+            const float* bv = a.bias_hm + head * 3 * a.dk + 2 * a.dk;
+            for (int i = lane; i < a.S * a.hw; i += 64) {
+                const int r = i / a.hw, c2 = i - r * a.hw;
+                *reinterpret_cast<float2*>(Qs + r * RS + 2 * c2) = *reinterpret_cast<const float2*>(bv + 2 * c2);
+            }
+        }
         wave_sync();
 
         // coalesced-as-possible store of ctx[seq*S + r][head*dk + c], dropout site 1
@@ -419,11 +456,21 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
     Prefetch<NS, ND> pg;
     const int blk = a.S * a.w2;
     long u = (long)blockIdx.x * WPB + wave;
+    // COMPACT: compact-row numbers (pos) of this lane's row in the current / next / next-but-one unit, so
+    // that neither the unit's own map nor the "is the next unit all padding?" test waits for memory
+    int p_cur = 0, p_n1 = 0, p_n2 = 0;
+    auto pos_of = [&](long uu) { return lane < a.S ? a.pos[(min(uu, total - 1) / a.h) * a.S + lane] : -1; };
+    bool ap_next = false;
     if (u < total) {
         const long seq = u / a.h;
         const int head = (int)(u - seq * a.h);
+        bool ap0 = false;
+        if (COMPACT) {
+            p_cur = pos_of(u); p_n1 = pos_of(u + ustride); p_n2 = pos_of(u + 2 * ustride);
+            ap0 = !MASKED && __ballot(p_cur >= 0) == 0ull;
+        }
         pf.init(ld, RS, blk, a.w2, a.hw, a.magic, lane);
-        pf.load(a.qkv + seq * a.S * ld + head * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
+        if (!ap0) pf.load(a.qkv + seq * a.S * ld + head * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
         pg.load(a.dctx + seq * a.S * a.d + head * a.dk, a.d, a.S, a.dk, lane);
     }
     for (; u < total; u += ustride) {
@@ -432,19 +479,28 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         int lv = lane;                           // opaque: see attn_fwd_kernel
         asm volatile("" : "+v"(lv));
         pf.touch();
-        pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
-        zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
+        bool allpad = false;
+        if (COMPACT) {
+            Ps[lane] = lane < a.S ? p_cur : 0;
+            allpad = !MASKED && __ballot(p_cur >= 0) == 0ull;        // no live token in this sequence
+            ap_next = !MASKED && __ballot(p_n1 >= 0) == 0ull;
+        }
+        if (!allpad) {
+            pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
+        }
         pg.store(Gs, RS, a.S, a.dk, lane);      // dctx arrives already masked (dctx GEMM epilogue)
         if (MASKED) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
-        if (COMPACT) Ps[lane] = lane < a.S ? a.pos[seq * a.S + lane] : 0;
         wave_sync();
-        if (PF) {                                // unconditional (clamped): see gemm_bf16.hip on `if (more)`
+        if (PF) {                                // (an all-padding next unit only needs its dO rows)
             const long un = min(u + ustride, total - 1), sn = un / a.h;
             const int hn = (int)(un - sn * a.h);
-            pf.load(a.qkv + sn * a.S * ld + hn * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            if (!ap_next) pf.load(a.qkv + sn * a.S * ld + hn * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
             pg.load(a.dctx + sn * a.S * a.d + hn * a.dk, a.d, a.S, a.dk, lane);
         }
+        if (COMPACT) { p_cur = p_n1; p_n1 = p_n2; p_n2 = pos_of(u + 3 * ustride); }
 
+        if (!allpad) {
         f32x16 st[NS][NS], dp[NS][NS];
         abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
         const float* msk = Ms;
@@ -541,11 +597,22 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
                 }
             }
         }
+        } else {
+            // all-padding sequence: identical Q|K|V rows => uniform attention, dS = 0, dQ = dK = 0 and every
+            // dV row = mean of the dO rows; nothing is written (padding rows), the rows' dV sum = sum of dO
+            constexpr int RG = ND == 1 ? 2 : 1;
+            const int col = ND == 1 ? l32 : lane, rg = ND == 1 ? hh : 0;
+            float s2 = 0.f;
+#pragma unroll 4
+            for (int r = rg; r < a.S; r += RG) s2 += Gs[r * RS + col];
+            if (ND == 1) s2 += __shfl_xor(s2, 32, 64);
+            if (ND != 1 || hh == 0) Acc[2 * DKP + col] += s2;
+        }
         wave_sync();
         if (!PF) {                            // big tiles: no registers to spare, load after the compute
             const long un = min(u + ustride, total - 1), sn = un / a.h;
             const int hn = (int)(un - sn * a.h);
-            pf.load(a.qkv + sn * a.S * ld + hn * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            if (!ap_next) pf.load(a.qkv + sn * a.S * ld + hn * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
             pg.load(a.dctx + sn * a.S * a.d + hn * a.dk, a.d, a.S, a.dk, lane);
         }
     }
@@ -586,23 +653,23 @@ static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream
     int blocks = (int)((total + WPB - 1) / WPB);
     const int cap = 256 * 16;               // persistent-ish: waves walk units with a grid stride
     if (blocks > cap) blocks = cap;
-    if (COMPACT)                            // every wave keeps one head: unit stride = multiple of h
+    if (COMPACT && BWD)                     // every wave keeps one head: unit stride = multiple of h
         while ((blocks * WPB) % a.h != 0) ++blocks;
     const char* name = BWD ? "attn_bwd" : "attn_fwd";
     hipError_t e;
     if (BWD) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    else e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NS, ND, WPB, MASKED>,
+    else e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NS, ND, WPB, MASKED, COMPACT && !MASKED>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
     {
         TimingScope ts(name, stream);
         if (BWD) hipLaunchKernelGGL((attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB, MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB, MASKED, COMPACT && !MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
         const int rc = check_launch(name);
         if (rc) return rc;
     }
-    if (COMPACT) {
+    if (COMPACT && BWD) {
         TimingScope ts("padsum_reduce", stream);
         hipLaunchKernelGGL(padsum_reduce_kernel, dim3(cdiv(3 * a.d, 4)), dim3(256), 0, stream, a.padsum, blocks * WPB, a.h,
                            a.dk, HeadPerm{a.dk, a.h}, dbias);
@@ -613,23 +680,24 @@ static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream
 
 template <int NS, int ND, int WPB, bool BWD>
 static int launch_attn_inst(const AttnArgs& a, float* dbias, hipStream_t stream) {
-    if (BWD && a.pos != nullptr)
-        return a.mask != nullptr ? launch_attn_inst3<NS, ND, WPB, BWD, true, BWD>(a, dbias, stream)
-                                 : launch_attn_inst3<NS, ND, WPB, BWD, false, BWD>(a, dbias, stream);
+    if (BWD ? a.pos != nullptr : a.ids != nullptr)     // compact backward / all-padding shortcut in the forward
+        return a.mask != nullptr ? launch_attn_inst3<NS, ND, WPB, BWD, true, true>(a, dbias, stream)
+                                 : launch_attn_inst3<NS, ND, WPB, BWD, false, true>(a, dbias, stream);
     return a.mask != nullptr ? launch_attn_inst3<NS, ND, WPB, BWD, true, false>(a, dbias, stream)
                              : launch_attn_inst3<NS, ND, WPB, BWD, false, false>(a, dbias, stream);
 }
 
-// pos / padsum / dbias_hm (backward only, all three or none): compact dQKV, see AttnArgs
+// forward: ids + bias_hm (both or none) enable the all-padding-sequence shortcut;
+// backward: pos / padsum / dbias (all three or none) = compact dQKV, see AttnArgs
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
-                     const float* dctx, float* dqkv, const uint8_t* mask, const int* pos, float* padsum, float* dbias,
-                     hipStream_t stream) {
+                     const float* dctx, float* dqkv, const uint8_t* mask, const int64_t* ids, const float* bias_hm,
+                     const int* pos, float* padsum, float* dbias, hipStream_t stream) {
     AttnArgs a;
     a.mask = mask;
     a.n_seq = n_seq; a.S = S; a.d = d; a.h = h; a.dk = d / h;
     a.scale = 1.0f / sqrtf((float)a.dk);
     a.qkv = qkv; a.ctx = ctx; a.drop = drop; a.dctx = dctx; a.dqkv = dqkv;
-    a.pos = pos; a.padsum = padsum;
+    a.pos = pos; a.padsum = padsum; a.ids = ids; a.bias_hm = bias_hm;
     a.hw = a.dk / 2; a.w2 = 3 * a.hw;
     a.magic = a.w2 > 0 ? (uint32_t)(((1u << 20) + a.w2 - 1) / a.w2) : 0;
     if (n_seq <= 0) return NRMS_OK;

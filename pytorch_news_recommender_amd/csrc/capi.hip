@@ -10,8 +10,8 @@
 namespace nrms {
 
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
-                     const float* dctx, float* dqkv, const uint8_t* mask, const int* pos, float* padsum, float* dbias,
-                     hipStream_t stream);
+                     const float* dctx, float* dqkv, const uint8_t* mask, const int64_t* ids, const float* bias_hm,
+                     const int* pos, float* padsum, float* dbias, hipStream_t stream);
 size_t attention_padsum_floats();
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
                        const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, int npass,
@@ -214,7 +214,7 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
             if (rc) return rc;
             rc = launch_gather_dropout_compact((long)M, d, ids, live, n_live, w->table, drop_e, acts->x, s);
             if (rc) return rc;
-            rc = launch_fill_pad_rows((long)M, 3 * d, ids, bq_hm, acts->qkv, s);
+            rc = launch_fill_pad_rows((long)desc->n_seq, S, 3 * d, ids, bq_hm, acts->qkv, amask == nullptr, s);
             if (rc) return rc;
             g.c_rows = live; g.m_dev = n_live;
         } else {
@@ -229,7 +229,9 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
     // concatenation, the output projection follows and carries the dropout in its epilogue.
     rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
-                          wo ? no_drop : drop_c, nullptr, nullptr, amask, nullptr, nullptr, nullptr, s);
+                          wo ? no_drop : drop_c, nullptr, nullptr, amask,
+                          (gather && skip_pad_rows(desc)) ? ids : nullptr, (gather && skip_pad_rows(desc)) ? bq_hm : nullptr,
+                          nullptr, nullptr, nullptr, s);
     if (rc) return rc;
     if (wo) {
         NTArgs o{};
@@ -356,7 +358,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     }
     // 4. attention backward
     rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask,
-                          compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
+                          nullptr, nullptr, compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
                           compact ? grads->b_qkv : nullptr, s);
     if (rc) return rc;
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings)

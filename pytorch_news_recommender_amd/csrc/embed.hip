@@ -69,31 +69,42 @@ __global__ __launch_bounds__(256) void scatter_dropout_kernel(unsigned long tota
 // qkv[m, :] = bias for padding tokens: with an all-zero embedding row 0 their x row is exactly zero
 // (also under dropout), so the projection of a padding token IS the bias and the GEMM skips them.
 constexpr int FILL_SLICES = 6;          // 64 lanes x 6 float4 = 1536 floats >= 3 d_model (d_model <= 512)
-__global__ __launch_bounds__(256) void fill_pad_rows_kernel(long M, int n4, const int64_t* ids, const float* row,
-                                                            float* out) {
-    // one wave per token row: the id test is wave-uniform, a lane's slices of the bias stay in registers
+template <bool SKIP_ALL_PAD>
+__global__ __launch_bounds__(256) void fill_pad_rows_kernel_t(long n_seq, int S, int n4, const int64_t* ids, const float* row,
+                                                              float* out) {
+    // one wave per sequence: its padding rows get the bias; a sequence that is ALL padding is skipped (with
+    // skip_all_pad: the attention kernels take the closed form for it and never read its rows)
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long)gridDim.x * 4;
     f32x4 b[FILL_SLICES];
 #pragma unroll
     for (int i = 0; i < FILL_SLICES; ++i)
         b[i] = (lane + 64 * i < n4) ? reinterpret_cast<const f32x4*>(row)[lane + 64 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long m = wave; m < M; m += n_waves) {
-        if (ids[m] != 0) continue;
-        f32x4* o = reinterpret_cast<f32x4*>(out) + m * n4;
+    for (long q = wave; q < n_seq; q += n_waves) {
+        const bool is_pad = lane < S && ids[q * S + lane] == 0;
+        unsigned long long m = __ballot(is_pad);
+        if (SKIP_ALL_PAD && __popcll(m) == S) continue;
+        while (m != 0ull) {
+            const int r = __builtin_ctzll(m);
+            m &= m - 1ull;
+            f32x4* o = reinterpret_cast<f32x4*>(out) + (q * S + r) * n4;
 #pragma unroll
-        for (int i = 0; i < FILL_SLICES; ++i)
-            if (lane + 64 * i < n4) o[lane + 64 * i] = b[i];
+            for (int i = 0; i < FILL_SLICES; ++i)
+                if (lane + 64 * i < n4) o[lane + 64 * i] = b[i];
+        }
     }
 }
 
-int launch_fill_pad_rows(long M, int n, const int64_t* ids, const float* row, float* out, hipStream_t stream) {
-    if (M <= 0) return NRMS_OK;
-    if ((n & 3) != 0 || n > 256 * FILL_SLICES) { set_error("fill_pad_rows: n=%d unsupported", n); return NRMS_EINVAL; }
-    int blocks = cdiv(M, 4);
+// skip_all_pad must match what the attention kernels do (they skip all-padding sequences only without a mask)
+int launch_fill_pad_rows(long n_seq, int S, int n, const int64_t* ids, const float* row, float* out, bool skip_all_pad,
+                         hipStream_t stream) {
+    if (n_seq <= 0) return NRMS_OK;
+    if ((n & 3) != 0 || n > 256 * FILL_SLICES || S > 64) { set_error("fill_pad_rows: n=%d S=%d unsupported", n, S); return NRMS_EINVAL; }
+    int blocks = cdiv(n_seq, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
     TimingScope ts("fill_pad_rows", stream);
-    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3(blocks), dim3(256), 0, stream, M, n / 4, ids, row, out);
+    if (skip_all_pad) hipLaunchKernelGGL(fill_pad_rows_kernel_t<true>, dim3(blocks), dim3(256), 0, stream, n_seq, S, n / 4, ids, row, out);
+    else hipLaunchKernelGGL(fill_pad_rows_kernel_t<false>, dim3(blocks), dim3(256), 0, stream, n_seq, S, n / 4, ids, row, out);
     return check_launch("fill_pad_rows");
 }
 

@@ -328,8 +328,10 @@ int launch_scatter_dropout(long M, int d, const int64_t* ids, const float* dx, c
 // x[r, :] = table[ids[live[r]], :] * keep(live[r], :) / (1 - p) for the compact rows r < *n_live
 int launch_gather_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live,
                                   const float* table, const Dropout& drop, float* x, hipStream_t stream);
-// out[m, :] = row[:] for every token m with ids[m] == 0 (n % 4 == 0)
-int launch_fill_pad_rows(long M, int n, const int64_t* ids, const float* row, float* out, hipStream_t stream);
+// out[m, :] = row[:] for every token m of the [n_seq, S] id matrix with ids[m] == 0 (n % 4 == 0); with
+// skip_all_pad, sequences without any real token are left untouched
+int launch_fill_pad_rows(long n_seq, int S, int n, const int64_t* ids, const float* row, float* out, bool skip_all_pad,
+                         hipStream_t stream);
 // dbias[perm.src(c)] += sum over the tokens m with ids[m] == 0 of x[m, c]   (n % 4 == 0)
 int launch_colsum_pad_rows(long M, int n, const int64_t* ids, const float* x, HeadPerm perm, float* dbias,
                            hipStream_t stream);

@@ -258,8 +258,8 @@ def test_live_row_compaction_edges(case):
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_padding_token_skip_equals_dense_path(precision):
     """NRMS_FLAG_PAD_ROW_ZERO (embedding row 0 all zeros): the compact path (Q|K|V projection and d(w_qkv) on
-    the non-padding tokens only) must reproduce the dense path -- forward bit for bit (row-independent
-    arithmetic; a padding row is 0.w + b = b exactly), gradients up to summation order -- also in train mode
+    the non-padding tokens only) must reproduce the dense path -- Q|K|V bit for bit (row-independent
+    arithmetic; a padding row is 0.w + b = b exactly), scores and gradients up to summation order -- also in train mode
     with both dropouts on (same seed => same masks)."""
     shape = synth.Shape(n_words=500, word_embed_size=120, num_attention_heads=6, query_vector_dim=64,
                         batch_size=12, history_len=20, n_candidates=4, n_words_title=17)
@@ -276,12 +276,16 @@ def test_padding_token_skip_equals_dense_path(precision):
         scores, loss, grads = fwd_bwd(model, batch)
         assert model.engine.pad_row_zero is skip
         out[skip] = (scores, grads)
-    np.testing.assert_array_equal(out[True][0], out[False][0])
+    # (an all-padding title takes the closed form ctx = b_v instead of summing 17 equal terms b_v / 17)
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=1e-6)
+    # gradients: to summation order, measured against the overall gradient scale (several tensors -- W_K.bias,
+    # the user encoder's additive weights at this size, d(b_add) as a cancelling sum -- are pure rounding
+    # noise many orders below it, where a relative comparison says nothing)
+    gscale = max(float(np.abs(out[False][1][n]).max()) for n in synth.param_names()
+                 if not n.endswith("word_embedding.0.weight"))
     for n in synth.param_names():
-        if n.endswith("W_K.bias"):                 # analytically zero: rounding noise only
-            continue
         a, b = out[True][1][n], out[False][1][n]
-        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * max(1e-12, float(np.abs(b).max())), err_msg=n)
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-7 * gscale, err_msg=n)
     # a table with a non-zero padding row never takes the compact path
     params2 = synth.make_params(shape, seed=131, pad_row_zero=False)
     model = make_model(shape, params2)
