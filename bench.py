@@ -39,12 +39,14 @@ DTYPES = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA inputs hi+lo, fp32 a
           "bf16": "bf16 (MFMA inputs), fp32 accumulate, fp32 storage"}
 
 
-def kernel_work(shape, B, live_frac=1.0, compact_qkv=False):
+def kernel_work(shape, B, live_frac=1.0, compact_qkv=False, allpad_frac=0.0):
     """Per kernel: (declared bound, algorithmic flop per step, algorithmic HBM bytes per step), summed over
     the news-encoder and user-encoder launches.  flop = 2mnk of the contractions; bytes =
     every activation tensor the kernel must read or write once, fp32 (weights are negligible).
     live_frac = share of the news-encoder token rows whose id is not the padding id: the X-gradient GEMM and
-    the embedding scatter only process those (padding_idx rows receive no gradient), so only they count."""
+    the embedding scatter only process those (padding_idx rows receive no gradient), so only they count.
+    allpad_frac = share of the titles without any real token: with compact_qkv the attention kernels take the
+    closed form for them (no Q|K|V read, no products)."""
     H, C, L = shape.history_len, shape.n_candidates, shape.n_words_title
     d, q = shape.word_embed_size, shape.query_vector_dim
     Ms = (B * (H + C) * L, B * H)             # rows: news tokens, user-encoder rows
@@ -54,6 +56,9 @@ def kernel_work(shape, B, live_frac=1.0, compact_qkv=False):
     add = 2.0 * M * d * q
     att = sum(n * 2.0 * 2 * S * S * d for n, S in seqs)        # QK^T + PV over all heads
     Md, Mq = 4.0 * M * d, 4.0 * M * q
+    ap = allpad_frac if compact_qkv else 0.0
+    att_live = seqs[0][0] * (1.0 - ap) * 2.0 * 2 * L * L * d + seqs[1][0] * 2.0 * 2 * H * H * d
+    Md_live = 4.0 * (Ms[0] * (1.0 - ap) + Ms[1]) * d      # Q|K|V rows the attention kernels actually read
     Mlx = Ms[0] * live_frac + Ms[1]           # token rows that are not padding (user-encoder rows all count)
     Ml = Mlx if compact_qkv else M            # rows the Q|K|V projection / d(w_qkv) / compact dQKV touch
     n_params = shape.n_words * d + 2 * (3 * d * d + 3 * d + q * d + 2 * q)
@@ -67,8 +72,8 @@ def kernel_work(shape, B, live_frac=1.0, compact_qkv=False):
         "addattn_fwd": ("mfma", add, Md + Mq),
         "dctx_bwd": ("mfma", add, Mq + Md),
         "dwadd_bwd": ("mfma", add, Mq + Md),
-        "attn_fwd": ("hbm", att, 3 * Md + Md),
-        "attn_bwd": ("hbm", 2.5 * att, 3 * Md + Md + 12.0 * Ml * d),
+        "attn_fwd": ("hbm", att_live, 3 * Md_live + Md),
+        "attn_bwd": ("hbm", 2.5 * att_live, 3 * Md_live + Md + 12.0 * Ml * d),
         "addattn_bwd_rows": ("hbm", 0.0, Md + Mq),
         "gather_dropout": ("hbm", 0.0, 2 * Mn_d * (live_frac if compact_qkv else 1.0)),
         "scatter_dropout": ("hbm", 0.0, 2 * Mn_d * live_frac),
@@ -190,7 +195,11 @@ def main():
         live = float((batch_np["browsed_titles"] != 0).sum() + (batch_np["candidate_titles"] != 0).sum())
         live_frac = live / float(B * (shape.history_len + shape.n_candidates) * shape.n_words_title)
         compact_qkv = bool(eng.pad_row_zero)
-        work = kernel_work(shape, B, live_frac, compact_qkv)
+        titles = np.concatenate([batch_np["browsed_titles"].reshape(-1, shape.n_words_title),
+                                 batch_np["candidate_titles"].reshape(-1, shape.n_words_title)])
+        allpad_frac = float((titles != 0).any(axis=1).mean())
+        allpad_frac = 1.0 - allpad_frac
+        work = kernel_work(shape, B, live_frac, compact_qkv, allpad_frac)
         kernels = {}
         for name, (bound, fl, by) in work.items():
             ms, n = eng.timing_read(name)
@@ -229,6 +238,7 @@ def main():
                                    "cand=5, title_len=30, d=300, h=10, q=200, V=45800, dropout=0.2, Adam(lr=1e-3)" % B,
                        "users_per_gpu": B, "global_batch": B * world,
                        "non_padding_token_fraction": round(live_frac, 4),
+                       "all_padding_title_fraction": round(allpad_frac, 4),
                        "padding_tokens_skipped": ("dX + embedding scatter (dead values); Q|K|V projection and d(w_qkv) too: "
                                                   "embedding row 0 is zero" if compact_qkv else
                                                   "dX + embedding scatter (dead values)"),
