@@ -89,6 +89,18 @@ __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint32_t site, ui
     return r[elem & 3] >= thresh ? inv_keep : 0.f;
 }
 
+// Branch-free tanh for the split-bf16 modes: 1 - 2 / (exp(2x) + 1) on v_exp_f32 / v_rcp_f32 (absolute error
+// ~1e-7, saturates correctly), and the odd Taylor polynomial where that form cancels (|x| < 0.12, truncation
+// < 1e-10).  libm's tanhf is ~45 instructions with two branches per call; the additive-attention epilogue
+// makes 104 calls per lane and tile.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __expf(2.0f * x);
+    const float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float x2 = x * x;
+    const float p = x * (1.0f + x2 * (-0.33333333f + x2 * (0.13333333f + x2 * -0.053968254f)));
+    return fabsf(x) < 0.12f ? p : r;
+}
+
 // Head-major column order of the Q/K/V projection.  The reference's W_Q, W_K, W_V stack gives output
 // column n = which * d + head * d_k + j (which = 0,1,2 for Q,K,V; model/nrms_v0.py:53-58 splits the heads
 // afterwards).  The HIP path stores the projection as n' = head * 3 d_k + which * d_k + j, so that one

@@ -360,6 +360,15 @@ __global__ __launch_bounds__(BF_THREADS, 2) void addattn_fwd_bf16_kernel(AddFwdA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
+    // this lane's columns n = 16 nt + r16: bias and query-vector slices once per tile (not per element)
+    float bcol[NT], qcol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * nt + r16;
+        const bool ok = n < g.N;
+        bcol[nt] = ok ? g.bias[n] : 0.f;
+        qcol[nt] = ok ? a.qv[n] : 0.f;              // q = 0 also zeroes the padded columns' contribution
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -367,13 +376,9 @@ __global__ __launch_bounds__(BF_THREADS, 2) void addattn_fwd_bf16_kernel(AddFwdA
             float part = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int n = 16 * nt + r16;
-                float t = 0.f;
-                if (n < g.N) {
-                    t = tanhf(acc[mt][nt][reg] + g.bias[n]);
-                    part += t * a.qv[n];
-                }
-                acc[mt][nt][reg] = t;
+                const float t = fast_tanh(acc[mt][nt][reg] + bcol[nt]);
+                part += t * qcol[nt];
+                acc[mt][nt][reg] = t;               // (columns >= N are never stored)
             }
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);

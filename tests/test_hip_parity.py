@@ -285,7 +285,7 @@ def test_padding_token_skip_equals_dense_path(precision):
                  if not n.endswith("word_embedding.0.weight"))
     for n in synth.param_names():
         a, b = out[True][1][n], out[False][1][n]
-        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-7 * gscale, err_msg=n)
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=2e-7 * gscale, err_msg=n)
     # a table with a non-zero padding row never takes the compact path
     params2 = synth.make_params(shape, seed=131, pad_row_zero=False)
     model = make_model(shape, params2)
