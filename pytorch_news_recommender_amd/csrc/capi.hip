@@ -52,7 +52,7 @@ TimingScope::TimingScope(const char* name, hipStream_t s) : active(false), slot(
     TimedLaunch t;
     t.name = name;
     if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return;
-    hipEventRecord(t.start, s);
+    (void)hipEventRecord(t.start, s);
     g_launches.push_back(t);
     slot = (int)g_launches.size() - 1;
     active = true;
@@ -61,7 +61,7 @@ TimingScope::TimingScope(const char* name, hipStream_t s) : active(false), slot(
 TimingScope::~TimingScope() {
     if (!active) return;
     std::lock_guard<std::mutex> lk(g_tmu);
-    hipEventRecord(g_launches[slot].stop, stream);
+    (void)hipEventRecord(g_launches[slot].stop, stream);
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -397,7 +397,7 @@ extern "C" void nrms_timing_enable(int enable) {
 
 extern "C" void nrms_timing_reset(void) {
     std::lock_guard<std::mutex> lk(g_tmu);
-    for (auto& t : g_launches) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    for (auto& t : g_launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     g_launches.clear();
 }
 

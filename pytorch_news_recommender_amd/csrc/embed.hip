@@ -108,33 +108,6 @@ int launch_fill_pad_rows(long n_seq, int S, int n, const int64_t* ids, const flo
     return check_launch("fill_pad_rows");
 }
 
-// Column sums of the padding-token rows of x [M, n]: their share of the bias gradient (the weight
-// gradient GEMM only visits the non-padding rows).  A block owns a contiguous range of rows; thread t
-// accumulates float4 column t of the rows whose id is 0 (a block-uniform test), then adds its sums once.
-__global__ __launch_bounds__(256) void colsum_pad_rows_kernel(long M, int n4, int rows_per_block, const int64_t* ids,
-                                                              const float* x, HeadPerm perm, float* dbias) {
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    const long r1 = min(M, r0 + rows_per_block);
-    for (int c4 = threadIdx.x; c4 < n4; c4 += 256) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (long r = r0; r < r1; ++r)
-            if (ids[r] == 0) s += *reinterpret_cast<const f32x4*>(x + r * (4L * n4) + 4 * c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dbias + perm.src(4 * c4 + e), s[e]);
-    }
-}
-
-int launch_colsum_pad_rows(long M, int n, const int64_t* ids, const float* x, HeadPerm perm, float* dbias,
-                           hipStream_t stream) {
-    if (M <= 0) return NRMS_OK;
-    if ((n & 3) != 0) { set_error("colsum_pad_rows: n=%d must be a multiple of 4", n); return NRMS_EINVAL; }
-    const int rows_per_block = 256;
-    TimingScope ts("colsum_pad_rows", stream);
-    hipLaunchKernelGGL(colsum_pad_rows_kernel, dim3(cdiv(M, rows_per_block)), dim3(256), 0, stream, M, n / 4, rows_per_block,
-                       ids, x, perm, dbias);
-    return check_launch("colsum_pad_rows");
-}
-
 // Token positions whose id is not the padding id, in ASCENDING order (deterministic: the order fixes the
 // summation order of the weight-gradient GEMM that runs over the compact rows), plus the inverse map.
 // Three small passes: per-block counts, one-block exclusive scan, ordered write.

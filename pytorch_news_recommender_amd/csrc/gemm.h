@@ -332,9 +332,6 @@ int launch_gather_dropout_compact(long M, int d, const int64_t* ids, const int* 
 // skip_all_pad, sequences without any real token are left untouched
 int launch_fill_pad_rows(long n_seq, int S, int n, const int64_t* ids, const float* row, float* out, bool skip_all_pad,
                          hipStream_t stream);
-// dbias[perm.src(c)] += sum over the tokens m with ids[m] == 0 of x[m, c]   (n % 4 == 0)
-int launch_colsum_pad_rows(long M, int n, const int64_t* ids, const float* x, HeadPerm perm, float* dbias,
-                           hipStream_t stream);
 // live[0 .. *n_live) = the token positions m with ids[m] != 0 in ascending order; pos (optional) = inverse map
 // (-1 for padding tokens); scratch: compact_scratch_ints(M) ints
 size_t compact_scratch_ints(long M);

@@ -111,7 +111,6 @@ int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const f
 // two-stage sum).
 // =======================================================================================
 constexpr int ROWS_WPB = 4;
-constexpr int ROWS_MAXQ = 256;
 
 __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
     int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w, const float* T, float* ds,
