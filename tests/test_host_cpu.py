@@ -195,3 +195,24 @@ def test_warmup_schedule_matches_reference_scheduler():
     for i, lr in enumerate(used):
         assert abs(lr - warmup_lr(1e-3, i, 500)) < 1e-12, (i, lr)
     assert used[0] == 0.0 and used[1] == 0.0 and abs(used[501] - 1e-3) < 1e-15
+
+
+def test_engine_scratch_bound_covers_library_sizes_and_flag_validation():
+    """The host side sizes the forward scratch with a closed-form bound (engine._acts); it must cover
+    nrms_encoder_fwd_scratch_bytes for every mode, with and without NRMS_FLAG_PAD_ROW_ZERO; unknown flag
+    bits are rejected."""
+    lib = _lib.load()
+    for d, h, q, n_seq, S in [(300, 10, 200, 28160, 30), (512, 8, 256, 1000, 64), (60, 6, 32, 7, 9), (8, 2, 4, 1, 1)]:
+        M = n_seq * S
+        bound_floats = 3 * d * d + 3 * d + 256 + (3 * d + 32) * (d + 32) + (M + M // 1024 + 512)
+        for prec in (0, 1, 2):
+            for vocab, flags in ((0, 0), (100, 0), (100, _lib.NRMS_FLAG_PAD_ROW_ZERO)):
+                desc = _lib.EncoderDesc(n_seq=n_seq, seq_len=S, d_model=d, n_heads=h, q_dim=q, vocab=vocab,
+                                        p_drop_embed=0.0, p_drop_ctx=0.0, precision=prec, flags=flags, seed=0)
+                need = lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(desc))
+                assert 0 < need <= 4 * bound_floats, (d, prec, vocab, flags, need, 4 * bound_floats)
+                assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(desc)) > 0
+    bad = _lib.EncoderDesc(n_seq=1, seq_len=5, d_model=60, n_heads=6, q_dim=32, vocab=10, p_drop_embed=0.0,
+                           p_drop_ctx=0.0, precision=0, flags=4, seed=0)
+    assert lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(bad)) == 0
+    assert b"flags" in lib.nrms_last_error()
