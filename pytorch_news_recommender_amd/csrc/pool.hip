@@ -25,23 +25,29 @@ __global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     gemm_nt_mainloop<NT, A_PLAIN>(g, row0, rows_valid, 0, acc, lds);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
+    // this lane's columns n = 16 nt + r16: bias and query-vector slices once per tile (not per element)
+    float bcol[NT], qcol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 16 * nt + r16;
+        const bool ok = n < g.N;
+        bcol[nt] = ok ? g.bias[n] : 0.f;
+        qcol[nt] = ok ? a.qv[n] : 0.f;              // q = 0 also zeroes the padded columns' contribution
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int rl = 32 * wave + 16 * mt + 4 * kq + reg;
-            const long grow = (long)row0 + rl;
             float part = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int n = 16 * nt + r16;
-                if (n < g.N) {
-                    const float t = tanhf(acc[mt][nt][reg] + g.bias[n]);
-                    part += t * a.qv[n];
-                    if (a.T != nullptr && rl < rows_valid) a.T[grow * g.N + n] = t;
-                }
+                const float t = tanhf(acc[mt][nt][reg] + bcol[nt]);     // exact-parity mode keeps libm's tanhf
+                part += t * qcol[nt];
+                acc[mt][nt][reg] = t;
             }
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);
@@ -49,6 +55,14 @@ __global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
             part += __shfl_xor(part, 8, 64);
             if (r16 == 0) sc[rl] = part;
         }
+    if (a.T != nullptr) {
+        // T [M, q] in whole rows through the per-wave LDS strips (the stage buffers are dead now)
+        static_assert(4 * 8 * (16 * NT + 8) <= 2 * (NT_BM + 16 * NT) * NT_BK, "epilogue strips must fit the stage buffers");
+        __syncthreads();
+        NTArgs tg = g;
+        tg.bias = nullptr; tg.C = a.T; tg.ldc = g.N;
+        nt_epilogue<NT, E_STORE>(tg, acc, row0, rows_valid, 0, wave, lane, lds + wave * 8 * (16 * NT + 8));
+    }
     __syncthreads();
     const int spb = rows_valid / a.S;
     if (tid < spb) {
