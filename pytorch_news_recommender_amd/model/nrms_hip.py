@@ -175,8 +175,10 @@ class Model(nn.Module):
             self._engine = NRMSEngine(self._dims, self._flat.device, precision=prec)
         elif self._engine.precision != prec:
             self._engine.set_precision(prec)
-        if getattr(self, "_pad_zero", None) is None:
-            # one host sync per weight load: is the padding row of the embedding table all zeros?
+        self._prepare_calls = getattr(self, "_prepare_calls", 0) + 1
+        if getattr(self, "_pad_zero", None) is None or self._prepare_calls % 256 == 0:
+            # one host sync per weight load (and a cheap re-validation every 256 calls, should somebody write
+            # into the table by hand without refresh_pad_row_flag()): is the padding row all zeros?
             tname = [n for n in self._names if n.endswith("word_embedding.0.weight") or n.endswith("word_embedding.weight")][0]
             self._pad_zero = bool((self._layout.view(self._flat, tname)[0] == 0).all().item())
         self._engine.pad_row_zero = self._pad_zero and bool(getattr(self.config, "skip_padding_tokens", True))
