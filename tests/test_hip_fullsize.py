@@ -104,3 +104,35 @@ def test_train_step_runs_and_loss_decreases_on_a_fixed_batch(full):
     model.config.learning_rate = 1e-3
     losses = [float(model.train_step(tb)) / shape.batch_size for _ in range(6)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_padding_token_skip_equals_dense_path_at_full_size(full):
+    """NRMS_FLAG_PAD_ROW_ZERO at the bench shape (844 800 token rows, ~65 % padding, ~41 % all-padding
+    titles): scores and every gradient tensor of the compact path against the dense path of the same model,
+    and the weight gradients of the compact path are run-to-run reproducible (deterministic compaction)."""
+    shape, model, batch, tb = full
+    eng, flat = model.engine, model._flat
+    lay = model._layout
+    g = torch.Generator(device="cpu").manual_seed(9)
+    res = {}
+    for skip in (True, False, True):
+        eng.pad_row_zero = skip
+        s = _scores(model, tb).clone()
+        d1 = (torch.randn(s.shape, generator=torch.Generator().manual_seed(9)) * 1e-3).cuda()
+        gf = torch.zeros_like(flat)
+        eng.backward(flat, gf, d1)
+        res.setdefault(skip, []).append((s, gf))
+    eng.pad_row_zero = model._pad_zero
+    (s_a, g_a), (s_c, g_c) = res[True]
+    s_b, g_b = res[False][0]
+    assert torch.equal(s_a, s_c)
+    table = "news_encoder.word_embedding.0.weight"
+    for name in lay.names:
+        if name != table:                        # the table gradient is a float-atomic scatter in both paths
+            assert torch.equal(lay.view(g_a, name), lay.view(g_c, name)), name
+    assert float((s_a - s_b).abs().max()) < 2e-6
+    gscale = max(float(lay.view(g_b, n).abs().max()) for n in lay.names if n != table)
+    for name in lay.names:
+        a, b = lay.view(g_a, name), lay.view(g_b, name)
+        tol = 1e-4 * float(b.abs().max()) + 2e-7 * gscale
+        assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), tol)
