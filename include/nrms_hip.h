@@ -47,6 +47,11 @@ extern "C" {
  * The row keeps its value under training (its gradient is identically zero), so the flag is a property
  * of the loaded weights.  Ignored when vocab == 0. */
 #define NRMS_FLAG_PAD_ROW_ZERO 1
+/* nrms_encoder_bwd leaves d(w_qkv) / d(b_qkv) out (its step 5); the caller runs nrms_encoder_bwd_wqkv with the
+ * same descriptor, activations and workspace afterwards.  Everything else, in particular the embedding-table
+ * gradient, is complete when nrms_encoder_bwd returns: a data-parallel caller starts the all-reduce of the
+ * table gradient (95 % of the gradient bytes) there and lets it run underneath the deferred GEMM. */
+#define NRMS_FLAG_DEFER_WQKV 2
 
 /* One self-attention + additive-pooling encoder pass over n_seq sequences of seq_len rows.
  * vocab > 0  : news encoder -- input is `ids` [n_seq, seq_len] int64, rows gathered from
@@ -128,6 +133,11 @@ int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* 
                      const nrms_encoder_acts* acts, const float* dout,
                      const nrms_encoder_grads* grads, float* dx,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* Step 5 of the backward on its own: d(w_qkv), d(b_qkv) += dQKV^T [X | 1] from the dQKV left in `workspace`
+ * by nrms_encoder_bwd(desc with NRMS_FLAG_DEFER_WQKV) -- same desc, ids / x, acts, grads, workspace. */
+int nrms_encoder_bwd_wqkv(const nrms_encoder_desc* desc, const int64_t* ids, const float* x,
+                          const nrms_encoder_acts* acts, const nrms_encoder_grads* grads,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* Click scores: bmm(cand [B,C,d], user [B,d,1]) then masked_fill(mask==0, -1e9)
  * (DotProductClickPredictor, nrms_v0.py:205-216; mask nrms_v0.py:272-274).  mask may be NULL. */

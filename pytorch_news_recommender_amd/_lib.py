@@ -12,6 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRMS_HIP_LIB") or os.path.join(PKG, "libnrms_hip.so")   # override: diagnostic builds only
 
 NRMS_FLAG_PAD_ROW_ZERO = 1
+NRMS_FLAG_DEFER_WQKV = 2
 NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1
 NRMS_PRECISION_BF16 = 2
@@ -54,6 +55,8 @@ SIGNATURES = {
     "nrms_encoder_bwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(EncoderActs), C.c_void_p, C.POINTER(EncoderGrads), C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nrms_encoder_bwd_wqkv": (C.c_int, [C.POINTER(EncoderDesc), C.c_void_p, C.c_void_p, C.POINTER(EncoderActs),
+                                        C.POINTER(EncoderGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "nrms_click_score_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "nrms_click_score_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -85,7 +85,7 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d->precision >= NRMS_PRECISION_FP32 && d->precision <= NRMS_PRECISION_BF16,
                  "%s: unsupported precision %d", who, d->precision);
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
-    NRMS_REQUIRE((d->flags & ~NRMS_FLAG_PAD_ROW_ZERO) == 0, "%s: unknown flags 0x%x", who, d->flags);
+    NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV)) == 0, "%s: unknown flags 0x%x", who, d->flags);
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
     return NRMS_OK;
 }
@@ -255,6 +255,36 @@ extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc
     return bwd_layout(desc).total;
 }
 
+// step 5 of the backward (shared by nrms_encoder_bwd and nrms_encoder_bwd_wqkv)
+static int bwd_wqkv(const nrms_encoder_desc* desc, const float* xin, const float* dqkv, const int* n_live,
+                    const nrms_encoder_grads* grads, float* tn_partial, hipStream_t s) {
+    const int d = desc->d_model, M = desc->n_seq * desc->seq_len;
+    TNArgs t{};
+    t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN;
+    t.A = dqkv; t.lda = 3 * d; t.B = xin; t.ldb = d;
+    t.dW = grads->w_qkv; t.dbias = grads->b_qkv; t.partial = tn_partial;
+    t.perm = HeadPerm{d / desc->n_heads, desc->n_heads};          // dQKV columns are head-major
+    if (skip_pad_rows(desc)) t.m_dev = n_live;                    // compact operands
+    return tn_gemm(desc, t, s, "dwqkv_bwd");
+}
+
+extern "C" int nrms_encoder_bwd_wqkv(const nrms_encoder_desc* desc, const int64_t* ids, const float* x,
+                                     const nrms_encoder_acts* acts, const nrms_encoder_grads* grads, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    int rc = validate_desc(desc, "encoder_bwd_wqkv");
+    if (rc) return rc;
+    NRMS_REQUIRE(acts && grads && workspace, "encoder_bwd_wqkv: null argument");
+    NRMS_REQUIRE(grads->w_qkv && grads->b_qkv, "encoder_bwd_wqkv: null gradient buffer");
+    const bool gather = desc->vocab > 0;
+    NRMS_REQUIRE(gather ? (ids != nullptr && acts->x != nullptr) : (x != nullptr), "encoder_bwd_wqkv: input missing");
+    if (desc->n_seq == 0) return NRMS_OK;
+    const BwdWorkspace L = bwd_layout(desc);
+    NRMS_REQUIRE(workspace_bytes >= L.total, "encoder_bwd_wqkv: workspace %zu < required %zu bytes", workspace_bytes, L.total);
+    char* base = (char*)workspace;
+    return bwd_wqkv(desc, gather ? acts->x : x, (const float*)(base + L.dqkv), (const int*)(base + L.n_live), grads,
+                    (float*)(base + L.tn_partial), (hipStream_t)stream);
+}
+
 extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
                                 const float* x, const uint8_t* mask, const nrms_encoder_acts* acts, const float* dout,
                                 const nrms_encoder_grads* grads, float* dx, void* workspace, size_t workspace_bytes,
@@ -361,16 +391,10 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
                           nullptr, nullptr, compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
                           compact ? grads->b_qkv : nullptr, s);
     if (rc) return rc;
-    // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings)
-    const float* xin = gather ? acts->x : x;
-    {
-        TNArgs t{};
-        t.M = M; t.N = 3 * d; t.K = d; t.amode = A_PLAIN;
-        t.A = dqkv; t.lda = 3 * d; t.B = xin; t.ldb = d;
-        t.dW = grads->w_qkv; t.dbias = grads->b_qkv; t.partial = tn_partial;
-        t.perm = perm;                                            // dQKV columns are head-major
-        if (compact) t.m_dev = n_live;
-        rc = tn_gemm(desc, t, s, "dwqkv_bwd");
+    // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings) -- or later,
+    //    by nrms_encoder_bwd_wqkv (NRMS_FLAG_DEFER_WQKV)
+    if ((desc->flags & NRMS_FLAG_DEFER_WQKV) == 0) {
+        rc = bwd_wqkv(desc, gather ? acts->x : x, dqkv, n_live, grads, tn_partial, s);
         if (rc) return rc;
     }
     // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: compact dX into the (now

@@ -281,8 +281,12 @@ class NRMSEngine:
         return dx[:B * H].view(B, H, d)
 
     # ---- full model backward ------------------------------------------------------------
-    def backward(self, flat, gflat, dscores):
-        """Accumulates d(loss)/d(params) into gflat (same layout as flat) given dscores [B,C]."""
+    def backward(self, flat, gflat, dscores, table_grad_ready=None):
+        """Accumulates d(loss)/d(params) into gflat (same layout as flat) given dscores [B,C].
+
+        table_grad_ready: optional callable invoked as soon as the embedding-table gradient (95 % of the
+        gradient bytes) is complete on the stream; the news encoder's d(W_qkv) GEMM is then deferred behind
+        it (NRMS_FLAG_DEFER_WQKV) so that a data-parallel caller can start the table all-reduce underneath."""
         sv = self._saved
         if sv is None:
             raise _lib.NrmsError("backward() without a training forward()")
@@ -307,10 +311,17 @@ class NRMSEngine:
                                    mask_mode=sv["user_mask_mode"])
         wn, gn = self._weights(flat, "news_encoder"), self._grads(gflat, "news_encoder")
         acts_n = self._acts("news", N * L, True, gather=True)
+        if table_grad_ready is not None:
+            desc_n.flags |= _lib.NRMS_FLAG_DEFER_WQKV
         rc = self.lib.nrms_encoder_bwd(C.byref(desc_n), C.byref(wn), _lib.ptr(sv["ids"]), None, None, C.byref(acts_n),
                                        _lib.ptr(dnv), C.byref(gn), None, _lib.ptr(ws),
                                        C.c_size_t(ws.numel() * 4), _stream())
         _lib.check(rc, "nrms_encoder_bwd(news)")
+        if table_grad_ready is not None:
+            table_grad_ready()
+            rc = self.lib.nrms_encoder_bwd_wqkv(C.byref(desc_n), _lib.ptr(sv["ids"]), None, C.byref(acts_n), C.byref(gn),
+                                                _lib.ptr(ws), C.c_size_t(ws.numel() * 4), _stream())
+            _lib.check(rc, "nrms_encoder_bwd_wqkv(news)")
 
     def adam_step(self, flat, gflat, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                   grad_scale=1.0):

@@ -264,9 +264,20 @@ class Model(nn.Module):
         scores = eng.forward(self._flat, bt, ct, mask, training=True, p_drop=p_drop, seed=seed)
         loss_sum, dscores = eng.ce_loss(scores, grad_scale=1.0 / gb)
         st["g"].zero_()
-        eng.backward(self._flat, st["g"], dscores)
-        if all_reduce is not None:
-            all_reduce(st["g"])
+        if all_reduce is not None and hasattr(all_reduce, "start"):
+            # the table gradient (first V*d floats of the flat buffer, 95 % of the bytes) is reduced underneath
+            # the deferred d(W_qkv) GEMM; the remaining 2.6 MB follow when the backward has been enqueued
+            n_table = self._dims.n_words * self._dims.word_embed_size
+            pending = []
+            eng.backward(self._flat, st["g"], dscores,
+                         table_grad_ready=lambda: pending.append(all_reduce.start(st["g"][:n_table])))
+            all_reduce(st["g"][n_table:])
+            for h in pending:
+                h.wait()
+        else:
+            eng.backward(self._flat, st["g"], dscores)
+            if all_reduce is not None:
+                all_reduce(st["g"])
         st["step"] += 1
         eng.adam_step(self._flat, st["g"], st["m"], st["v"], st["step"],
                       lr=float(self.config.learning_rate if lr is None else lr), betas=betas, eps=eps)

@@ -49,6 +49,11 @@ def shard_batch(batch: dict, rank: int, world: int):
     return {k: v[lo:hi] for k, v in batch.items()}
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 class GradAllReduce:
     """callable(flat_grad): in-place sum over ranks of the single flat gradient buffer
     (57.6 MB at V=45 800).  One large message, as the xGMI mesh prefers."""
@@ -56,6 +61,18 @@ class GradAllReduce:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def start(self, part: torch.Tensor):
+        """Begin the in-place sum of `part` over the ranks and return a handle with .wait().  With RCCL the
+        collective runs on the process group's own stream, ordered after the work already enqueued on the
+        current stream, and .wait() makes the current stream wait for it -- no host synchronisation: kernels
+        enqueued between start() and wait() overlap with it."""
+        if self.world <= 1:
+            return _Done()
+        if part.is_cuda and dist.get_backend(self.group) == "gloo":
+            self(part)                           # test rigs only: synchronous, staged through the host
+            return _Done()
+        return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def __call__(self, flat_grad: torch.Tensor):
         if self.world > 1:

@@ -60,7 +60,14 @@ def _worker(rank, world, port, out_dir):
     for n, t in p.items():
         if t.grad is not None:
             lay.view(gflat, n).copy_(t.grad)
-    parallel.GradAllReduce()(gflat)
+    # the way Model.train_step reduces: table part asynchronously (overlapped with the deferred d(W_qkv)
+    # GEMM on the GPU), the remaining tensors afterwards, then wait
+    reduce = parallel.GradAllReduce()
+    n_table = shape.n_words * shape.word_embed_size
+    assert lay.entries["news_encoder.word_embedding.0.weight"][0] == 0          # the table leads the flat buffer
+    handle = reduce.start(gflat[:n_table])
+    reduce(gflat[n_table:])
+    handle.wait()
     tmax = parallel.max_over_ranks(float(rank + 1), torch.device("cpu"))
     assert tmax == float(world)
     parallel.barrier()

@@ -80,3 +80,44 @@ def test_two_ranks_match_single_process(tmp_path):
     # Adam amplifies fp32 summation-order noise where |g| ~ eps (see test_hip_parity.assert_params_close)
     assert np.median(diff) < 1e-6 and np.quantile(diff, 0.999) < 1e-4 and diff.max() < 2.1e-3, (
         float(np.median(diff)), float(diff.max()))
+
+
+def test_deferred_wqkv_backward_equals_plain_backward():
+    """engine.backward(table_grad_ready=...) -- NRMS_FLAG_DEFER_WQKV + nrms_encoder_bwd_wqkv -- calls the hook
+    once, after which only d(W_qkv) / d(b_qkv) of the news encoder are still outstanding; the result equals the
+    one-call backward (bit for bit outside the float-atomic table gradient)."""
+    import numpy as np
+    import torch
+    from pytorch_news_recommender_amd import synth
+    from tests.test_hip_parity import make_model, tbatch
+    shape = synth.Shape(n_words=400, word_embed_size=120, num_attention_heads=6, query_vector_dim=64,
+                        batch_size=9, history_len=12, n_candidates=4, n_words_title=14)
+    params = synth.make_params(shape, seed=141)
+    batch = tbatch(synth.make_batch(shape, seed=142, ragged=True, min_title=1))
+    model = make_model(shape, params)
+    eng, flat, lay = model.engine, model._flat, model._layout
+    dev = flat.device
+    bt, ct, cm = (batch[k].to(dev) for k in ("browsed_titles", "candidate_titles", "candidate_mask"))
+    s = eng.forward(flat, bt, ct, cm, training=True)
+    dsc = (torch.randn(s.shape, generator=torch.Generator().manual_seed(3)) * 1e-2).to(dev)
+    g_plain = torch.zeros_like(flat)
+    eng.backward(flat, g_plain, dsc)
+    eng.forward(flat, bt, ct, cm, training=True)
+    g_split = torch.zeros_like(flat)
+    seen = []
+
+    def hook():
+        torch.cuda.synchronize()
+        wq = lay.view(g_split, "news_encoder.multihead_self_attention.W_Q.weight")
+        tab = lay.view(g_split, "news_encoder.word_embedding.0.weight")
+        seen.append((float(wq.abs().max()), float(tab.abs().max())))
+
+    eng.backward(flat, g_split, dsc, table_grad_ready=hook)
+    assert len(seen) == 1 and seen[0][0] == 0.0 and seen[0][1] > 0.0      # table done, W_qkv still outstanding
+    table = "news_encoder.word_embedding.0.weight"
+    for n in lay.names:
+        a, b = lay.view(g_split, n), lay.view(g_plain, n)
+        if n == table:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-9)
+        else:
+            assert torch.equal(a, b), n
