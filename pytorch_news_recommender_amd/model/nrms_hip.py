@@ -14,6 +14,8 @@ weights); the nn.Linear / nn.Embedding forwards are never called.
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -264,7 +266,7 @@ class Model(nn.Module):
         scores = eng.forward(self._flat, bt, ct, mask, training=True, p_drop=p_drop, seed=seed)
         loss_sum, dscores = eng.ce_loss(scores, grad_scale=1.0 / gb)
         st["g"].zero_()
-        if all_reduce is not None and hasattr(all_reduce, "start"):
+        if all_reduce is not None and hasattr(all_reduce, "start") and not os.environ.get("NRMS_NO_OVERLAP"):
             # the table gradient (first V*d floats of the flat buffer, 95 % of the bytes) is reduced underneath
             # the deferred d(W_qkv) GEMM; the remaining 2.6 MB follow when the backward has been enqueued
             n_table = self._dims.n_words * self._dims.word_embed_size
