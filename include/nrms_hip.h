@@ -104,13 +104,19 @@ typedef struct nrms_encoder_grads {   /* same shapes as the weights; accumulated
  * `ctx` (and `x` for the news encoder) are required scratch; `t` and `w` may then be NULL. */
 typedef struct nrms_encoder_acts {
     float* x;              /* [M, d]   news encoder only: gathered word embeddings AFTER dropout
-                                       (the user encoder's input is the caller's `x`); may be NULL if vocab==0 */
-    float* qkv;            /* [M, 3d]  Q|K|V projections incl. bias */
+                                       (the user encoder's input is the caller's `x`); may be NULL if vocab==0.
+                                       With NRMS_FLAG_PAD_ROW_ZERO only the non-padding tokens are stored, compact,
+                                       in ascending token order (the buffer is still sized [M, d]) */
+    float* qkv;            /* [M, 3d]  Q|K|V projections incl. bias, columns HEAD-MAJOR: head h occupies columns
+                                       [3 d_k h, 3 d_k (h+1)) as Q | K | V (internal layout, read by the backward
+                                       only).  With NRMS_FLAG_PAD_ROW_ZERO the rows of sequences that consist of
+                                       padding only are left unwritten (the attention takes their closed form) */
     float* attn;           /* [M, d]   use_output_proj only: head-concatenated attention output (input of W_O) */
     float* ctx;            /* [M, d]   head-concatenated attention output AFTER dropout */
     float* t;              /* [M, q]   tanh(linear(ctx))            (nrms_v0.py:108) */
     float* w;              /* [M]      additive-attention softmax weights (nrms_v0.py:110-112) */
-    void*  scratch;        /* nrms_encoder_fwd_scratch_bytes(desc) bytes: head-major W_qkv copy + bf16 weight planes */
+    void*  scratch;        /* nrms_encoder_fwd_scratch_bytes(desc) bytes: head-major W_qkv copy, bf16 weight planes,
+                              token compaction lists */
 } nrms_encoder_acts;
 
 /* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V
