@@ -264,37 +264,35 @@ __device__ __forceinline__ void at_x_tiles(const float* A, int RS, int l32, int 
         }
 }
 
-// out^T[dd][j] = sum_i A[i][dd] T[i][j], T a row-major [SP][SP+1] LDS image
+// out^T[dd][j] = sum_i A[i][dd] X[i][j] for an accumulator tile set X^T[j][i] (queries i in lanes): X is
+// brought into "queries in rows" order through an LDS image, one 32-column block (jt) at a time -- the image is
+// [SP][33] floats whatever the sequence length, so it always fits over the dead V tile (a full [64][65] image
+// cost the 64-row kernels a third of their occupancy).
+constexpr int TSH = 33;
 template <int NS, int ND>
-__device__ __forceinline__ void at_lds_tiles(const float* A, int RS, const float* T, int l32, int hh,
-                                             f32x16 (&out)[ND][NS]) {
-    constexpr int TS = 32 * NS + 1;
+__device__ __forceinline__ void at_lds_transposed(const float* A, int RS, float* T, const f32x16 (&xt)[NS][NS], int l32,
+                                                  int hh, f32x16 (&out)[ND][NS]) {
 #pragma unroll
-    for (int dt = 0; dt < ND; ++dt)
+    for (int jt = 0; jt < NS; ++jt) {
+        wave_sync();                               // earlier readers of the image (and of the tile it aliases) are done
 #pragma unroll
-        for (int jt = 0; jt < NS; ++jt) {
+        for (int it = 0; it < NS; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(it * 32 + l32) * TSH + crow32(r, hh)] = xt[jt][it][r];
+        wave_sync();
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll 8
             for (int t = 0; t < 16 * NS; ++t) {
                 const int i = 2 * t + hh;
-                acc = mfma32(A[i * RS + dt * 32 + l32], T[i * TS + jt * 32 + l32], acc);
+                acc = mfma32(A[i * RS + dt * 32 + l32], T[i * TSH + l32], acc);
             }
             out[dt][jt] = acc;
         }
-}
-
-// accumulator tile set X^T[j][i] -> LDS image T[i][j]
-template <int NS>
-__device__ __forceinline__ void transpose_to_lds(float* T, const f32x16 (&xt)[NS][NS], int l32, int hh) {
-    constexpr int TS = 32 * NS + 1;
-#pragma unroll
-    for (int jt = 0; jt < NS; ++jt)
-#pragma unroll
-        for (int it = 0; it < NS; ++it)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T[(it * 32 + l32) * TS + jt * 32 + crow32(r, hh)] = xt[jt][it][r];
+    }
 }
 
 // out^T[dd][i] accumulator tiles -> LDS rows [i][dd].  Unconditional: the padding positions get
@@ -428,7 +426,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 template <int NS, int ND, int WPB, bool MASKED, bool COMPACT>
 __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kernel(AttnArgs a) {
     constexpr bool PF = NS == 1;      // prefetch across the compute only where registers allow
-    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = SP + 1;
+    constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = TSH;
     // the 32x32 transpose image fits inside the V region once V is dead (after dP^T): no LDS of its
     // own -> 18.7 KB per wave instead of 22.9 KB, i.e. 8 waves per CU instead of 6 (this kernel is a
     // long chain of LDS round trips, so it lives off occupancy)
@@ -526,11 +524,8 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         }
         // dV^T = dO^T P  (queries summed: P through the transpose image, which may live in the dead V
         // region); dV stays in registers until that image has also served dK
-        wave_sync();
-        transpose_to_lds<NS>(Tb, st, l32, hh);
-        wave_sync();
         f32x16 dv[ND][NS];
-        at_lds_tiles<NS, ND>(Gs, RS, Tb, l32, hh, dv);
+        at_lds_transposed<NS, ND>(Gs, RS, Tb, st, l32, hh, dv);
         // dQ^T = K^T dS^T  (keys summed: dS^T straight from registers); K is dead afterwards -> stage dQ there
         {
             f32x16 dq[ND][NS];
@@ -539,11 +534,9 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
             stage_out<NS, ND>(Ks, RS, dq, a.S, a.dk, l32, hh);
         }
         // dK^T = Q^T dS ; dO is dead -> stage dK there
-        transpose_to_lds<NS>(Tb, dp, l32, hh);
-        wave_sync();
         {
             f32x16 dkk[ND][NS];
-            at_lds_tiles<NS, ND>(Qs, RS, Tb, l32, hh, dkk);
+            at_lds_transposed<NS, ND>(Qs, RS, Tb, dp, l32, hh, dkk);
             wave_sync();
             stage_out<NS, ND>(Gs, RS, dkk, a.S, a.dk, l32, hh);
         }
@@ -646,8 +639,8 @@ size_t attention_padsum_floats() { return (size_t)(256 * 16 + 64) * 4 * PADSUM_S
 template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT>
 static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream) {
     constexpr int SP = 32 * NS, RS = 32 * ND + 4;
-    constexpr bool ALIAS = SP * (SP + 1) <= SP * RS;
-    constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : SP * (SP + 1)) + 64 + (COMPACT ? 64 + 3 * 32 * ND : 0)) : (3 * SP * RS + 64);
+    constexpr bool ALIAS = SP * 33 <= SP * RS;          // half-width transpose image: always over the V tile
+    constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : SP * 33) + 64 + (COMPACT ? 64 + 3 * 32 * ND : 0)) : (3 * SP * RS + 64);
     constexpr size_t bytes = wf * WPB * sizeof(float);
     const long total = (long)a.n_seq * a.h;
     int blocks = (int)((total + WPB - 1) / WPB);
