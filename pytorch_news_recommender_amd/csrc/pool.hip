@@ -191,20 +191,29 @@ __global__ __launch_bounds__(64 * ROWS_WPB) void addattn_bwd_rows_kernel(
     if (qok) *reinterpret_cast<f32x4*>(dq_partial + gw * q + 4 * lane) = dq;
 }
 
-__global__ __launch_bounds__(256) void colsum_add_kernel(const float* partial, int rows, int cols, float* out) {
-    // one block per 16 columns: 16 row-groups x 16 columns per pass keep 16 loads per column in flight
-    __shared__ float red[16][17];
+__global__ __launch_bounds__(1024) void colsum_add_kernel(const float* partial, int rows, int cols, float* out) {
+    // one block per 16 columns: 64 row-groups x 16 columns, 4 independent loads per thread in flight (the column
+    // count is small -- q = 200 gives 13 blocks -- so the kernel lives off memory-level parallelism per CU)
+    __shared__ float red[64][17];
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = rg; r < rows; r += 16) s += partial[(long)r * cols + c];
-    red[rg][cl] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int r = rg;
+        for (; r + 192 < rows; r += 256) {
+            s0 += partial[(long)r * cols + c];
+            s1 += partial[(long)(r + 64) * cols + c];
+            s2 += partial[(long)(r + 128) * cols + c];
+            s3 += partial[(long)(r + 192) * cols + c];
+        }
+        for (; r < rows; r += 64) s0 += partial[(long)r * cols + c];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && c < cols) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        for (int i = 0; i < 64; ++i) t += red[i][cl];
         out[c] += t;
     }
 }
@@ -229,7 +238,7 @@ int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, co
         if (rc) return rc;
     }
     TimingScope ts("colsum_add", stream);
-    hipLaunchKernelGGL(colsum_add_kernel, dim3(cdiv(q, 16)), dim3(256), 0, stream, dq_partial, waves, q, dq);
+    hipLaunchKernelGGL(colsum_add_kernel, dim3(cdiv(q, 16)), dim3(1024), 0, stream, dq_partial, waves, q, dq);
     return check_launch("colsum_add");
 }
 
