@@ -713,8 +713,19 @@ __global__ void tnb_reduce_kernel(const float* partial, int splits, int N, int K
     const long total = (long)N * (K + 1);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long n = idx / (K + 1), k = idx - n * (K + 1);
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += partial[(long)sp * n_pad * k_pad + n * k_pad + k];
+        // fixed summation order, four independent partial sums so that four slab reads are in flight
+        const float* pp = partial + n * k_pad + k;
+        const long slab = n_pad * k_pad;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 3 < splits; sp += 4) {
+            s0 += pp[(long)sp * slab];
+            s1 += pp[(long)(sp + 1) * slab];
+            s2 += pp[(long)(sp + 2) * slab];
+            s3 += pp[(long)(sp + 3) * slab];
+        }
+        for (; sp < splits; ++sp) s0 += pp[(long)sp * slab];
+        const float s = (s0 + s1) + (s2 + s3);
         const long nd = perm.src((int)n);
         if (k < K) dW[nd * K + k] += s;
         else if (dbias != nullptr) dbias[nd] += s;
