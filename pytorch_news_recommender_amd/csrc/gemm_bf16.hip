@@ -393,20 +393,27 @@ __global__ __launch_bounds__(BF_THREADS, 2) void addattn_fwd_bf16_kernel(AddFwdA
                                  reinterpret_cast<float*>(smem) + wave * 8 * (16 * NT + 8));
     }
     __syncthreads();
+    // softmax over each sequence: one 64-lane wave per sequence, a lane per position (S <= 64), reductions by
+    // shuffles (the first version let `spb` single threads walk their sequences serially while 500 others idled)
     const int spb = rows_valid / a.S;
-    if (tid < spb) {
-        float* s = sc + tid * a.S;
-        if (a.mask != nullptr)
-            for (int i = 0; i < a.S; ++i)
-                if (a.mask[(long)row0 + tid * a.S + i] == 0) s[i] = -1e9f;
-        float mx = -1e30f;
-        for (int i = 0; i < a.S; ++i) mx = fmaxf(mx, s[i]);
-        float sum = 0.f;
-        for (int i = 0; i < a.S; ++i) { const float e = expf(s[i] - mx); s[i] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int i = 0; i < a.S; ++i) {
-            s[i] *= inv;
-            if (a.wout != nullptr) a.wout[(long)row0 + tid * a.S + i] = s[i];
+    for (int sq = wave; sq < spb; sq += BF_THREADS / 64) {
+        float* sp = sc + sq * a.S;
+        float v = -1e30f;
+        if (lane < a.S) {
+            v = sp[lane];
+            if (a.mask != nullptr && a.mask[(long)row0 + sq * a.S + lane] == 0) v = -1e9f;
+        }
+        float mx = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float e = lane < a.S ? expf(v - mx) : 0.f;
+        float sum = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float w = e / sum;
+        if (lane < a.S) {
+            sp[lane] = w;
+            if (a.wout != nullptr) a.wout[(long)row0 + sq * a.S + lane] = w;
         }
     }
     __syncthreads();
@@ -415,9 +422,14 @@ __global__ __launch_bounds__(BF_THREADS, 2) void addattn_fwd_bf16_kernel(AddFwdA
         const int sq = idx / (a.d / 4), c4 = idx - sq * (a.d / 4);
         const float* crow = g.A + ((long)row0 + sq * a.S) * g.lda + 4 * c4;
         const float* w = sc + sq * a.S;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < a.S; ++i) o += w[i] * *reinterpret_cast<const f32x4*>(crow + (long)i * g.lda);
-        *reinterpret_cast<f32x4*>(a.out + (seq0 + sq) * a.d + 4 * c4) = o;
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+        int i = 0;
+        for (; i + 1 < a.S; i += 2) {               // two independent row loads per trip (L2-resident tile)
+            o0 += w[i] * *reinterpret_cast<const f32x4*>(crow + (long)i * g.lda);
+            o1 += w[i + 1] * *reinterpret_cast<const f32x4*>(crow + (long)(i + 1) * g.lda);
+        }
+        if (i < a.S) o0 += w[i] * *reinterpret_cast<const f32x4*>(crow + (long)i * g.lda);
+        *reinterpret_cast<f32x4*>(a.out + (seq0 + sq) * a.d + 4 * c4) = o0 + o1;
     }
 }
 
