@@ -64,20 +64,26 @@ __global__ __launch_bounds__(256, 2) void addattn_fwd_kernel(AddFwdArgs a) {
         nt_epilogue<NT, E_STORE>(tg, acc, row0, rows_valid, 0, wave, lane, lds + wave * 8 * (16 * NT + 8));
     }
     __syncthreads();
+    // softmax over each sequence: one wave per sequence, a lane per position (see addattn_fwd_bf16_kernel)
     const int spb = rows_valid / a.S;
-    if (tid < spb) {
-        float* s = sc + tid * a.S;
-        if (a.mask != nullptr)
-            for (int i = 0; i < a.S; ++i)
-                if (a.mask[(long)row0 + tid * a.S + i] == 0) s[i] = -1e9f;
-        float mx = -1e30f;
-        for (int i = 0; i < a.S; ++i) mx = fmaxf(mx, s[i]);
-        float sum = 0.f;
-        for (int i = 0; i < a.S; ++i) { const float e = expf(s[i] - mx); s[i] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int i = 0; i < a.S; ++i) {
-            s[i] *= inv;
-            if (a.wout != nullptr) a.wout[(long)row0 + tid * a.S + i] = s[i];
+    for (int sq = wave; sq < spb; sq += 4) {
+        float* sp = sc + sq * a.S;
+        float v = -1e30f;
+        if (lane < a.S) {
+            v = sp[lane];
+            if (a.mask != nullptr && a.mask[(long)row0 + sq * a.S + lane] == 0) v = -1e9f;
+        }
+        float mx = v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float e = lane < a.S ? expf(v - mx) : 0.f;
+        float sum = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float w = e / sum;
+        if (lane < a.S) {
+            sp[lane] = w;
+            if (a.wout != nullptr) a.wout[(long)row0 + sq * a.S + lane] = w;
         }
     }
     __syncthreads();
