@@ -25,11 +25,12 @@ __global__ __launch_bounds__(256) void gather_dropout_kernel(unsigned total4, un
 __global__ __launch_bounds__(256) void gather_dropout_compact_kernel(unsigned d4, const int64_t* ids, const int* live,
                                                                      const int* n_live, const float* table, Dropout drop,
                                                                      float* x) {
-    const unsigned long total4 = (unsigned long)(*n_live) * d4;
-    const unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
-    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        const unsigned long r = i / d4;
-        const unsigned c4 = (unsigned)(i - r * d4);
+    // 32-bit index arithmetic (the launcher checks M * d/4 < 2^32): a 64-bit division per element costs as
+    // much as the Philox call
+    const unsigned total4 = (unsigned)(*n_live) * d4;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const unsigned r = i / d4, c4 = i - r * d4;
         const long t = live[r];
         f32x4 v = *reinterpret_cast<const f32x4*>(table + ids[t] * (long)(4 * d4) + 4 * c4);
         if (drop.thresh != 0u) v *= dropout_scale4(drop.seed, 0u, (uint64_t)(t * d4 + c4), drop.thresh, drop.inv_keep);
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void gather_dropout_compact_kernel(unsigned d4
 int launch_gather_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live,
                                   const float* table, const Dropout& drop, float* x, hipStream_t stream) {
     if (M <= 0) return NRMS_OK;
+    if (M * (d / 4) >= (1L << 32)) { set_error("gather: %ld float4 elements overflow the 32-bit index", M * (d / 4)); return NRMS_EINVAL; }
     int blocks = cdiv(M * (d / 4), 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     TimingScope ts("gather_dropout", stream);
@@ -199,13 +201,15 @@ int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* pos, in
 }
 
 // dtable[ids[t], :] += dx[r, :] * keep(t, :) / (1 - p) for the compact rows r < *n_live, t = live[r].
+template <typename IDX>
 __global__ __launch_bounds__(256) void scatter_dropout_compact_kernel(unsigned d, const int64_t* ids, const int* live,
                                                                       const int* n_live, const float* dx, Dropout drop,
                                                                       float* dtable) {
-    const unsigned long total = (unsigned long)(*n_live) * d;
-    const unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
-    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const unsigned long r = i / d;
+    // IDX = unsigned where M * d < 2^32 (a 64-bit division per element costs as much as the Philox call)
+    const IDX total = (IDX)(*n_live) * d;
+    const IDX stride = (IDX)gridDim.x * blockDim.x;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const IDX r = i / d;
         const unsigned c = (unsigned)(i - r * d);
         const long t = live[r];
         const long id = ids[t];
@@ -221,8 +225,12 @@ int launch_scatter_dropout_compact(long M, int d, const int64_t* ids, const int*
     int blocks = cdiv(M * d, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     TimingScope ts("scatter_dropout", stream);
-    hipLaunchKernelGGL(scatter_dropout_compact_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)d, ids, live, n_live,
-                       dx, drop, dtable);
+    if (M * d < (1L << 32))
+        hipLaunchKernelGGL(scatter_dropout_compact_kernel<unsigned>, dim3(blocks), dim3(256), 0, stream, (unsigned)d, ids,
+                           live, n_live, dx, drop, dtable);
+    else
+        hipLaunchKernelGGL(scatter_dropout_compact_kernel<unsigned long>, dim3(blocks), dim3(256), 0, stream, (unsigned)d, ids,
+                           live, n_live, dx, drop, dtable);
     return check_launch("scatter_dropout");
 }
 
