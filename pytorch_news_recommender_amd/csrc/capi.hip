@@ -114,7 +114,7 @@ static size_t wplane_bytes(const nrms_encoder_desc* d) {
 }
 
 struct BwdWorkspace {
-    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, live, pos, n_live, cscr, padsum, total;   // byte offsets
+    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, live, pos, n_live, cscr, padsum, sscr, total;   // byte offsets
 };
 
 static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
@@ -141,6 +141,7 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     w.n_live = take(d->vocab > 0 ? 64 : 0);
     w.cscr = take(d->vocab > 0 ? compact_scratch_ints((long)M) : 0);
     w.padsum = take(pz ? attention_padsum_floats() : 0);
+    w.sscr = take(d->vocab > 0 ? scatter_grouped_scratch_ints((long)M, d->vocab) : 0);
     w.total = off;
     return w;
 }
@@ -410,7 +411,12 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "dx_bwd");
         if (rc) return rc;
     }
-    if (gather) rc = launch_scatter_dropout_compact((long)M, d, ids, live, n_live, dctx, drop_e, grads->table, s);
+    if (gather) {
+        static const bool atomic_scatter = getenv("NRMS_ATOMIC_SCATTER") != nullptr;      // A/B switch
+        if (atomic_scatter) rc = launch_scatter_dropout_compact((long)M, d, ids, live, n_live, dctx, drop_e, grads->table, s);
+        else rc = launch_scatter_grouped((long)M, desc->vocab, d, ids, live, n_live, dctx, drop_e, grads->table,
+                                         (int*)(base + L.sscr), s);
+    }
     return rc;
 }
 

@@ -50,24 +50,6 @@ int launch_gather_dropout_compact(long M, int d, const int64_t* ids, const int* 
     return check_launch("gather_dropout");
 }
 
-// dtable[ids[m], :] += dx[m, :] * keep(m, :) / (1 - p), rows with id 0 skipped (padding_idx).
-// One float per lane so that a wave-instruction adds 256 contiguous bytes of one table row (the
-// shape global_atomic_add_f32 runs at full rate on gfx950); float atomics are order-dependent in
-// the last bits, as any parallel reduction of the reference's dense gradient would be.
-__global__ __launch_bounds__(256) void scatter_dropout_kernel(unsigned long total, unsigned d, const int64_t* ids,
-                                                              const float* dx, Dropout drop, float* dtable) {
-    const unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
-    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const unsigned long m = i / d;
-        const unsigned c = (unsigned)(i - m * d);
-        const long id = ids[m];
-        if (id == 0) continue;
-        float v = dx[i];
-        if (drop.thresh != 0u) v *= dropout_scale1(drop.seed, 0u, (uint64_t)i, drop.thresh, drop.inv_keep);
-        atomicAdd(dtable + id * (long)d + c, v);
-    }
-}
-
 // qkv[m, :] = bias for padding tokens: with an all-zero embedding row 0 their x row is exactly zero
 // (also under dropout), so the projection of a padding token IS the bias and the GEMM skips them.
 constexpr int FILL_SLICES = 6;          // 64 lanes x 6 float4 = 1536 floats >= 3 d_model (d_model <= 512)
@@ -234,6 +216,122 @@ int launch_scatter_dropout_compact(long M, int d, const int64_t* ids, const int*
     return check_launch("scatter_dropout");
 }
 
+// ---------------------------------------------------------------------------------------
+// Grouped scatter: the live tokens are bucketed by word id (histogram -> exclusive scan -> placement), then one
+// wave per vocabulary row sums the dX rows of its bucket and adds the result to the table gradient with plain
+// stores.  Against the atomic scatter: no float atomics at all (the 88 M of them were its bound), one Philox
+// call per float4 instead of per float, and every table-gradient row is written exactly once.
+__global__ __launch_bounds__(256) void tok_hist_kernel(const int64_t* ids, const int* live, const int* n_live, int* cnt) {
+    const int n = *n_live;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
+        atomicAdd(cnt + ids[live[r]], 1);
+}
+
+// exclusive scan of n ints in place, two small kernels: block-local scans of 1024 elements + block totals, then
+// every block adds the sum of the totals before it (n / 1024 <= a few dozen blocks; a single-block version took 73 us)
+__global__ __launch_bounds__(1024) void scan_local_kernel(int n, int* data, int* bsum) {
+    __shared__ int buf[1024];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int v = i < n ? data[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (i < n) data[i] = buf[threadIdx.x] - v;
+    if (threadIdx.x == 1023) bsum[blockIdx.x] = buf[1023];
+}
+
+__global__ __launch_bounds__(1024) void scan_add_kernel(int n, int n_blocks, int* data, const int* bsum, int* total) {
+    __shared__ int base;
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int b = 0; b < (int)blockIdx.x; ++b) s += bsum[b];
+        base = s;
+        if (blockIdx.x == n_blocks - 1) *total = s + bsum[blockIdx.x];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) data[i] += base;
+}
+
+__global__ __launch_bounds__(256) void tok_place_kernel(const int64_t* ids, const int* live, const int* n_live,
+                                                        const int* offs, int* cursor, int* order) {
+    const int n = *n_live;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const long id = ids[live[r]];
+        order[offs[id] + atomicAdd(cursor + id, 1)] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_grouped_kernel(int V, int d4, const int* live, const int* offs,
+                                                              const int* total, const int* order, const float* dx,
+                                                              Dropout drop, float* dtable) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V || v == 0) return;                                   // id 0 = padding: no gradient
+    const int beg = offs[v], end = v + 1 < V ? offs[v + 1] : *total;
+    if (beg == end) return;
+    // a lane owns float4 columns lane, lane + 64, ... (SL slices): ONE pass over the bucket, all slices of a
+    // token's row loaded together (a pass per slice doubled the dependent order -> row load chain)
+    constexpr int SL = 2;                          // d_model <= 512 -> d4 <= 128
+    f32x4 s[SL];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int k = beg; k < end; ++k) {
+        const int r = order[k];
+        const long t = live[r];
+#pragma unroll
+        for (int j = 0; j < SL; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 < d4) {
+                f32x4 g = *reinterpret_cast<const f32x4*>(dx + ((long)r * d4 + c4) * 4);
+                if (drop.thresh != 0u) g *= dropout_scale4(drop.seed, 0u, (uint64_t)(t * d4 + c4), drop.thresh, drop.inv_keep);
+                s[j] += g;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < d4) *reinterpret_cast<f32x4*>(dtable + ((long)v * d4 + c4) * 4) += s[j];
+    }
+}
+
+size_t scatter_grouped_scratch_ints(long M, int V) { return (size_t)2 * (V + 64) + (size_t)M + 64; }
+
+// scratch: scatter_grouped_scratch_ints(M, V) ints.  dx is compact (row r belongs to token live[r]).
+int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
+                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream) {
+    if (M <= 0) return NRMS_OK;
+    int* cnt = scratch;                       // [V] counts -> exclusive offsets (in place)
+    int* cursor = cnt + V + 64;               // [V]
+    int* total = cursor + V;                  // [1]
+    int* order = cursor + V + 64;             // [M]
+    if (hipMemsetAsync(cnt, 0, (size_t)(2 * (V + 64)) * sizeof(int), stream) != hipSuccess) {
+        set_error("scatter_grouped: memset failed");
+        return NRMS_ELAUNCH;
+    }
+    int blocks = cdiv(M, 256);
+    if (blocks > 2048) blocks = 2048;
+    TimingScope ts("scatter_dropout", stream);
+    hipLaunchKernelGGL(tok_hist_kernel, dim3(blocks), dim3(256), 0, stream, ids, live, n_live, cnt);
+    {
+        const int nb = cdiv(V, 1024);
+        int* bsum = order;                    // [nb] block totals: the bucket array is free until the placement
+        hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(1024), 0, stream, V, cnt, bsum);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(1024), 0, stream, V, nb, cnt, bsum, total);
+    }
+    hipLaunchKernelGGL(tok_place_kernel, dim3(blocks), dim3(256), 0, stream, ids, live, n_live, cnt, cursor, order);
+    hipLaunchKernelGGL(scatter_grouped_kernel, dim3(cdiv(V, 4)), dim3(256), 0, stream, V, d / 4, live, cnt, total, order, dx,
+                       drop, dtable);
+    return check_launch("scatter_grouped");
+}
+
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,
                           hipStream_t stream) {
     if (M <= 0) return NRMS_OK;
@@ -245,18 +343,6 @@ int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table,
     hipLaunchKernelGGL(gather_dropout_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)total4, (unsigned)(d / 4),
                        ids, table, drop, x);
     return check_launch("gather_dropout");
-}
-
-int launch_scatter_dropout(long M, int d, const int64_t* ids, const float* dx, const Dropout& drop, float* dtable,
-                           hipStream_t stream) {
-    if (M <= 0) return NRMS_OK;
-    const long total = M * d;
-    int blocks = cdiv(total, 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    TimingScope ts("scatter_dropout", stream);
-    hipLaunchKernelGGL(scatter_dropout_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned long)total, (unsigned)d,
-                       ids, dx, drop, dtable);
-    return check_launch("scatter_dropout");
 }
 
 }  // namespace nrms

@@ -323,8 +323,6 @@ int launch_addattn_fwd_bf16(int npass, const AddFwdArgs& a, void* wplanes, hipSt
 // embed.hip
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,
                           hipStream_t stream);
-int launch_scatter_dropout(long M, int d, const int64_t* ids, const float* dx, const Dropout& drop, float* dtable,
-                           hipStream_t stream);
 // x[r, :] = table[ids[live[r]], :] * keep(live[r], :) / (1 - p) for the compact rows r < *n_live
 int launch_gather_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live,
                                   const float* table, const Dropout& drop, float* x, hipStream_t stream);
@@ -337,6 +335,10 @@ int launch_fill_pad_rows(long n_seq, int S, int n, const int64_t* ids, const flo
 size_t compact_scratch_ints(long M);
 int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* pos, int* n_live, int* scratch,
                              hipStream_t stream);
+// grouped (atomic-free) scatter of a COMPACT dx; scratch: scatter_grouped_scratch_ints(M, V) ints
+size_t scatter_grouped_scratch_ints(long M, int V);
+int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
+                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream);
 // same as launch_scatter_dropout for a COMPACT dx: row r of dx belongs to token live[r], r < *n_live
 int launch_scatter_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
                                    const Dropout& drop, float* dtable, hipStream_t stream);
