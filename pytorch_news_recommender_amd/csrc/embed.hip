@@ -281,9 +281,7 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(int V, int d4, con
     f32x4 s[SL];
 #pragma unroll
     for (int j = 0; j < SL; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int k = beg; k < end; ++k) {
-        const int r = order[k];
+    auto add_row = [&](int r) {
         const long t = live[r];
 #pragma unroll
         for (int j = 0; j < SL; ++j) {
@@ -293,6 +291,21 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(int V, int d4, con
                 if (drop.thresh != 0u) g *= dropout_scale4(drop.seed, 0u, (uint64_t)(t * d4 + c4), drop.thresh, drop.inv_keep);
                 s[j] += g;
             }
+        }
+    };
+    // The placement fills a bucket in whatever order its atomics resolve.  Each 64-entry chunk of the bucket is
+    // therefore consumed in ASCENDING row order (wave-wide minimum selection): a word that occurs at most 64
+    // times in the step -- all of them in practice outside a handful of stop words -- gets a bit-reproducible
+    // gradient row; longer buckets are reproducible up to the order of their chunks.
+    for (int k0 = beg; k0 < end; k0 += 64) {
+        const int n = min(64, end - k0);
+        int mine = lane < n ? order[k0 + lane] : 0x7fffffff;
+        for (int i = 0; i < n; ++i) {
+            int m = mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+            add_row(m);
+            if (mine == m) mine = 0x7fffffff;
         }
     }
 #pragma unroll
