@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--users-per-gpu", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-padding", action="store_true",
+                    help="diagnostics: process padding tokens densely (as if embedding row 0 were not zero)")
     ap.add_argument("--cpu-sample-users", type=int, default=64)
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
                     help="bf16x3 (default) is the fastest mode inside the 1e-4 score-parity bar (measured 5e-7); "
@@ -153,6 +155,7 @@ def main():
     cfg.dropout = 0.2
     cfg.learning_rate = 1e-3
     cfg.precision = args.precision
+    cfg.skip_padding_tokens = not args.dense_padding
     cfg.word_embed_size = shape.word_embed_size
     params = synth.make_params(shape, seed=0)
     model = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
