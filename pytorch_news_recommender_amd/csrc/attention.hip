@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void padsum_reduce_kernel(const float* padsum,
     if (lane == 0) dbias[perm.src(np)] += s;
 }
 
-size_t attention_padsum_floats() { return (size_t)(256 * 16 + 64) * 4 * PADSUM_STRIDE; }
+size_t attention_padsum_floats() { return (size_t)(256 * 16 + 256) * 4 * PADSUM_STRIDE; }   // grid cap + up to n_heads - 1 extra blocks, 4 waves each
 
 template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT>
 static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream) {
