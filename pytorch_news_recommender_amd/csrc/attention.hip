@@ -392,23 +392,54 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
         }
         wave_sync();
 
-        // coalesced-as-possible store of ctx[seq*S + r][head*dk + c], dropout site 1
-        constexpr int LPR = 16 * ND, RPI = 64 / LPR;
-        const int c2 = lane % LPR, rsub = lane / LPR;
-        if (2 * c2 < a.dk) {
-            for (int r = rsub; r < a.S; r += RPI) {
-                float2 v = *reinterpret_cast<const float2*>(Qs + r * RS + 2 * c2);
+        // store of ctx[seq*S + r][head*dk + c] through dropout site 1
+        if (ND == 1) {
+            // One lane per Philox GROUP (4 consecutive elements of the flat [M, d] index, 16-byte aligned in the
+            // ctx row): 8 groups cover a head's <= 32 columns, 8 rows per wave-instruction.  A lane makes ONE
+            // Philox call for its four elements and stores them as one float4 (the head's first / last group may
+            // be half outside the head: then a float2) -- half the Philox calls and half the store instructions
+            // of a float2-per-lane loop.
+            const int gi = lane & 7, rsub = lane >> 3;
+            const int hb = head * a.dk;
+            const int o0 = hb & 3;                                   // 0 or 2 (d_k is even, d % 4 == 0)
+            const int clo = 4 * gi - o0, chi = clo + 2;              // head-relative columns of the two float2 halves
+            const bool vlo = clo >= 0 && clo < a.dk, vhi = chi < a.dk;
+            for (int r = rsub; r < a.S; r += 8) {
                 const long m = seq * a.S + r;
-                const int col = head * a.dk + 2 * c2;
+                float2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+                if (vlo) lo = *reinterpret_cast<const float2*>(Qs + r * RS + clo);
+                if (vhi) hi = *reinterpret_cast<const float2*>(Qs + r * RS + chi);
                 if (a.drop.thresh != 0u) {
                     uint32_t rnd[4];
-                    const uint64_t e = (uint64_t)(m * a.d + col);
-                    philox4x32_7(a.drop.seed, e >> 2, 1u, rnd);
-                    const int q = (int)(e & 3);          // 0 or 2: col is even
-                    v.x = (q == 0 ? rnd[0] : rnd[2]) >= a.drop.thresh ? v.x * a.drop.inv_keep : 0.f;
-                    v.y = (q == 0 ? rnd[1] : rnd[3]) >= a.drop.thresh ? v.y * a.drop.inv_keep : 0.f;
+                    philox4x32_7(a.drop.seed, (uint64_t)(m * a.d + hb + clo) >> 2, 1u, rnd);
+                    lo.x = rnd[0] >= a.drop.thresh ? lo.x * a.drop.inv_keep : 0.f;
+                    lo.y = rnd[1] >= a.drop.thresh ? lo.y * a.drop.inv_keep : 0.f;
+                    hi.x = rnd[2] >= a.drop.thresh ? hi.x * a.drop.inv_keep : 0.f;
+                    hi.y = rnd[3] >= a.drop.thresh ? hi.y * a.drop.inv_keep : 0.f;
                 }
-                *reinterpret_cast<float2*>(a.ctx + m * a.d + col) = v;
+                float* o = a.ctx + m * a.d + hb + clo;
+                if (vlo && vhi) *reinterpret_cast<f32x4*>(o) = f32x4{lo.x, lo.y, hi.x, hi.y};
+                else if (vlo) *reinterpret_cast<float2*>(o) = lo;
+                else if (vhi) *reinterpret_cast<float2*>(o + 2) = hi;
+            }
+        } else {
+            constexpr int LPR = 16 * ND, RPI = 64 / LPR;
+            const int c2 = lane % LPR, rsub = lane / LPR;
+            if (2 * c2 < a.dk) {
+                for (int r = rsub; r < a.S; r += RPI) {
+                    float2 v = *reinterpret_cast<const float2*>(Qs + r * RS + 2 * c2);
+                    const long m = seq * a.S + r;
+                    const int col = head * a.dk + 2 * c2;
+                    if (a.drop.thresh != 0u) {
+                        uint32_t rnd[4];
+                        const uint64_t e = (uint64_t)(m * a.d + col);
+                        philox4x32_7(a.drop.seed, e >> 2, 1u, rnd);
+                        const int q = (int)(e & 3);          // 0 or 2: col is even
+                        v.x = (q == 0 ? rnd[0] : rnd[2]) >= a.drop.thresh ? v.x * a.drop.inv_keep : 0.f;
+                        v.y = (q == 0 ? rnd[1] : rnd[3]) >= a.drop.thresh ? v.y * a.drop.inv_keep : 0.f;
+                    }
+                    *reinterpret_cast<float2*>(a.ctx + m * a.d + col) = v;
+                }
             }
         }
         wave_sync();
