@@ -38,6 +38,13 @@ extern "C" {
                                    v_mfma_f32_16x16x32_bf16, fp32 accumulate (~2^-16 relative per product);
                                    attention, softmaxes, pooling, loss, optimizer and all HBM tensors stay fp32 */
 #define NRMS_PRECISION_BF16   2 /* same kernels, hi*hi only: plain bf16 inputs, fp32 accumulate */
+#define NRMS_PRECISION_FP16   3 /* fused path: one wavefront per sequence, every contraction on v_mfma_f32_32x32x16_f16
+                                   (fp16 operands: 11 significant bits, fp32 accumulate), Q/K/V, attention probabilities
+                                   and tanh(.) register-resident, activations kept for the backward in fp16.
+                                   Restrictions: seq_len <= 32, d_model <= 320, d_k <= 32, n_heads <= 10, q_dim <= 224,
+                                   no output projection, no masks (NRMS_EINVAL otherwise).  Activation buffers change
+                                   meaning (see nrms_encoder_acts); context-dropout counters run over the padded
+                                   [M, 32 n_heads] layout (nrms_dropout_keep_mask with d = 32 n_heads). */
 
 /* nrms_encoder_desc.flags */
 /* The caller guarantees that row 0 of `table` (the padding row, nn.Embedding padding_idx=0,
@@ -117,6 +124,9 @@ typedef struct nrms_encoder_acts {
     float* w;              /* [M]      additive-attention softmax weights (nrms_v0.py:110-112) */
     void*  scratch;        /* nrms_encoder_fwd_scratch_bytes(desc) bytes: head-major W_qkv copy, bf16 weight planes,
                               token compaction lists */
+    /* NRMS_PRECISION_FP16: x, ctx, t hold fp16 with padded pitches KP = 32 ceil(d/32), DP = 32 n_heads,
+     * QP = 32 ceil(q/32):  x [M, KP] (required for both encoders: gathered embeddings / the cast input),
+     * ctx [M, DP] (head-padded, internal order), t [M, QP]; w [M] fp32; qkv and attn are unused (may be NULL). */
 } nrms_encoder_acts;
 
 /* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V
@@ -144,6 +154,19 @@ int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* 
 int nrms_encoder_bwd_wqkv(const nrms_encoder_desc* desc, const int64_t* ids, const float* x,
                           const nrms_encoder_acts* acts, const nrms_encoder_grads* grads,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Word ids must lie in [0, vocab) before they reach nrms_encoder_fwd / _bwd: the kernels index the table, the
+ * token histogram and the placement lists with the raw id.  nn.Embedding raises on an out-of-range index
+ * (nrms_v0.py:134-139,166); this is the device-side counterpart for untrusted input:
+ * dst[i] = src[i] if 0 <= src[i] < vocab, else 0 (the padding id); *n_bad += number of ids replaced
+ * (device int32 the caller zeroes and reads back when it chooses to synchronise).  dst may alias src. */
+int nrms_sanitize_ids(const int64_t* src, int64_t* dst, int64_t n, int32_t vocab, int32_t* n_bad, void* stream);
+
+/* Evaluation encodes every DISTINCT title once (get_news_vector, nrms_v0.py:278-289, is the reference's hook for
+ * caching news vectors; an impression padded to max_candidate_size = 300 slots, data_handler.py:174-177, is mostly
+ * padding and repeats).  keys[t] = 64-bit hash of the seq_len word ids of title t: equal titles have equal keys;
+ * the caller groups by key and verifies its representatives (a collision costs a re-run, not correctness). */
+int nrms_title_keys(const int64_t* ids, int64_t n_titles, int32_t seq_len, int64_t* keys, void* stream);
 
 /* Click scores: bmm(cand [B,C,d], user [B,d,1]) then masked_fill(mask==0, -1e9)
  * (DotProductClickPredictor, nrms_v0.py:205-216; mask nrms_v0.py:272-274).  mask may be NULL. */

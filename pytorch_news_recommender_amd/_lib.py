@@ -16,7 +16,8 @@ NRMS_FLAG_DEFER_WQKV = 2
 NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1
 NRMS_PRECISION_BF16 = 2
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+NRMS_PRECISION_FP16 = 3
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 
 
 class NrmsError(RuntimeError):
@@ -57,6 +58,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "nrms_encoder_bwd_wqkv": (C.c_int, [C.POINTER(EncoderDesc), C.c_void_p, C.c_void_p, C.POINTER(EncoderActs),
                                         C.POINTER(EncoderGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nrms_sanitize_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "nrms_title_keys": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "nrms_click_score_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "nrms_click_score_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

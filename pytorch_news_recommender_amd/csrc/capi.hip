@@ -82,8 +82,15 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d->p_drop_embed >= 0.f && d->p_drop_embed < 1.f && d->p_drop_ctx >= 0.f && d->p_drop_ctx < 1.f,
                  "%s: dropout probabilities must be in [0,1)", who);
     NRMS_REQUIRE(d->vocab > 0 || d->p_drop_embed == 0.f, "%s: embedding dropout needs the news encoder (vocab>0)", who);
-    NRMS_REQUIRE(d->precision >= NRMS_PRECISION_FP32 && d->precision <= NRMS_PRECISION_BF16,
+    NRMS_REQUIRE(d->precision >= NRMS_PRECISION_FP32 && d->precision <= NRMS_PRECISION_FP16,
                  "%s: unsupported precision %d", who, d->precision);
+    if (d->precision == NRMS_PRECISION_FP16) {
+        const char* why = nullptr;
+        NRMS_REQUIRE(fused16_supported(d->seq_len, d->d_model, d->n_heads, d->q_dim, &why),
+                     "%s: precision fp16 needs %s (use bf16x3 for this shape)", who, why);
+        NRMS_REQUIRE(d->use_output_proj == 0 && d->mask_mode == 0,
+                     "%s: precision fp16 supports neither the output projection nor masks (use bf16x3)", who);
+    }
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
     NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV)) == 0, "%s: unknown flags 0x%x", who, d->flags);
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
@@ -103,7 +110,7 @@ static int tn_gemm(const nrms_encoder_desc* d, const TNArgs& t, hipStream_t s, c
 }
 
 static size_t wplane_bytes(const nrms_encoder_desc* d) {
-    if (d->precision == NRMS_PRECISION_FP32) return 0;
+    if (d->precision == NRMS_PRECISION_FP32 || d->precision == NRMS_PRECISION_FP16) return 0;
     const int dm = d->d_model, q = d->q_dim;
     size_t m = gemm_nt_bf16_wplane_bytes(3 * dm, dm);                    // QKV
     const size_t a = gemm_nt_bf16_wplane_bytes(dm, 3 * dm);             // dX
@@ -166,11 +173,71 @@ static FwdScratch fwd_scratch(const nrms_encoder_desc* d) {
     return f;
 }
 
+// ---- fp16 mode: planes | live | pos | n_live | compaction scratch
+struct Fwd16Scratch { size_t planes, live, pos, n_live, cscr, total; };
+static Fwd16Scratch fwd16_scratch(const nrms_encoder_desc* d) {
+    Fwd16Scratch f;
+    const size_t M = (size_t)d->n_seq * d->seq_len;
+    const bool gather = d->vocab > 0;
+    f.planes = 0;
+    f.live = align_up(fused16_layout(d->d_model, d->n_heads, d->q_dim).total, 256);
+    f.pos = f.live + (gather ? align_up(M * sizeof(int), 256) : 0);
+    f.n_live = f.pos + (gather ? align_up(M * sizeof(int), 256) : 0);
+    f.cscr = f.n_live + (gather ? 256 : 0);
+    f.total = f.cscr + (gather ? align_up(compact_scratch_ints((long)M) * sizeof(int), 256) : 0);
+    return f;
+}
+
+static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids, const float* x,
+                         const nrms_encoder_acts* acts, float* out, hipStream_t s) {
+    const bool gather = desc->vocab > 0;
+    NRMS_REQUIRE(acts->x && acts->ctx && acts->scratch, "encoder_fwd(fp16): acts.x, acts.ctx and acts.scratch are required");
+    const int S = desc->seq_len, d = desc->d_model, h = desc->n_heads, q = desc->q_dim;
+    const long M = (long)desc->n_seq * S;
+    const Fwd16Scratch fs = fwd16_scratch(desc);
+    const Fused16Layout L = fused16_layout(d, h, q);
+    char* base = (char*)acts->scratch;
+    int rc = launch_prep16(d, h, q, w->w_qkv, w->b_qkv, w->w_add, w->b_add, w->q_vec, base + fs.planes, s);
+    if (rc) return rc;
+    Fused16Fwd f{};
+    f.n_seq = desc->n_seq; f.S = S; f.d = d; f.h = h; f.q = q;
+    f.planes = base + fs.planes; f.x16 = acts->x; f.ctx16 = acts->ctx; f.t16 = acts->t; f.w = acts->w; f.out = out;
+    f.drop = make_dropout(desc->seed, desc->p_drop_ctx);
+    if (gather) {
+        const Dropout drop_e = make_dropout(desc->seed, desc->p_drop_embed);
+        if (skip_pad_rows(desc)) {
+            int* live = (int*)(base + fs.live);
+            int* pos = (int*)(base + fs.pos);
+            int* n_live = (int*)(base + fs.n_live);
+            rc = launch_compact_live_rows(M, ids, live, pos, n_live, (int*)(base + fs.cscr), s);
+            if (rc) return rc;
+            rc = launch_gather16(M, d, L.KP, ids, live, n_live, w->table, drop_e, acts->x, s);
+            if (rc) return rc;
+            f.pos = pos;
+            f.ids = ids;
+        } else {
+            rc = launch_gather16(M, d, L.KP, ids, nullptr, nullptr, w->table, drop_e, acts->x, s);
+            if (rc) return rc;
+        }
+    } else {
+        rc = launch_cast16(M, d, L.KP, x, acts->x, s);
+        if (rc) return rc;
+    }
+    return launch_fused_fwd16(f, s);
+}
+
 extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
                                 const float* x, const uint8_t* mask, const nrms_encoder_acts* acts, float* out,
                                 void* stream) {
     int rc = validate_desc(desc, "encoder_fwd");
     if (rc) return rc;
+    if (desc->precision == NRMS_PRECISION_FP16) {
+        NRMS_REQUIRE(w && acts && out, "encoder_fwd: null argument");
+        NRMS_REQUIRE(w->w_qkv && w->b_qkv && w->w_add && w->b_add && w->q_vec, "encoder_fwd: null weight");
+        NRMS_REQUIRE(desc->vocab > 0 ? (ids != nullptr && w->table != nullptr) : (x != nullptr), "encoder_fwd: input missing");
+        if (desc->n_seq == 0) return NRMS_OK;
+        return encoder_fwd16(desc, w, ids, x, acts, out, (hipStream_t)stream);
+    }
     NRMS_REQUIRE(w && acts && out, "encoder_fwd: null argument");
     NRMS_REQUIRE(w->w_qkv && w->b_qkv && w->w_add && w->b_add && w->q_vec, "encoder_fwd: null weight");
     NRMS_REQUIRE(acts->qkv && acts->ctx, "encoder_fwd: acts.qkv / acts.ctx are required");
@@ -248,11 +315,13 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
 
 extern "C" size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc) {
     if (validate_desc(desc, "encoder_fwd_scratch_bytes")) return 0;
+    if (desc->precision == NRMS_PRECISION_FP16) return fwd16_scratch(desc).total;
     return fwd_scratch(desc).total;
 }
 
 extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc) {
     if (validate_desc(desc, "encoder_bwd_workspace_bytes")) return 0;
+    if (desc->precision == NRMS_PRECISION_FP16) { set_error("encoder_bwd: the fp16 backward is not built yet"); return 0; }
     return bwd_layout(desc).total;
 }
 
@@ -274,6 +343,7 @@ extern "C" int nrms_encoder_bwd_wqkv(const nrms_encoder_desc* desc, const int64_
                                      size_t workspace_bytes, void* stream) {
     int rc = validate_desc(desc, "encoder_bwd_wqkv");
     if (rc) return rc;
+    NRMS_REQUIRE(desc->precision != NRMS_PRECISION_FP16, "encoder_bwd_wqkv: the fp16 backward is not built yet");
     NRMS_REQUIRE(acts && grads && workspace, "encoder_bwd_wqkv: null argument");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv, "encoder_bwd_wqkv: null gradient buffer");
     const bool gather = desc->vocab > 0;
@@ -292,6 +362,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
                                 void* stream) {
     int rc = validate_desc(desc, "encoder_bwd");
     if (rc) return rc;
+    NRMS_REQUIRE(desc->precision != NRMS_PRECISION_FP16, "encoder_bwd: the fp16 backward is not built yet");
     NRMS_REQUIRE(w && acts && dout && grads && workspace, "encoder_bwd: null argument");
     NRMS_REQUIRE(acts->qkv && acts->ctx && acts->t && acts->w, "encoder_bwd: all saved activations are required");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec,
@@ -418,6 +489,18 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
                                          (int*)(base + L.sscr), s);
     }
     return rc;
+}
+
+extern "C" int nrms_sanitize_ids(const int64_t* src, int64_t* dst, int64_t n, int32_t vocab, int32_t* n_bad, void* stream) {
+    NRMS_REQUIRE(n >= 0 && vocab > 0, "sanitize_ids: n=%ld vocab=%d", (long)n, vocab);
+    NRMS_REQUIRE(n == 0 || (src && dst && n_bad), "sanitize_ids: null argument");
+    return launch_sanitize_ids((long)n, src, dst, vocab, n_bad, (hipStream_t)stream);
+}
+
+extern "C" int nrms_title_keys(const int64_t* ids, int64_t n_titles, int32_t seq_len, int64_t* keys, void* stream) {
+    NRMS_REQUIRE(n_titles >= 0 && seq_len >= 1, "title_keys: n_titles=%ld seq_len=%d", (long)n_titles, seq_len);
+    NRMS_REQUIRE(n_titles == 0 || (ids && keys), "title_keys: null argument");
+    return launch_title_keys((long)n_titles, seq_len, ids, keys, (hipStream_t)stream);
 }
 
 extern "C" void nrms_timing_enable(int enable) {

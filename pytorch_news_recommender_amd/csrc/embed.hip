@@ -345,6 +345,59 @@ int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* 
     return check_launch("scatter_grouped");
 }
 
+// dst[i] = src[i] if 0 <= src[i] < vocab else 0 (the padding id); *n_bad += number of ids replaced.  The encoder
+// kernels index the table, the histogram and the placement arrays with the raw id: every id stream goes through
+// here first (nn.Embedding raises on an out-of-range index, nrms_v0.py:134-139).
+__global__ __launch_bounds__(256) void sanitize_ids_kernel(long n, const int64_t* src, int64_t* dst, long vocab, int* n_bad) {
+    int bad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int64_t v = src[i];
+        const bool ok = v >= 0 && v < vocab;
+        bad += ok ? 0 : 1;
+        dst[i] = ok ? v : 0;
+    }
+    const unsigned long long m = __ballot(bad != 0);
+    if (m != 0ull) {                                   // rare path
+        bad = (int)wave_sum((float)bad);               // <= 64 * few per wave: exact in fp32
+        if ((threadIdx.x & 63) == 0) atomicAdd(n_bad, bad);
+    }
+}
+
+int launch_sanitize_ids(long n, const int64_t* src, int64_t* dst, int vocab, int* n_bad, hipStream_t stream) {
+    if (n <= 0) return NRMS_OK;
+    int blocks = cdiv(n, 256 * 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    TimingScope ts("sanitize_ids", stream);
+    hipLaunchKernelGGL(sanitize_ids_kernel, dim3(blocks), dim3(256), 0, stream, n, src, dst, (long)vocab, n_bad);
+    return check_launch("sanitize_ids");
+}
+
+// keys[t] = 64-bit hash of title t's L word ids (one lane per title; titles are 30 words).  Equal titles get
+// equal keys; the caller verifies the converse on its representatives, so a collision costs time, not correctness.
+__global__ __launch_bounds__(256) void title_keys_kernel(long n, int L, const int64_t* ids, int64_t* keys) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)L;
+        const int64_t* row = ids + t * L;
+        for (int i = 0; i < L; ++i) {
+            uint64_t k = (uint64_t)row[i] * 0xFF51AFD7ED558CCDull;
+            k ^= k >> 32;
+            h = (h ^ k) * 0xC4CEB9FE1A85EC53ull;
+            h ^= h >> 29;
+        }
+        h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33;
+        keys[t] = (int64_t)h;
+    }
+}
+
+int launch_title_keys(long n, int L, const int64_t* ids, int64_t* keys, hipStream_t stream) {
+    if (n <= 0) return NRMS_OK;
+    int blocks = cdiv(n, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    TimingScope ts("title_keys", stream);
+    hipLaunchKernelGGL(title_keys_kernel, dim3(blocks), dim3(256), 0, stream, n, L, ids, keys);
+    return check_launch("title_keys");
+}
+
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,
                           hipStream_t stream) {
     if (M <= 0) return NRMS_OK;

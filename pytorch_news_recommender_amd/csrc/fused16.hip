@@ -1,0 +1,574 @@
+// fp16 mode (NRMS_PRECISION_FP16): the encoder forward as ONE kernel, one wavefront per sequence.
+//
+//   ids -> [gather16: x16 fp16, compact live rows] -> fused_fwd16:
+//       per head:  QT = Wq x^T, KT = Wk x^T (features x tokens), V = x Wv^T (tokens x features)   -- v_mfma_f32_32x32x16_f16
+//                  S^T = K Q^T  -> softmax over the key ROWS (registers)  -> ctx^T = V^T P^T      -- operands straight
+//                  from the accumulators of the previous product (no LDS, no shuffles)
+//       then:      T^T = Wadd ctx^T, tanh, . q_vec (register rows), softmax over the tokens (lanes), pooling
+//
+// Replaces NewsEncoder.forward / UserEncoder.forward (model/nrms_v0.py:154-176, 188-199; SDPA :13-23, MHSA :46-76,
+// additive attention :100-126) for sequences of at most 32 rows.  The only things shared between the 8 waves of a
+// workgroup are the weight tiles (32 output rows x K, fp16), streamed through a 3-slot LDS ring; Q, K, V, the
+// attention probabilities and tanh(.) never leave the register file.  HBM sees: x16 (read), ctx16 / T16 / w (written
+// for the backward), the [n_seq, d] output.
+//
+// Layouts (all fp16 tensors are zero padded):
+//   x16    [rows][KP]      KP = d rounded up to 32; row = compact live-token index (pos[token]) or the token itself
+//   wqkv16 [3h tiles][32][KP]   tile 3*head + {0,1,2} = the head's W_Q (pre-scaled by 1/sqrt(d_k)), W_K, W_V rows
+//   ctx16  [n_seq*S][DP]   DP = 32 h: head-padded features, and INSIDE every 16-feature block in "P16" order: memory
+//                          position 8*hh + j  <->  feature 16 b + 8 (j>>2) + 4 hh + (j&3).  That is exactly the order in
+//                          which a 32x32 accumulator hands its rows to the next MFMA as an operand (cdna guide, section 3),
+//                          so ctx^T goes from the PV product into the additive projection without any data movement.
+//   wadd16 [QP/32 tiles][32][DP]  columns in the same P16 order;   T16 [n_seq*S][QP] natural order
+#include "gemm.h"
+
+namespace nrms {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma32h(const h8& a, const h8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// registers 8s..8s+7 of a 32x32 accumulator as the fp16 operand of k-step s (rows of the accumulator = k)
+__device__ __forceinline__ h8 acc_frag(const f32x16& x, int s) {
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (_Float16)x[8 * s + j];
+    return r;
+}
+
+// padded feature index held by register r of lane-half hh (accumulator row), and the P16 memory position of it
+__device__ __forceinline__ int p16_pos(int fpad) {           // natural padded feature -> position inside its row
+    const int b = fpad >> 4, t = fpad & 15;
+    const int hh = (t >> 2) & 1, j = ((t >> 3) << 2) | (t & 3);
+    return 16 * b + 8 * hh + j;
+}
+
+constexpr int F16_WAVES = 8;
+constexpr int F16_THREADS = 64 * F16_WAVES;
+constexpr int F16_KS = 20;            // k-steps of 16 input features held in registers: d <= 320
+constexpr int F16_CS = 20;            // ctx k-steps: DP = 32 h <= 320
+constexpr int F16_QT = 7;             // q tiles of 32: q <= 224
+constexpr int F16_STG = 3;            // 16-byte staging chunks per thread and tile: 32 * pitch / 8 <= 512 * 3
+
+struct Fwd16Args {
+    int n_seq, S, d, h, dk, q;
+    int KP, DP, QP;
+    const _Float16* x16;      // [rows][KP]
+    const int* pos;           // [n_seq*S] token -> x16 row, -1 = padding token (zero row); null: row = token
+    const int64_t* ids;       // news encoder with NRMS_FLAG_PAD_ROW_ZERO: all-padding titles take the closed form; else null
+    const int* order;         // optional [n_seq]: sequence handled by slot i (non-empty titles first); null = identity
+    const _Float16* wqkv16;   // [3h][32][KP]
+    const float* bqkv32;      // [3h][32]  (Q part pre-scaled)
+    const _Float16* wadd16;   // [QP/32][32][DP]
+    const float* badd32;      // [QP]
+    const float* qv32;        // [QP]
+    _Float16* ctx16;          // [n_seq*S][DP]
+    _Float16* t16;            // [n_seq*S][QP] or null (inference)
+    float* w;                 // [n_seq*S] or null
+    float* out;               // [n_seq][d]
+    Dropout drop;             // context dropout (site 1, element index = token * DP + padded feature)
+};
+
+template <bool TRAIN>
+__global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int S = a.S, KP = a.KP, DP = a.DP, QP = a.QP;
+    const int ks_n = KP >> 4, cs_n = DP >> 4, qt_n = QP >> 5;
+    const int pitch = ((KP > DP ? KP : DP) + 8) * 2;            // LDS row pitch in bytes: +16 B => conflict-free b128 reads
+    const int slot_bytes = 32 * pitch;
+    const int n_head_tiles = 3 * a.h, n_tiles = n_head_tiles + qt_n;
+
+    // ---- which sequence this wave owns
+    const int slot_id = blockIdx.x * F16_WAVES + wave;
+    const bool valid = slot_id < a.n_seq;
+    const int seq = valid ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0;
+    const long tok0 = (long)seq * S;                             // first token of the sequence
+    const bool tok_ok = valid && l32 < S;
+    bool empty = false;                                          // all-padding title: attention is uniform over equal rows
+    if (a.ids != nullptr && valid) {
+        const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
+        empty = __ballot(is_pad) == ~0ull;
+    }
+    const bool skip_heads = __syncthreads_and((!valid || empty) ? 1 : 0) != 0;     // whole workgroup without a live title
+    const int n_begin = skip_heads ? n_head_tiles : 0;
+
+    // ---- weight-tile ring: tile n lives in slot n % 3; tile n+2 is fetched while tile n is consumed
+    h8 stg[F16_STG];
+    auto tile_src = [&](int n, int& rowchunks) -> const _Float16* {
+        if (n < n_head_tiles) { rowchunks = KP >> 3; return a.wqkv16 + (long)n * 32 * KP; }
+        rowchunks = DP >> 3;
+        return a.wadd16 + (long)(n - n_head_tiles) * 32 * DP;
+    };
+    auto stage_load = [&](int n) {
+        if (n >= n_tiles) return;
+        int rc;
+        const _Float16* src = tile_src(n, rc);
+        const int total = 32 * rc;
+#pragma unroll
+        for (int i = 0; i < F16_STG; ++i) {
+            const int c = tid + F16_THREADS * i;
+            if (c < total) stg[i] = *reinterpret_cast<const h8*>(src + (long)c * 8);      // tiles are contiguous [32][rc*8]
+        }
+    };
+    auto stage_store = [&](int n) {
+        if (n >= n_tiles) return;
+        int rc;
+        (void)tile_src(n, rc);
+        const int total = 32 * rc;
+        char* dst = smem + (n % 3) * slot_bytes;
+#pragma unroll
+        for (int i = 0; i < F16_STG; ++i) {
+            const int c = tid + F16_THREADS * i;
+            if (c < total) {
+                const int row = c / rc, col = c - row * rc;
+                *reinterpret_cast<h8*>(dst + row * pitch + col * 16) = stg[i];
+            }
+        }
+    };
+    auto wfrag = [&](int n, int s) -> h8 {                      // rows l32 of tile n, k-step s
+        return *reinterpret_cast<const h8*>(smem + (n % 3) * slot_bytes + l32 * pitch + (16 * s + 8 * hh) * 2);
+    };
+
+    stage_load(n_begin);
+    stage_store(n_begin);
+    stage_load(n_begin + 1);
+    stage_store(n_begin + 1);
+
+    // ---- this lane's x fragments: token l32, features 16 s + 8 hh .. +7 (A operand of x W^T and B operand of W x^T)
+    h8 xf[F16_KS];
+    {
+        long row = -1;
+        if (tok_ok && !empty) row = a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32;
+        const _Float16* xr = a.x16 + (row < 0 ? 0 : row) * KP + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < F16_KS; ++s) {
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (s < ks_n && row >= 0) v = *reinterpret_cast<const h8*>(xr + 16 * s);
+            xf[s] = v;
+        }
+    }
+    __syncthreads();
+
+    const long ctx_row = (tok0 + l32) * (long)DP;                 // this lane's ctx16 row (token l32)
+    int n = n_begin;
+    if (!skip_heads) {
+        for (int head = 0; head < a.h; ++head) {
+            f32x16 qt, kt, vv;
+            // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] + b
+            stage_load(n + 2);
+            {
+                const float* b = a.bqkv32 + (n * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qt[4 * g + e] = bb[e];
+                }
+                if (valid && !empty) {
+#pragma unroll
+                    for (int s = 0; s < F16_KS; ++s)
+                        if (s < ks_n) qt = mfma32h(wfrag(n, s), xf[s], qt);
+                }
+            }
+            stage_store(n + 2);
+            __syncthreads();
+            ++n;
+            // ---- tile K
+            stage_load(n + 2);
+            {
+                const float* b = a.bqkv32 + (n * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) kt[4 * g + e] = bb[e];
+                }
+                if (valid && !empty) {
+#pragma unroll
+                    for (int s = 0; s < F16_KS; ++s)
+                        if (s < ks_n) kt = mfma32h(wfrag(n, s), xf[s], kt);
+                }
+            }
+            stage_store(n + 2);
+            __syncthreads();
+            ++n;
+            // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k] + b   (bias per column = lane)
+            stage_load(n + 2);
+            {
+                const float bv = a.bqkv32[n * 32 + l32];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vv[r] = bv;
+                if (valid && !empty) {
+#pragma unroll
+                    for (int s = 0; s < F16_KS; ++s)
+                        if (s < ks_n) vv = mfma32h(xf[s], wfrag(n, s), vv);
+                }
+            }
+            stage_store(n + 2);
+            // ---- attention of this head, entirely in registers
+            f32x16 ct;                                   // ctx^T[f][tok]
+            if (valid && !empty) {
+                f32x16 st;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                // S^T[j][i] = sum_f KT[f][j] QT[f][i]   (rows j = keys in registers, columns i = queries on lanes)
+                st = mfma32h(acc_frag(kt, 0), acc_frag(qt, 0), st);
+                st = mfma32h(acc_frag(kt, 1), acc_frag(qt, 1), st);
+                float m = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = crow32(r, hh);
+                    st[r] = j < S ? st[r] : -3.0e38f;        // rows beyond the sequence are not keys
+                    m = fmaxf(m, st[r]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = crow32(r, hh);
+                    const float p = j < S ? __expf(st[r] - m) : 0.f;
+                    st[r] = p;
+                    sum += p;
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] *= inv;
+                // ctx^T[f][i] = sum_j V[j][f] P^T[j][i]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ct[r] = 0.f;
+                ct = mfma32h(acc_frag(vv, 0), acc_frag(st, 0), ct);
+                ct = mfma32h(acc_frag(vv, 1), acc_frag(st, 1), ct);
+            } else {
+                // all-padding title: S equal rows V_j = b_v, uniform attention => ctx = b_v for every token
+                const float* b = a.bqkv32 + ((n) * 32);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ct[4 * g + e] = bb[e];
+                }
+            }
+            if (TRAIN && a.drop.thresh != 0u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
+                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ct[4 * g + e] *= sc[e];
+                }
+            }
+            if (tok_ok) {
+                _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
+                *reinterpret_cast<h8*>(dst) = acc_frag(ct, 0);
+                *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct, 1);
+            }
+            __syncthreads();
+            ++n;
+        }
+    } else {
+        // no live title in this workgroup: every sequence takes the closed form, no weight tile of the heads is needed
+        for (int head = 0; head < a.h; ++head) {
+            f32x16 ct;
+            const float* b = a.bqkv32 + ((3 * head + 2) * 32);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ct[4 * g + e] = bb[e];
+            }
+            if (TRAIN && a.drop.thresh != 0u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
+                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ct[4 * g + e] *= sc[e];
+                }
+            }
+            if (tok_ok) {
+                _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
+                *reinterpret_cast<h8*>(dst) = acc_frag(ct, 0);
+                *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct, 1);
+            }
+        }
+    }
+
+    // ---- additive attention: T^T[q][tok] = sum_f Wadd[q][f] ctx^T[f][tok]; the ctx operand is read back in the
+    // very layout it was stored in (own stores: wait for them, then plain loads)
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's ctx16 stores have landed
+    h8 cf[F16_CS];
+    {
+        const _Float16* src = a.ctx16 + ctx_row + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < F16_CS; ++s) {
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (s < cs_n && tok_ok) v = *reinterpret_cast<const h8*>(src + 16 * s);
+            cf[s] = v;
+        }
+    }
+    float score = 0.f;                                            // sum_q q_vec[q] tanh(.)[q][tok], per token = per lane
+#pragma unroll
+    for (int t = 0; t < F16_QT; ++t) {
+        if (t < qt_n) {
+            stage_load(n + 2);
+            f32x16 tt;
+            const float* b = a.badd32 + 32 * t;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tt[4 * g + e] = bb[e];
+            }
+            if (valid) {
+#pragma unroll
+                for (int s = 0; s < F16_CS; ++s)
+                    if (s < cs_n) tt = mfma32h(wfrag(n, s), cf[s], tt);
+            }
+            const float* qv = a.qv32 + 32 * t;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + 8 * g + 4 * hh);
+                h4 th;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fast_tanh(tt[4 * g + e]);
+                    score += qq[e] * v;
+                    th[e] = (_Float16)v;
+                }
+                if (TRAIN && a.t16 != nullptr && tok_ok)
+                    *reinterpret_cast<h4*>(a.t16 + (tok0 + l32) * (long)QP + 32 * t + 8 * g + 4 * hh) = th;
+            }
+            stage_store(n + 2);
+            __syncthreads();
+            ++n;
+        }
+    }
+    score += __shfl_xor(score, 32, 64);
+    // softmax over the tokens of the sequence (lanes 0..S-1 of either half)
+    float sm = l32 < S ? score : -3.0e38f;
+    float mx = sm;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float ev = l32 < S ? __expf(sm - mx) : 0.f;
+    float es = ev;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
+    const float wgt = ev / es;
+    if (TRAIN && a.w != nullptr && tok_ok && hh == 0) a.w[tok0 + l32] = wgt;
+
+    // ---- pooling: out[f] = sum_tok w_tok ctx[tok][f].  Lane c owns the 16-byte chunk c of a ctx16 row (DP/8 chunks).
+    if (valid) {
+        const int n_chunks = DP >> 3;
+        float acc8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
+        const _Float16* base = a.ctx16 + tok0 * (long)DP + lane * 8;
+        for (int t = 0; t < S; ++t) {
+            const float wt = __builtin_amdgcn_readlane(wgt, t);
+            if (lane < n_chunks) {
+                const h8 v = *reinterpret_cast<const h8*>(base + (long)t * DP);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += wt * (float)v[j];
+            }
+        }
+        if (lane < n_chunks) {
+            const int b16 = lane >> 1, ch = lane & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int fpad = 16 * b16 + 8 * (j >> 2) + 4 * ch + (j & 3);
+                const int head = fpad >> 5, f = fpad & 31;
+                if (f < a.dk) a.out[(long)seq * a.d + head * a.dk + f] = acc8[j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight planes of one encoder (a few hundred KB): one launch per call
+struct Prep16Args {
+    int d, h, dk, q, KP, DP, QP;
+    const float* w_qkv;   // [3d][d]
+    const float* b_qkv;   // [3d]
+    const float* w_add;   // [q][d]
+    const float* b_add;   // [q]
+    const float* q_vec;   // [q]
+    _Float16* wqkv16;     // [3h][32][KP]
+    float* bqkv32;        // [3h][32]
+    _Float16* wadd16;     // [QP][DP]  (P16 column order)
+    float* badd32;        // [QP]
+    float* qv32;          // [QP]
+};
+
+__global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
+    const float qscale = 1.0f / sqrtf((float)a.dk);
+    const long n1 = (long)3 * a.h * 32 * a.KP, n2 = (long)a.QP * a.DP, n3 = (long)3 * a.h * 32, n4 = a.QP;
+    const long total = n1 + n2 + n3 + 2 * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const int k = (int)(i % a.KP);
+            const long r = i / a.KP;
+            const int f = (int)(r & 31), tile = (int)(r >> 5), head = tile / 3, which = tile - 3 * head;
+            float v = 0.f;
+            if (f < a.dk && k < a.d) v = a.w_qkv[((long)which * a.d + head * a.dk + f) * a.d + k] * (which == 0 ? qscale : 1.0f);
+            a.wqkv16[i] = (_Float16)v;
+        } else if (i < n1 + n2) {
+            const long j = i - n1;
+            const int p = (int)(j % a.DP), qq = (int)(j / a.DP);
+            // memory position p of the row holds padded feature fpad (P16 order inside each 16-block)
+            const int b16 = p >> 4, t = p & 15, hh = t >> 3, jj = t & 7;
+            const int fpad = 16 * b16 + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+            const int head = fpad >> 5, f = fpad & 31;
+            float v = 0.f;
+            if (qq < a.q && f < a.dk) v = a.w_add[(long)qq * a.d + head * a.dk + f];
+            a.wadd16[j] = (_Float16)v;
+        } else if (i < n1 + n2 + n3) {
+            const long j = i - n1 - n2;
+            const int f = (int)(j & 31), tile = (int)(j >> 5), head = tile / 3, which = tile - 3 * head;
+            float v = 0.f;
+            if (f < a.dk) v = a.b_qkv[which * a.d + head * a.dk + f] * (which == 0 ? qscale : 1.0f);
+            a.bqkv32[j] = v;
+        } else if (i < n1 + n2 + n3 + n4) {
+            const long j = i - n1 - n2 - n3;
+            a.badd32[j] = j < a.q ? a.b_add[j] : 0.f;
+        } else {
+            const long j = i - n1 - n2 - n3 - n4;
+            a.qv32[j] = j < a.q ? a.q_vec[j] : 0.f;
+        }
+    }
+}
+
+// x16[r, :] = fp16(table[ids[t], :] * keep(t, :) / (1 - p)), t = live[r] (r < *n_live) or t = r (live == null);
+// columns d..KP-1 are zero.  Same Philox counters (site 0, element index t*d + c) as the fp32 gather.
+__global__ __launch_bounds__(256) void gather16_kernel(unsigned d4, unsigned kp4, long M, const int64_t* ids, const int* live,
+                                                       const int* n_live, const float* table, Dropout drop, _Float16* x16) {
+    const unsigned rows = live != nullptr ? (unsigned)(*n_live) : (unsigned)M;
+    const unsigned total = rows * kp4;
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const unsigned r = i / kp4, c4 = i - r * kp4;
+        const long t = live != nullptr ? (long)live[r] : (long)r;
+        h4 o = {0, 0, 0, 0};
+        if (c4 < d4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(table + ids[t] * (long)(4 * d4) + 4 * c4);
+            if (drop.thresh != 0u) v *= dropout_scale4(drop.seed, 0u, (uint64_t)(t * d4 + c4), drop.thresh, drop.inv_keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+        }
+        *reinterpret_cast<h4*>(x16 + (long)i * 4) = o;
+    }
+}
+
+// fp32 rows [M][d] (the user encoder's input: news vectors) -> x16 [M][KP]
+__global__ __launch_bounds__(256) void cast16_kernel(unsigned d4, unsigned kp4, long M, const float* x, _Float16* x16) {
+    const unsigned total = (unsigned)M * kp4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / kp4, c4 = i - r * kp4;
+        h4 o = {0, 0, 0, 0};
+        if (c4 < d4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)r * d4 + c4) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+        }
+        *reinterpret_cast<h4*>(x16 + (long)i * 4) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+bool fused16_supported(int S, int d, int h, int q, const char** why) {
+    const int dk = d / h;
+    const char* w = nullptr;
+    if (S > 32) w = "seq_len <= 32";
+    else if (d > 16 * F16_KS) w = "d_model <= 320";
+    else if (dk > 32) w = "d_k <= 32";
+    else if (32 * h > 16 * F16_CS) w = "n_heads <= 10";
+    else if (q > 32 * F16_QT) w = "q_dim <= 224";
+    if (why) *why = w;
+    return w == nullptr;
+}
+
+Fused16Layout fused16_layout(int d, int h, int q) {
+    Fused16Layout L;
+    L.KP = cdiv(d, 32) * 32;
+    L.DP = 32 * h;
+    L.QP = cdiv(q, 32) * 32;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    L.wqkv16 = take((size_t)3 * h * 32 * L.KP * 2);
+    L.wadd16 = take((size_t)L.QP * L.DP * 2);
+    L.bqkv32 = take((size_t)3 * h * 32 * 4);
+    L.badd32 = take((size_t)L.QP * 4);
+    L.qv32 = take((size_t)L.QP * 4);
+    L.total = off;
+    return L;
+}
+
+int launch_prep16(int d, int h, int q, const float* w_qkv, const float* b_qkv, const float* w_add, const float* b_add,
+                  const float* q_vec, void* planes, hipStream_t stream) {
+    const Fused16Layout L = fused16_layout(d, h, q);
+    char* base = (char*)planes;
+    Prep16Args a{};
+    a.d = d; a.h = h; a.dk = d / h; a.q = q; a.KP = L.KP; a.DP = L.DP; a.QP = L.QP;
+    a.w_qkv = w_qkv; a.b_qkv = b_qkv; a.w_add = w_add; a.b_add = b_add; a.q_vec = q_vec;
+    a.wqkv16 = (_Float16*)(base + L.wqkv16); a.wadd16 = (_Float16*)(base + L.wadd16);
+    a.bqkv32 = (float*)(base + L.bqkv32); a.badd32 = (float*)(base + L.badd32); a.qv32 = (float*)(base + L.qv32);
+    const long total = (long)3 * h * 32 * L.KP + (long)L.QP * L.DP + 3 * h * 32 + 2 * L.QP;
+    TimingScope ts("prep16", stream);
+    hipLaunchKernelGGL(prep16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a);
+    return check_launch("prep16");
+}
+
+int launch_gather16(long M, int d, int KP, const int64_t* ids, const int* live, const int* n_live, const float* table,
+                    const Dropout& drop, void* x16, hipStream_t stream) {
+    if (M <= 0) return NRMS_OK;
+    if (M * (KP / 4) >= (1L << 32)) { set_error("gather16: index overflow"); return NRMS_EINVAL; }
+    int blocks = cdiv(M * (KP / 4), 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    TimingScope ts("gather_dropout", stream);
+    hipLaunchKernelGGL(gather16_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)(d / 4), (unsigned)(KP / 4), M, ids, live,
+                       n_live, table, drop, (_Float16*)x16);
+    return check_launch("gather16");
+}
+
+int launch_cast16(long M, int d, int KP, const float* x, void* x16, hipStream_t stream) {
+    if (M <= 0) return NRMS_OK;
+    if (M * (KP / 4) >= (1L << 32)) { set_error("cast16: index overflow"); return NRMS_EINVAL; }
+    int blocks = cdiv(M * (KP / 4), 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    TimingScope ts("cast16", stream);
+    hipLaunchKernelGGL(cast16_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)(d / 4), (unsigned)(KP / 4), M, x, (_Float16*)x16);
+    return check_launch("cast16");
+}
+
+int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
+    if (f.n_seq <= 0) return NRMS_OK;
+    const Fused16Layout L = fused16_layout(f.d, f.h, f.q);
+    const char* base = (const char*)f.planes;
+    Fwd16Args a{};
+    a.n_seq = f.n_seq; a.S = f.S; a.d = f.d; a.h = f.h; a.dk = f.d / f.h; a.q = f.q;
+    a.KP = L.KP; a.DP = L.DP; a.QP = L.QP;
+    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.ids = f.ids; a.order = f.order;
+    a.wqkv16 = (const _Float16*)(base + L.wqkv16); a.bqkv32 = (const float*)(base + L.bqkv32);
+    a.wadd16 = (const _Float16*)(base + L.wadd16); a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
+    a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;
+    const int pitch = ((L.KP > L.DP ? L.KP : L.DP) + 8) * 2;
+    const size_t lds = (size_t)3 * 32 * pitch;
+    const bool train = f.t16 != nullptr;
+    const void* fn = train ? (const void*)fused_fwd16_kernel<true> : (const void*)fused_fwd16_kernel<false>;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("fused_fwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    TimingScope ts("fused_fwd16", stream);
+    const dim3 grid(cdiv(f.n_seq, F16_WAVES));
+    if (train) hipLaunchKernelGGL(fused_fwd16_kernel<true>, grid, dim3(F16_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL(fused_fwd16_kernel<false>, grid, dim3(F16_THREADS), lds, stream, a);
+    return check_launch("fused_fwd16");
+}
+
+}  // namespace nrms

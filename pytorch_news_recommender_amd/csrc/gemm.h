@@ -320,7 +320,36 @@ struct AddFwdArgs {
 };
 int launch_addattn_fwd_bf16(int npass, const AddFwdArgs& a, void* wplanes, hipStream_t stream);
 
+// fused16.hip: fp16 mode.  One wavefront per sequence; weight planes prepared once per call.
+struct Fused16Layout { int KP, DP, QP; size_t wqkv16, wadd16, bqkv32, badd32, qv32, total; };   // byte offsets into `planes`
+Fused16Layout fused16_layout(int d, int h, int q);
+bool fused16_supported(int S, int d, int h, int q, const char** why);
+int launch_prep16(int d, int h, int q, const float* w_qkv, const float* b_qkv, const float* w_add, const float* b_add,
+                  const float* q_vec, void* planes, hipStream_t stream);
+// x16[r, 0:KP] = fp16(table[ids[t]] * keep / (1-p)), t = live[r] for r < *n_live (live == null: t = r < M)
+int launch_gather16(long M, int d, int KP, const int64_t* ids, const int* live, const int* n_live, const float* table,
+                    const Dropout& drop, void* x16, hipStream_t stream);
+int launch_cast16(long M, int d, int KP, const float* x, void* x16, hipStream_t stream);
+struct Fused16Fwd {
+    int n_seq, S, d, h, q;
+    const void* planes;       // fused16_layout(d, h, q).total bytes, filled by launch_prep16
+    const void* x16;          // [rows][KP] fp16
+    const int* pos;           // token -> x16 row (-1: zero row) or null (row = token)
+    const int64_t* ids;       // non-null: sequences whose ids are all 0 take the closed form (padding row is zero)
+    const int* order;         // optional permutation of the sequences
+    void* ctx16;              // [n_seq*S][DP] fp16 (always written: the kernel reads it back)
+    void* t16;                // [n_seq*S][QP] fp16 or null (inference)
+    float* w;                 // [n_seq*S] or null
+    float* out;               // [n_seq][d]
+    Dropout drop;             // context dropout
+};
+int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream);
+
 // embed.hip
+// dst[i] = src[i] if 0 <= src[i] < vocab else 0; *n_bad += ids replaced (dst may alias src)
+int launch_sanitize_ids(long n, const int64_t* src, int64_t* dst, int vocab, int* n_bad, hipStream_t stream);
+// keys[t] = 64-bit hash of the L word ids of title t
+int launch_title_keys(long n, int L, const int64_t* ids, int64_t* keys, hipStream_t stream);
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,
                           hipStream_t stream);
 // x[r, :] = table[ids[live[r]], :] * keep(live[r], :) / (1 - p) for the compact rows r < *n_live

@@ -11,16 +11,89 @@ Only the keys the NRMS path reads are always filled; abstract / category keys ar
 unless the dictionaries are given) so the collated dict has the reference's full key set.
 
 MIND itself is not available offline, so ``SyntheticMind`` fabricates a corpus + behaviours with
-the same structure; ``load_dataset`` reads the reference's pickles when they exist.
+the same structure; ``load_dataset`` / ``get_Words_Infos`` / ``read_dev_labels`` / ``get_Test_List`` read the
+files the reference's own preprocessing writes under ``config.data_path`` when they exist (the user's own
+data: nothing of the kind ships with the reference).
 """
 from __future__ import annotations
 
+import csv
 import os
 import pickle
+from ast import literal_eval
 
 import numpy as np
 import torch
 from torch.utils.data import Dataset
+
+
+def _words_infos(config, title_pkl, abst_pkl, words_csv):
+    """news index -> padded word-id list, for titles and abstracts: the pickled dicts when they exist, otherwise
+    built from the headerless ``news_id,title,abstract`` csv (list literals) and cached as pickles, exactly as
+    the reference does (data_handler.py:113-135)."""
+    base = config.data_path
+    tp, ap = os.path.join(base, title_pkl), os.path.join(base, abst_pkl)
+    if os.path.exists(tp):
+        with open(tp, 'rb') as f:
+            title_dict = pickle.load(f)
+        abst_dict = None
+        if os.path.exists(ap):
+            with open(ap, 'rb') as f:
+                abst_dict = pickle.load(f)
+        return title_dict, abst_dict
+    src = os.path.join(base, words_csv)
+    if not os.path.exists(src):
+        raise FileNotFoundError("neither %s nor %s exists: run the reference's data_processor first, or pass "
+                                "id2title_dict / use --dataset synthetic" % (tp, src))
+    title_dict, abst_dict = {}, {}
+    csv.field_size_limit(1 << 30)
+    with open(src, newline='') as f:
+        for i, row in enumerate(csv.reader(f)):          # columns: news_id, title, abstract (no header)
+            title_dict[i] = literal_eval(row[1])
+            abst_dict[i] = literal_eval(row[2])
+    with open(tp, 'wb') as f:
+        pickle.dump(title_dict, f)
+    with open(ap, 'wb') as f:
+        pickle.dump(abst_dict, f)
+    return title_dict, abst_dict
+
+
+def get_Words_Infos(config):
+    """data_handler.py:113-135."""
+    return _words_infos(config, 'news_title.pkl', 'news_abst.pkl', 'news_words.csv')
+
+
+def get_Demo_Words_Infos(config):
+    """data_handler.py:137-159."""
+    return _words_infos(config, 'demo_news_title.pkl', 'demo_news_abst.pkl', 'demo_news_words.csv')
+
+
+def read_dev_labels(config, file=None):
+    """Per-impression 0/1 label lists from the ``y_true`` column (space-separated) of dev_behaviors.csv
+    (train_eval.py:36-39; demo mode: small_dev_behaviors.csv, train_eval.py:156-158)."""
+    if file is None:
+        file = 'small_dev_behaviors.csv' if getattr(config, 'mode', 'large') == 'demo' else 'dev_behaviors.csv'
+    path = os.path.join(config.data_path, file)
+    csv.field_size_limit(1 << 30)
+    with open(path, newline='') as f:
+        return [[int(v) for v in row['y_true'].split(' ')] for row in csv.DictReader(f)]
+
+
+def get_Test_List(config):
+    """Number of shown candidates per test impression (train_eval.py:287-298): the cached
+    test_imps_list.pkl, or counted from the 4th (impressions) column of test/behaviors.tsv and cached."""
+    cache = os.path.join(config.data_path, 'test_imps_list.pkl')
+    if os.path.exists(cache):
+        with open(cache, 'rb') as f:
+            return pickle.load(f)
+    lens = []
+    with open(os.path.join(config.test_path, 'behaviors.tsv')) as f:
+        for line in f:
+            cols = line.rstrip('\n').split('\t')
+            lens.append(len(cols[-1].split(' ')))
+    with open(cache, 'wb') as f:
+        pickle.dump(lens, f)
+    return lens
 
 
 class MyDataset(Dataset):
@@ -30,7 +103,11 @@ class MyDataset(Dataset):
         self.data_type = type
         self.bacthes = datas                       # (sic) attribute name of the reference
         if id2title_dict is None:
-            raise ValueError("id2title_dict is required (news index -> padded title word ids)")
+            # the reference's constructor (data_handler.py:162-170): the word dictionaries come from config.data_path
+            if getattr(config, 'mode', 'large') == 'demo':
+                id2title_dict, id2abst_dict = get_Demo_Words_Infos(config)
+            else:
+                id2title_dict, id2abst_dict = get_Words_Infos(config)
         self.id2title_dict = id2title_dict
         self.id2abst_dict = id2abst_dict
         # training: 1 positive + sample_size negatives; evaluation: padded to max_candidate_size

@@ -114,9 +114,29 @@ class NRMSEngine:
             raise _lib.NrmsError("the NRMS HIP engine needs a GPU device (got %s); there is no CPU path" % device)
         self._bufs = {}
         self._saved = None
+        self.fp16_backward = False         # the fused fp16 backward (training in fp16 mode)
+        self._gen = 0                      # generation stamp of _saved (checked by the autograd backward)
+        # out-of-range word ids: counted on the device by nrms_sanitize_ids, surfaced without a host sync
+        # (the count is copied to pinned memory behind the kernel and looked at on a later call)
+        self._bad_ids = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._bad_event = None
+        self._news_cache = None
+
+    FP16_LIMITS = dict(seq_len=32, d_model=320, d_k=32, n_heads=10, q_dim=224)
+
+    def _fp16_ok(self, enc, seq_len, mask_mode, training):
+        """The fused fp16 kernels cover the shapes of include/nrms_hip.h (NRMS_PRECISION_FP16); an encoder pass
+        outside them (e.g. the user encoder over a 50-slot history) runs in bf16x3 instead."""
+        d, L = self.dims, self.FP16_LIMITS
+        h = d.heads(enc)
+        return (seq_len <= L["seq_len"] and d.word_embed_size <= L["d_model"] and h <= L["n_heads"]
+                and d.word_embed_size // h <= L["d_k"] and d.query_vector_dim <= L["q_dim"]
+                and not d.output_proj and not mask_mode and (not training or self.fp16_backward))
 
     def set_precision(self, precision):
-        """"fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections, ~2^-16 relative) or "bf16"."""
+        """"fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections, ~2^-16 relative), "bf16", or "fp16"
+        (fused one-wave-per-sequence kernels on fp16 MFMA, fp16 activations; bf16x3 where a shape is outside them)."""
         if precision not in _lib.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self.precision = precision
@@ -132,12 +152,15 @@ class NRMSEngine:
             self._bufs[key] = t
         return t
 
-    def _desc(self, enc, n_seq, seq_len, p_embed=0.0, p_ctx=0.0, seed=0, mask_mode=0):
+    def _desc(self, enc, n_seq, seq_len, p_embed=0.0, p_ctx=0.0, seed=0, mask_mode=0, training=False):
         d = self.dims
+        prec = self.precision
+        if prec == "fp16" and not self._fp16_ok(enc, seq_len, mask_mode, training):
+            prec = "bf16x3"
         return _lib.EncoderDesc(n_seq=n_seq, seq_len=seq_len, d_model=d.word_embed_size, n_heads=d.heads(enc),
                                 q_dim=d.query_vector_dim, vocab=d.n_words if enc == "news_encoder" else 0,
                                 p_drop_embed=float(p_embed), p_drop_ctx=float(p_ctx),
-                                precision=_lib.PRECISIONS[self.precision], use_output_proj=int(d.output_proj),
+                                precision=_lib.PRECISIONS[prec], use_output_proj=int(d.output_proj),
                                 mask_mode=int(mask_mode),
                                 flags=(_lib.NRMS_FLAG_PAD_ROW_ZERO if (self.pad_row_zero and enc == "news_encoder") else 0),
                                 seed=int(seed))
@@ -155,8 +178,20 @@ class NRMSEngine:
     def _grads(self, gflat, enc):
         return self._ptrs(_lib.EncoderGrads, gflat, enc)
 
-    def _acts(self, tag, M, need_bwd, gather=False):
+    def _acts(self, tag, M, need_bwd, gather=False, desc=None):
         d, q = self.dims.word_embed_size, self.dims.query_vector_dim
+        if desc is not None and desc.precision == _lib.NRMS_PRECISION_FP16:
+            # fp16 activations with padded pitches (include/nrms_hip.h, nrms_encoder_acts)
+            KP, DP, QP = -(-d // 32) * 32, 32 * desc.n_heads, -(-q // 32) * 32
+            h = torch.float16
+            x = self._buf(tag + ".x16", M * KP, h)
+            ctx = self._buf(tag + ".ctx16", M * DP, h)
+            t = self._buf(tag + ".t16", M * QP, h) if need_bwd else None
+            w = self._buf(tag + ".w", M) if need_bwd else None
+            nbytes = int(self.lib.nrms_encoder_fwd_scratch_bytes(C.byref(desc)))
+            scratch = self._buf("fwd_scratch16", (nbytes + 3) // 4)
+            dp = lambda z: None if z is None else z.data_ptr()
+            return _lib.EncoderActs(x=dp(x), qkv=None, attn=None, ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
         x = self._buf(tag + ".x", M * d) if gather else None
         qkv = self._buf(tag + ".qkv", M * 3 * d)
         attn = self._buf(tag + ".attn", M * d) if self.dims.output_proj else None
@@ -168,39 +203,85 @@ class NRMSEngine:
         dp = lambda z: None if z is None else z.data_ptr()
         return _lib.EncoderActs(x=dp(x), qkv=dp(qkv), attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
 
+    # ---- word-id validation (nn.Embedding raises on an out-of-range index; here: device-side, deferred) ----
+    def sanitize_ids(self, src, dst):
+        """dst = src with ids outside [0, n_words) replaced by the padding id 0 (so no kernel can index out of
+        bounds), counting them on the device.  The count reaches the host asynchronously: poll_ids() on a later
+        call, or check_ids() (synchronises), raises NrmsError."""
+        n = src.numel()
+        if n == 0:
+            return dst
+        rc = self.lib.nrms_sanitize_ids(_lib.ptr(src), _lib.ptr(dst), C.c_int64(n), int(self.dims.n_words),
+                                        _lib.ptr(self._bad_ids), _stream())
+        _lib.check(rc, "nrms_sanitize_ids")
+        self._bad_host.copy_(self._bad_ids, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._bad_event = ev
+        return dst
+
+    def _raise_bad_ids(self):
+        n = int(self._bad_host.item())
+        if n:
+            self._bad_ids.zero_()
+            self._bad_host.zero_()
+            raise _lib.NrmsError("%d word id(s) outside [0, %d) reached the embedding gather (treated as the padding "
+                                 "id on the device; the vocabulary and the embedding table disagree)" % (n, self.dims.n_words))
+
+    def poll_ids(self):
+        """Non-blocking: raises if an earlier call's id check has completed and found out-of-range ids."""
+        if self._bad_event is not None and self._bad_event.query():
+            self._bad_event = None
+            self._raise_bad_ids()
+
+    def check_ids(self):
+        """Blocking form of poll_ids(): waits for the pending id checks."""
+        if self._bad_event is not None:
+            self._bad_event.synchronize()
+            self._bad_event = None
+        self._raise_bad_ids()
+
     # ---- news vectors for an arbitrary list of titles (a-5, a-9 get_news_vector) ---------
-    def encode_titles(self, flat, ids, out=None, p_embed=0.0, p_ctx=0.0, seed=0, save=False, tag="news",
-                      chunk_titles=32768, mask=None, mask_mode=0):
+    def encode_titles(self, flat, ids, out=None, p_embed=0.0, p_ctx=0.0, seed=0, save=False, tag=None,
+                      chunk_titles=32768, mask=None, mask_mode=0, trusted_ids=False):
         """ids [N, L] int64 on the device -> news vectors [N, d].  With save=True (training) the
         activations are kept for the backward and the call is not chunked.  mask [N, L] uint8 with
         mask_mode bits (1 = attention pairs, 2 = pooling) gives nrms_v1's masked primitives."""
         N, L = ids.shape
         d = self.dims.word_embed_size
+        if tag is None:
+            tag = "news" if save else "news_eval"
         if out is None:
             out = torch.empty(N, d, dtype=torch.float32, device=self.device)
-        ids = ids.contiguous()
+        if trusted_ids:
+            ids = ids.contiguous()
+        else:
+            self.poll_ids()
+            ids = self.sanitize_ids(ids.contiguous(), self._buf(tag + ".ids", N * L, torch.int64)[:N * L].view(N, L))
         if mask is not None:
             mask = mask.contiguous()
         w = self._weights(flat, "news_encoder")
         step = N if save else min(N, chunk_titles)
         for s0 in range(0, N, max(step, 1)):
             n = min(step, N - s0)
-            desc = self._desc("news_encoder", n, L, p_embed, p_ctx, seed, mask_mode if mask is not None else 0)
-            acts = self._acts(tag, n * L, save, gather=True)
+            desc = self._desc("news_encoder", n, L, p_embed, p_ctx, seed, mask_mode if mask is not None else 0, training=save)
+            acts = self._acts(tag, n * L, save, gather=True, desc=desc)
             mp = None if mask is None else C.c_void_p(mask[s0:].data_ptr())
             rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), C.c_void_p(ids[s0:].data_ptr()), None, mp,
                                            C.byref(acts), C.c_void_p(out[s0:].data_ptr()), _stream())
             _lib.check(rc, "nrms_encoder_fwd(news)")
         return out
 
-    def encode_users(self, flat, news_vectors, out=None, save=False, tag="user", mask=None, mask_mode=0):
+    def encode_users(self, flat, news_vectors, out=None, save=False, tag=None, mask=None, mask_mode=0):
         """news_vectors [B, H, d] -> user vectors [B, d] (a-6, a-9 get_user_vector)."""
         B, H, d = news_vectors.shape
+        if tag is None:
+            tag = "user" if save else "user_eval"
         if out is None:
             out = torch.empty(B, d, dtype=torch.float32, device=self.device)
         w = self._weights(flat, "user_encoder")
-        desc = self._desc("user_encoder", B, H, mask_mode=mask_mode if mask is not None else 0)
-        acts = self._acts(tag, B * H, save)
+        desc = self._desc("user_encoder", B, H, mask_mode=mask_mode if mask is not None else 0, training=save)
+        acts = self._acts(tag, B * H, save, desc=desc)
         rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), None, C.c_void_p(news_vectors.data_ptr()),
                                        _lib.ptr(None if mask is None else mask.contiguous()), C.byref(acts),
                                        C.c_void_p(out.data_ptr()), _stream())
@@ -220,31 +301,37 @@ class NRMSEngine:
     def forward(self, flat, hist_ids, cand_ids, cand_mask, training, p_drop=0.0, seed=0, user_mask=None,
                 user_mask_mode=0):
         """hist_ids [B,H,L], cand_ids [B,C,L] int64 and cand_mask [B,C] uint8 (or None) on the
-        device -> scores [B,C].  training=True keeps what backward() needs."""
+        device -> scores [B,C].  training=True keeps what backward() needs; p_drop is applied as given
+        (the caller passes 0 in eval mode; a train-mode forward under no_grad still drops, as nn.Dropout does)."""
         B, H, L = hist_ids.shape
         Cn = cand_ids.shape[1]
         d = self.dims.word_embed_size
         N = B * (H + Cn)
-        ids = self._buf("ids", N * L, torch.int64)[:N * L].view(N, L)
-        ids[:B * H].copy_(hist_ids.reshape(B * H, L))
-        ids[B * H:].copy_(cand_ids.reshape(B * Cn, L))
-        nv = self._buf("news_vec", N * d)[:N * d].view(N, d)
-        p = p_drop if training else 0.0
+        # training activations and inference scratch live under different tags: an inference call (get_news_vector,
+        # an eval forward) between a training forward and its backward must not overwrite what the backward reads
+        sfx = "" if training else "_eval"
+        self.poll_ids()
+        ids = self._buf("ids" + sfx, N * L, torch.int64)[:N * L].view(N, L)
+        self.sanitize_ids(hist_ids.reshape(B * H, L).contiguous(), ids[:B * H])
+        self.sanitize_ids(cand_ids.reshape(B * Cn, L).contiguous(), ids[B * H:])
+        nv = self._buf("news_vec" + sfx, N * d)[:N * d].view(N, d)
+        p = float(p_drop)
         p_embed = 0.0 if self.dims.style == "v1" else p        # nrms_v1 has no embedding dropout (nrms_v1.py:159-161)
-        self.encode_titles(flat, ids, out=nv, p_embed=p_embed, p_ctx=p, seed=seed, save=training)
+        self.encode_titles(flat, ids, out=nv, p_embed=p_embed, p_ctx=p, seed=seed, save=training, tag="news" + sfx,
+                           trusted_ids=True)
         hist = nv[:B * H].view(B, H, d)
         cand = nv[B * H:].view(B, Cn, d)
-        user = self._buf("user_vec", B * d)[:B * d].view(B, d)
-        self.encode_users(flat, hist, out=user, save=training, mask=user_mask, mask_mode=user_mask_mode)
+        user = self._buf("user_vec" + sfx, B * d)[:B * d].view(B, d)
+        self.encode_users(flat, hist, out=user, save=training, tag="user" + sfx, mask=user_mask, mask_mode=user_mask_mode)
         if cand_mask is not None:
             cand_mask = cand_mask.contiguous()
         scores = torch.empty(B, Cn, dtype=torch.float32, device=self.device)
         self.click_scores(cand, user, cand_mask, out=scores)
         if training:
+            self._gen += 1
             self._saved = dict(B=B, H=H, C=Cn, L=L, ids=ids, nv=nv, user=user, mask=cand_mask, p=p, p_embed=p_embed,
-                               seed=seed, user_mask=user_mask, user_mask_mode=user_mask_mode if user_mask is not None else 0)
-        else:
-            self._saved = None
+                               seed=seed, user_mask=user_mask, user_mask_mode=user_mask_mode if user_mask is not None else 0,
+                               gen=self._gen)
         return scores
 
     def ce_loss(self, scores, grad_scale=None, want_grad=True):
@@ -269,10 +356,10 @@ class NRMSEngine:
         B, H, d = news_vectors.shape
         if dx is None:
             dx = torch.empty(B * H, d, dtype=torch.float32, device=self.device)
-        desc = self._desc("user_encoder", B, H, mask_mode=mask_mode if mask is not None else 0)
+        desc = self._desc("user_encoder", B, H, mask_mode=mask_mode if mask is not None else 0, training=True)
         ws = self._bwd_workspace(desc)
         w, g = self._weights(flat, "user_encoder"), self._grads(gflat, "user_encoder")
-        acts = self._acts(tag, B * H, True)
+        acts = self._acts(tag, B * H, True, desc=desc)
         rc = self.lib.nrms_encoder_bwd(C.byref(desc), C.byref(w), None, _lib.ptr(news_vectors),
                                        _lib.ptr(None if mask is None else mask.contiguous()), C.byref(acts),
                                        _lib.ptr(dout.contiguous()), C.byref(g), _lib.ptr(dx), _lib.ptr(ws),
@@ -281,8 +368,10 @@ class NRMSEngine:
         return dx[:B * H].view(B, H, d)
 
     # ---- full model backward ------------------------------------------------------------
-    def backward(self, flat, gflat, dscores, table_grad_ready=None):
+    def backward(self, flat, gflat, dscores, table_grad_ready=None, gen=None):
         """Accumulates d(loss)/d(params) into gflat (same layout as flat) given dscores [B,C].
+        gen: the generation stamp of the training forward this backward belongs to (saved activations are one
+        slot: a later training forward replaces them, and a backward for the earlier one must not run on them).
 
         table_grad_ready: optional callable invoked as soon as the embedding-table gradient (95 % of the
         gradient bytes) is complete on the stream; the news encoder's d(W_qkv) GEMM is then deferred behind
@@ -290,6 +379,9 @@ class NRMSEngine:
         sv = self._saved
         if sv is None:
             raise _lib.NrmsError("backward() without a training forward()")
+        if gen is not None and gen != sv["gen"]:
+            raise _lib.NrmsError("backward() for training forward #%d, but the saved activations belong to forward #%d: "
+                                 "a later training forward replaced them (one forward/backward pair at a time)" % (gen, sv["gen"]))
         B, H, Cn, L = sv["B"], sv["H"], sv["C"], sv["L"]
         d = self.dims.word_embed_size
         N = B * (H + Cn)
@@ -304,13 +396,13 @@ class NRMSEngine:
                                            _stream())
         _lib.check(rc, "nrms_click_score_bwd")
         # user encoder: its input gradient lands directly in the history rows of d(news vectors)
-        desc_u = self._desc("user_encoder", B, H, mask_mode=sv["user_mask_mode"])
-        desc_n = self._desc("news_encoder", N, L, sv["p_embed"], sv["p"], sv["seed"])
+        desc_u = self._desc("user_encoder", B, H, mask_mode=sv["user_mask_mode"], training=True)
+        desc_n = self._desc("news_encoder", N, L, sv["p_embed"], sv["p"], sv["seed"], training=True)
         ws = self._bwd_workspace(desc_u, desc_n)
-        self.encode_users_backward(flat, gflat, hist.view(B, H, d), duser, dx=dnv, mask=sv["user_mask"],
+        self.encode_users_backward(flat, gflat, hist.view(B, H, d), duser, dx=dnv, tag="user", mask=sv["user_mask"],
                                    mask_mode=sv["user_mask_mode"])
         wn, gn = self._weights(flat, "news_encoder"), self._grads(gflat, "news_encoder")
-        acts_n = self._acts("news", N * L, True, gather=True)
+        acts_n = self._acts("news", N * L, True, gather=True, desc=desc_n)
         if table_grad_ready is not None:
             desc_n.flags |= _lib.NRMS_FLAG_DEFER_WQKV
         rc = self.lib.nrms_encoder_bwd(C.byref(desc_n), C.byref(wn), _lib.ptr(sv["ids"]), None, None, C.byref(acts_n),
@@ -340,6 +432,23 @@ class NRMSEngine:
         return auc
 
     # ---- inference with unique-title caching (SURVEY f-1) -------------------------------------
+    def unique_titles(self, ids):
+        """ids [N, L] -> (representative titles [U, L], inverse [N]) with ids == uniq[inverse].  Titles are
+        grouped by a 64-bit device hash of their word ids (nrms_title_keys) -- a 1-D radix sort of N keys instead
+        of a lexicographic sort of N x L words -- and the grouping is verified against the representatives; on a
+        hash collision (never observed; ~N^2 / 2^65) the exact row-wise unique takes over."""
+        N, L = ids.shape
+        keys = torch.empty(N, dtype=torch.int64, device=self.device)
+        rc = self.lib.nrms_title_keys(_lib.ptr(ids), C.c_int64(N), int(L), _lib.ptr(keys), _stream())
+        _lib.check(rc, "nrms_title_keys")
+        ukeys, inverse = torch.unique(keys, return_inverse=True)
+        rep = torch.empty(ukeys.shape[0], dtype=torch.int64, device=self.device)
+        rep.scatter_(0, inverse, torch.arange(N, device=self.device))       # any member represents its group
+        uniq = ids.index_select(0, rep)
+        if not bool((uniq.index_select(0, inverse) == ids).all().item()):
+            uniq, inverse = torch.unique(ids, dim=0, return_inverse=True)
+        return uniq, inverse
+
     def forward_dedup(self, flat, hist_ids, cand_ids, cand_mask):
         """Same scores as forward(training=False), but every distinct title of the batch is encoded
         once (the reference encodes all B*(H+C) slots, 350 per user at C=300, most of them padding
@@ -347,16 +456,75 @@ class NRMSEngine:
         B, H, L = hist_ids.shape
         Cn = cand_ids.shape[1]
         d = self.dims.word_embed_size
-        ids = torch.cat([hist_ids.reshape(B * H, L), cand_ids.reshape(B * Cn, L)], dim=0)
-        uniq, inverse = torch.unique(ids, dim=0, return_inverse=True)
-        vec = self.encode_titles(flat, uniq, tag="news_eval")
+        N = B * (H + Cn)
+        self.poll_ids()
+        ids = self._buf("ids_eval", N * L, torch.int64)[:N * L].view(N, L)
+        self.sanitize_ids(hist_ids.reshape(B * H, L).contiguous(), ids[:B * H])
+        self.sanitize_ids(cand_ids.reshape(B * Cn, L).contiguous(), ids[B * H:])
+        uniq, inverse = self.unique_titles(ids)
+        vec = self.encode_titles(flat, uniq, tag="news_eval", trusted_ids=True)
         nv = vec.index_select(0, inverse)
-        hist = nv[:B * H].view(B, H, d).contiguous()
-        cand = nv[B * H:].view(B, Cn, d).contiguous()
+        hist = nv[:B * H].view(B, H, d)
+        cand = nv[B * H:].view(B, Cn, d)
         user = self.encode_users(flat, hist, tag="user_eval")
         if cand_mask is not None:
             cand_mask = cand_mask.contiguous()
         return self.click_scores(cand, user, cand_mask), int(uniq.shape[0])
+
+    # persistent news-vector cache across evaluation batches, keyed by the news ids the batch dict carries
+    # (browsed_ids / candidate_ids, data_handler.py:204-222; 0 = padding slot = all-padding title)
+    def news_cache_begin(self, capacity=1 << 16):
+        d = self.dims.word_embed_size
+        self._news_cache = dict(vec=torch.zeros(capacity, d, dtype=torch.float32, device=self.device),
+                                have=torch.zeros(capacity, dtype=torch.bool, device=self.device), encoded=0, hits=0)
+
+    def news_cache_end(self):
+        st = getattr(self, "_news_cache", None)
+        self._news_cache = None
+        return None if st is None else dict(encoded=st["encoded"], lookups=st["hits"])
+
+    def forward_cached(self, flat, hist_ids, cand_ids, hist_news, cand_news, cand_mask):
+        """forward(training=False) for batches that carry news ids: a news item is encoded the first time it is
+        seen during the evaluation (weights are constant between news_cache_begin / news_cache_end) and looked up
+        afterwards -- the offline news-vector caching get_news_vector exists for (nrms_v0.py:278-289)."""
+        st = self._news_cache
+        B, H, L = hist_ids.shape
+        Cn = cand_ids.shape[1]
+        d = self.dims.word_embed_size
+        N = B * (H + Cn)
+        news = torch.cat([hist_news.reshape(-1), cand_news.reshape(-1)]).to(torch.int64)
+        top = int(news.max().item()) + 1 if N else 1
+        if top > st["vec"].shape[0]:                                  # grow (amortised doubling)
+            cap = max(top, 2 * st["vec"].shape[0])
+            vec = torch.zeros(cap, d, dtype=torch.float32, device=self.device)
+            have = torch.zeros(cap, dtype=torch.bool, device=self.device)
+            vec[:st["vec"].shape[0]] = st["vec"]
+            have[:st["have"].shape[0]] = st["have"]
+            st["vec"], st["have"] = vec, have
+        if int(news.min().item()) < 0:
+            raise _lib.NrmsError("negative news id in browsed_ids / candidate_ids")
+        u, inv = torch.unique(news, return_inverse=True)
+        missing = u[~st["have"].index_select(0, u)]
+        if missing.numel():
+            rep = torch.empty(u.shape[0], dtype=torch.int64, device=self.device)
+            rep.scatter_(0, inv, torch.arange(N, device=self.device))
+            slot = torch.full((st["vec"].shape[0],), -1, dtype=torch.int64, device=self.device)
+            slot[u] = rep
+            rows = slot.index_select(0, missing)                       # a slot of the batch holding each missing news item
+            titles = torch.where((rows < B * H).unsqueeze(1),
+                                 hist_ids.reshape(B * H, L).index_select(0, rows.clamp(max=B * H - 1)),
+                                 cand_ids.reshape(B * Cn, L).index_select(0, (rows - B * H).clamp(min=0)))
+            st["vec"].index_copy_(0, missing, self.encode_titles(flat, titles.contiguous(), tag="news_eval"))
+            st["have"][missing] = True
+            st["encoded"] += int(missing.numel())
+        st["hits"] += N
+        nv = st["vec"].index_select(0, news)
+        hist = nv[:B * H].view(B, H, d)
+        cand = nv[B * H:].view(B, Cn, d)
+        user = self.encode_users(flat, hist, tag="user_eval")
+        if cand_mask is not None:
+            cand_mask = cand_mask.contiguous()
+        return self.click_scores(cand, user, cand_mask)
 
     def dropout_keep_mask(self, seed, site, n_rows, p_drop):
         d = self.dims.word_embed_size

@@ -1,5 +1,6 @@
-"""Ranking metrics with the reference's signatures (/root/reference/MIND_2020/evaluation.py:6-27).
-``auc_score`` is what ``evaluate`` uses (train_eval.py:219-227); the reference delegates to
+"""``auc_score`` with the reference's signature (/root/reference/MIND_2020/evaluation.py:26-27) -- the only
+metric on the path (the reference's dcg / ndcg / mrr helpers are unused by ``evaluate``: SURVEY section 2, out of scope).
+It is what ``evaluate`` uses (train_eval.py:219-227); the reference delegates to
 sklearn.metrics.roc_auc_score -- here it is the same Mann-Whitney statistic in numpy float64
 (host) and in the HIP kernel ``nrms_impression_auc`` (device, used by train_eval.evaluate)."""
 import numpy as np
@@ -15,22 +16,3 @@ def auc_score(y_true, y_pred):
     greater = np.searchsorted(neg_sorted, pos, side="left")          # negatives strictly below each positive
     equal = np.searchsorted(neg_sorted, pos, side="right") - greater
     return float((greater.sum() + 0.5 * equal.sum()) / (pos.size * neg.size))
-
-
-def dcg_score(y_true, y_score, k=10):
-    order = np.argsort(y_score)[::-1]
-    y_true = np.take(y_true, order[:k])
-    gains = 2 ** y_true - 1
-    discounts = np.log2(np.arange(len(y_true)) + 2)
-    return np.sum(gains / discounts)
-
-
-def ndcg_score(y_true, y_score, k=10):
-    return dcg_score(y_true, y_score, k) / dcg_score(y_true, y_true, k)
-
-
-def mrr_score(y_true, y_score):
-    order = np.argsort(y_score)[::-1]
-    y_true = np.take(y_true, order)
-    rr_score = y_true / (np.arange(len(y_true)) + 1)
-    return np.sum(rr_score) / np.sum(y_true)

@@ -85,14 +85,25 @@ class _NRMSFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, bt, ct, mask, p_drop, seed, *params):
         ctx.model = model
-        return model._engine.forward(model._flat, bt, ct, mask, training=True, p_drop=p_drop, seed=seed)
+        scores = model._engine.forward(model._flat, bt, ct, mask, training=True, p_drop=p_drop, seed=seed)
+        ctx.gen = model._engine._saved["gen"]
+        return scores
 
     @staticmethod
     def backward(ctx, dscores):
         model = ctx.model
-        # fresh buffer per backward: autograd may keep the returned views as .grad
-        gflat = torch.zeros_like(model._flat)
-        model._engine.backward(model._flat, gflat, dscores)
+        # ONE persistent flat gradient buffer (57.6 MB at V = 45 800) in the reference's loop, where
+        # model.zero_grad() has set every .grad to None (train_eval.py:115): autograd then adopts the returned views
+        # as .grad, and the next backward may reuse the buffer.  When gradients are being accumulated (.grad still
+        # set, possibly aliasing the buffer) a fresh buffer is used so that nothing autograd holds is overwritten.
+        accumulating = any(p.grad is not None for p in model.parameters())
+        gflat = None if accumulating else model._autograd_grad
+        if gflat is None or gflat.shape != model._flat.shape or gflat.device != model._flat.device:
+            gflat = torch.empty_like(model._flat)
+            if not accumulating:
+                model._autograd_grad = gflat
+        gflat.zero_()
+        model._engine.backward(model._flat, gflat, dscores, gen=ctx.gen)
         grads = tuple(model._layout.view(gflat, n) for n in model._names)
         return (None, None, None, None, None, None) + grads
 
@@ -119,7 +130,12 @@ class Model(nn.Module):
         self._engine = None
         self._opt = None
         self._calls = 0
+        self._autograd_grad = None
         self._flatten(table.device)
+        # a load through ANY parent (the dispatch wrapper of model/__init__.py included) may change the embedding
+        # table: nn.Module.load_state_dict recurses via _load_from_state_dict and never calls a child's
+        # load_state_dict, so the reset lives in a post-hook, which fires on recursive loads too
+        self.register_load_state_dict_post_hook(Model._reset_pad_flag)
 
     # ---- topology hooks (overridden by model/nrms_v1_hip.py) ---------------------------------------
     def _build_modules(self, config, table):
@@ -143,10 +159,9 @@ class Model(nn.Module):
         self._opt = None
         self._pad_zero = None
 
-    def load_state_dict(self, *args, **kwargs):
-        out = super().load_state_dict(*args, **kwargs)
-        self._pad_zero = None                      # the embedding table may have changed
-        return out
+    @staticmethod
+    def _reset_pad_flag(module, incompatible_keys):
+        module._pad_zero = None                    # the embedding table may have changed
 
     def refresh_pad_row_flag(self):
         """Re-evaluate NRMS_FLAG_PAD_ROW_ZERO (include/nrms_hip.h) after writing into the embedding table by
@@ -208,9 +223,14 @@ class Model(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _NRMSFunction.apply(self, bt, ct, mask, p_drop, seed, *params)
         if p_drop == 0.0 and getattr(self, "dedup_inference", True):
+            get = batch.get if hasattr(batch, "get") else (lambda k: None)
+            bn, cn = get("browsed_ids"), get("candidate_ids")
+            if self._engine._news_cache is not None and bn is not None and cn is not None:
+                # inside train_eval.evaluate / test: news vectors are cached across batches by news id
+                return self._engine.forward_cached(self._flat, bt, ct, torch.as_tensor(bn).to(dev), torch.as_tensor(cn).to(dev), mask)
             scores, self.last_unique_titles = self._engine.forward_dedup(self._flat, bt, ct, mask)
             return scores
-        return self._engine.forward(self._flat, bt, ct, mask, training=False)
+        return self._engine.forward(self._flat, bt, ct, mask, training=False, p_drop=p_drop, seed=seed)
 
     def _ordered_params(self):
         named = dict(self.named_parameters())

@@ -3,12 +3,14 @@
     python -m pytorch_news_recommender_amd.run_v0 --model nrms_hip --dataset synthetic
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m pytorch_news_recommender_amd.run_v0 ...
 
-``--dataset large|demo`` expects the reference's preprocessed files under config.data_path;
-``--dataset synthetic`` fabricates a MIND-shaped corpus (no data ships offline).
+``--dataset large|demo`` reads what the reference's preprocessing leaves under config.data_path
+(idx_train_datas.pkl / idx_dev_datas.pkl, news_title.pkl or news_words.csv, dev_behaviors.csv:
+data_handler.py:43-135, train_eval.py:36-39); ``--dataset synthetic`` fabricates a MIND-shaped corpus (no
+data ships offline).  ``--batch_size`` (not a reference flag; its scripts hard-code 512 / 256, run_v0.py:44,
+run_demo.py:28) lets BASELINE config 0 (batch 32) run through the same entry.
 """
 import argparse
 import os
-import pickle
 import time
 
 import numpy as np
@@ -17,7 +19,7 @@ from torch.utils.data import DataLoader
 
 from . import parallel
 from .config import Config
-from .data_handler import MyDataset, SyntheticMind, load_dataset
+from .data_handler import MyDataset, SyntheticMind, load_dataset, read_dev_labels
 from .model import Model
 from .train_eval import test, train
 
@@ -33,6 +35,11 @@ def build_parser():
     parser.add_argument('--epochs', type=int, default=None)
     parser.add_argument('--max_batches', type=int, default=None)
     parser.add_argument('--synthetic_users', type=int, default=20480)
+    parser.add_argument('--batch_size', type=int, default=512)
+    parser.add_argument('--precision', type=str, default=None, help='fp32 | bf16x3 | bf16 | fp16 (HIP path)')
+    parser.add_argument('--num_workers', type=int, default=6)
+    parser.add_argument('--data_path', type=str, default=None, help='overrides config.data_path (./data_processed/)')
+    parser.add_argument('--save_path', type=str, default=None, help='overrides config.save_path (./save_model/)')
     return parser
 
 
@@ -43,9 +50,16 @@ def main(argv=None):
     torch.cuda.manual_seed_all(422)
     model_name = args.model + '_' + (args.description or time.strftime('%m-%d_%H'))
     config = Config(model_name)
-    config.batch_size = 512
+    config.batch_size = args.batch_size
+    if args.precision:
+        config.precision = args.precision
     config.num_epochs = 6 if args.epochs is None else args.epochs
     config.mode = args.dataset
+    if args.data_path:
+        config.data_path = os.path.join(args.data_path, '')
+    if args.save_path:
+        config.save_path = os.path.join(args.save_path, '')
+        config.log_path = os.path.join(args.save_path, 'logs', model_name)
     config.__nrms__()
 
     if args.dataset == 'synthetic':
@@ -60,36 +74,47 @@ def main(argv=None):
         train_samples = corpus.train_samples(args.synthetic_users)
         dev_samples, dev_labels = corpus.eval_samples(1024)
     else:
-        with open(os.path.join(config.data_path, 'id2title_dict.pkl'), 'rb') as f:
-            titles = pickle.load(f)
-        train_samples = load_dataset(config, config.train_data, config.data_path, _type=0)
-        dev_samples = load_dataset(config, config.dev_data, config.data_path, _type=1)[:100000]
-        with open(os.path.join(config.data_path, 'dev_labels.pkl'), 'rb') as f:
-            dev_labels = pickle.load(f)
+        if args.dataset == 'demo':
+            config.word_embedding_pretrained = 'demo_word_embedding.npz'       # run_demo.py:31
+        titles = None                                  # MyDataset loads news_title.pkl / news_words.csv itself
+        demo = args.dataset == 'demo'
+        train_samples = load_dataset(config, 'small_train.pkl' if demo else config.train_data, config.data_path, _type=0)
+        dev_samples = load_dataset(config, 'small_dev.pkl' if demo else config.dev_data, config.data_path, _type=1)[:100000]
+        dev_labels = read_dev_labels(config)
 
     recommender = Model(config, args)
     if world > 1:
         recommender.model._rank_salt = rank * 0x632BE59BD9B4E019
         recommender.model.engine
         parallel.broadcast_parameters(recommender.model._flat)
-        lo, hi = parallel.shard_rows(len(train_samples), rank, world)
-        train_samples = train_samples[lo:hi]
+        # every rank: the same number of equal-sized batches (the gradient all-reduce is collective and the loss is
+        # the mean over world * batch_size users): equal shards, incomplete last batches dropped
+        per_rank = len(train_samples) // world
+        train_samples = train_samples[rank * per_rank:(rank + 1) * per_rank]
     if rank == 0:
         print(model_name, config.device, sum(p.numel() for p in recommender.parameters()), 'parameters')
 
     def loader(samples, typ, shuffle):
         return DataLoader(MyDataset(config, samples, type=typ, id2title_dict=titles), batch_size=config.batch_size,
-                          num_workers=6, drop_last=False, shuffle=shuffle, pin_memory=True)
+                          num_workers=args.num_workers, drop_last=(world > 1 and typ == 0), shuffle=shuffle,
+                          pin_memory=True)
 
     if not args.test:
         hist = train(config, recommender, loader(train_samples, 0, True), loader(dev_samples, 1, False), dev_labels,
                      max_batches=args.max_batches, verbose=rank == 0)
         if rank == 0:
             print('final dev AUC:', hist['aucs'][-1] if hist['aucs'] else None)
+        return hist
     else:
-        recommender.load_state_dict(torch.load(os.path.join(config.save_path, args.load), weights_only=True))
-        out = test(config, recommender, loader(dev_samples, 1, False), [len(y) for y in dev_labels])
+        # run_v0.py:93-111: the test set through the checkpoint named by --load (or the best one by file-name AUC)
+        if args.dataset == 'synthetic':
+            test_samples, shown = dev_samples, [len(y) for y in dev_labels]
+        else:
+            test_samples, shown = load_dataset(config, config.test_data, config.data_path, _type=1), None
+        out = test(config, recommender, loader(test_samples, 1, False), shown, ckpt_file=args.load,
+                   pick_best=args.load is None)
         print('saved to', out)
+        return out
 
 
 if __name__ == '__main__':

@@ -177,6 +177,25 @@ def make_eval_impressions(n_imp: int, max_cand: int, seed: int = 7, min_cand: in
     return scores, labels
 
 
+def dataset_fixture_inputs():
+    """Hand-written samples for the MyDataset fixture (tests/golden/g6_dataset.npz): the positional sample
+    format of data_handler.py:206-231, news indices 1-based, ``id2title_dict[news - 1]`` = padded word ids."""
+    cfg = dict(history_len=5, n_words_title=4, n_words_abst=3, sample_size=2, max_candidate_size=6, batch_size=2)
+    titles = {0: [11, 12, 0, 0], 1: [21, 0, 0, 0], 2: [31, 32, 33, 34], 3: [41, 42, 43, 0], 4: [51, 52, 0, 0],
+              5: [61, 0, 0, 0]}
+    absts = {i: [100 + i, 200 + i, 0] for i in range(6)}
+    train = [
+        # history, categ, subcateg, impressions (positive first), imp categ, imp subcateg
+        [[3, 1], [2, 1], [5, 4], [2, 4, 5], [1, 2, 3], [7, 8, 9]],
+        [[6, 5, 4, 3, 2], [1, 1, 2, 2, 3], [4, 4, 5, 5, 6], [1, 6, 3, 2, 5], [3, 2, 1], [9, 8, 7]],   # imps cut to sample_size+1
+    ]
+    evals = [
+        [[2], [3], [6], [1, 2, 3, 4], [1, 1, 2, 2], [4, 5, 6, 7]],
+        [[1, 2, 3, 4, 5], [1, 2, 3, 1, 2], [4, 5, 6, 4, 5], [6, 5, 4, 3, 2, 1], [3, 3, 2, 2, 1, 1], [9, 9, 8, 8, 7, 7]],
+    ]
+    return dict(config=cfg, id2title_dict=titles, id2abst_dict=absts, train_samples=train, eval_samples=evals)
+
+
 def make_params_v1(shape: Shape, seed: int = 0):
     """Parameters with nrms_v1's names (model/nrms_v1.py:54-55,87,115): linear_layers.{0,1,2},
     output_linear (W_O), query_vector; same initial distributions as make_params."""

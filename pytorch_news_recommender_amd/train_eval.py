@@ -38,18 +38,31 @@ def _pad_labels(y_true, max_c, device):
     return torch.from_numpy(lab).to(device), torch.from_numpy(lens).to(device)
 
 
-def evaluate(config, model, data_iter, y_true, AUC_best=None, verbose=True):
+def evaluate(config, model, data_iter, y_true=None, AUC_best=None, verbose=True):
     """y_true: list (one entry per impression, in data_iter order) of 0/1 label lists -- the
-    reference keeps it in the module global ``_y_true`` read from dev_behaviors.csv (:36-39)."""
+    reference keeps it in the module global ``_y_true`` read from dev_behaviors.csv (:36-39); None reads
+    that file (data_handler.read_dev_labels).
+
+    Deviation, on purpose: the reference calls ``model.eval()`` here and never ``model.train()`` again (its
+    re-enable is commented out, train_eval.py:122,230), so after its first evaluation it trains with dropout
+    off.  This evaluate() restores the mode it found."""
+    if y_true is None:
+        from .data_handler import read_dev_labels
+        y_true = read_dev_labels(config)
     net = _inner(model)
     was_training = net.training
     net.eval()
     scores = []
-    with torch.no_grad():
-        for datas in data_iter:
-            scores.append(net(datas))
-    rank_score = torch.cat(scores, dim=0)
     eng = net.engine
+    eng.news_cache_begin()                     # weights are constant from here to the end of the evaluation
+    try:
+        with torch.no_grad():
+            for datas in data_iter:
+                scores.append(net(datas))
+    finally:
+        net.last_eval_cache = eng.news_cache_end()
+    rank_score = torch.cat(scores, dim=0)
+    eng.check_ids()
     lab, lens = _pad_labels(y_true[:rank_score.shape[0]], rank_score.shape[1], rank_score.device)
     aucs = eng.impression_auc(rank_score, lab, lens)
     AUC = float(aucs.mean().item())
@@ -60,6 +73,8 @@ def evaluate(config, model, data_iter, y_true, AUC_best=None, verbose=True):
 
 
 def log_res(config, step, auc):
+    if parallel.env_world()[0] != 0:             # one writer: every rank computes the same dev AUC
+        return
     os.makedirs(config.log_path, exist_ok=True)
     with open(os.path.join(config.log_path, 'res.txt'), 'a+') as f:
         f.write('{}_{}_:auc_{}\n'.format(time.strftime('%m-%d_%H.%M'), auc, step))
@@ -149,6 +164,7 @@ def train(config, model, train_iter, dev_iter=None, dev_labels=None, use_autogra
                 window.append(loss_sum / B)
             if total_batch % STEP_SIZE == 0:                 # one host sync per 100 iterations, not two per step
                 vals = [float(v) for v in window]
+                net.engine.check_ids()                       # out-of-range word ids of the last 100 steps surface here
                 hist['losses'].extend(vals)
                 window = []
                 if verbose:
@@ -189,16 +205,47 @@ def _cal_test(scores, n):
     return rank
 
 
-def test(config, model, data_iter, test_list_nums, ckpt_file=None, out_file=None):
-    """Writes ``<impression index> [r1,r2,...]`` lines; returns the file name."""
+def best_checkpoint(config):
+    """The checkpoint of this model name with the highest dev AUC in its file name
+    (``..._auc_0.673.ckpt``, written by train(); selection rule of train_eval.py:303-308, parsed as a float
+    instead of ``eval``).  None if there is none above 0.5."""
+    best, best_auc = None, 0.5
+    if not os.path.isdir(config.save_path):
+        return None
+    for ckpt in sorted(os.listdir(config.save_path)):
+        if config.model_name not in ckpt or not ckpt.endswith('.ckpt'):
+            continue
+        try:
+            auc = float(ckpt[:-len('.ckpt')].split('_')[-1])
+        except ValueError:
+            continue
+        if auc > best_auc:
+            best, best_auc = ckpt, auc
+    return best
+
+
+def test(config, model, data_iter, test_list_nums=None, ckpt_file=None, out_file=None, pick_best=False):
+    """Writes ``<impression index> [r1,r2,...]`` lines; returns the file name.  test_list_nums: shown
+    candidates per impression (None: data_handler.get_Test_List, train_eval.py:287-298,315); pick_best: load the
+    best checkpoint by file-name AUC when ckpt_file is None (train_eval.py:301-310)."""
     net = _inner(model)
+    if ckpt_file is None and pick_best:
+        ckpt_file = best_checkpoint(config)
     if ckpt_file is not None:
         model.load_state_dict(torch.load(os.path.join(config.save_path, ckpt_file), weights_only=True))
+    if test_list_nums is None:
+        from .data_handler import get_Test_List
+        test_list_nums = get_Test_List(config)
     net.eval()
     scores = []
-    with torch.no_grad():
-        for datas in data_iter:
-            scores.append(net(datas).cpu())
+    net.engine.news_cache_begin()
+    try:
+        with torch.no_grad():
+            for datas in data_iter:
+                scores.append(net(datas).cpu())
+    finally:
+        net.engine.news_cache_end()
+    net.engine.check_ids()
     test_rank_score = np.concatenate([s.numpy() for s in scores])
     ranks = [_cal_test(test_rank_score[i], int(n)) for i, n in enumerate(test_list_nums[:len(test_rank_score)])]
     file_name = out_file or 'sumbit_{}_{}.txt'.format(config.model_name, time.strftime('%m-%d_%H.%M', time.localtime()))

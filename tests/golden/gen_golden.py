@@ -20,6 +20,10 @@ reference's own classes:
   g4_auc.npz    evaluation.auc_score per padded impression + the mean (train_eval.py:219-271).
   g5_adam.npz   nrms_v0 + torch.optim.Adam(lr=1e-3) for 3 steps, dropout=0: losses and the
                 parameters afterwards (64 sampled table rows).
+  g6_dataset.npz  the batch-dict items of the reference's own ``MyDataset.__getitem__``
+                (data_handler.py:185-250; ``np.int = int`` shim for numpy 2, stub ``nltk``) on the
+                hand-written samples of ``synth.dataset_fixture_inputs()``: all 13 keys, train (type 0)
+                and evaluation (type 1) padding.
 
 The reference is imported, never copied; no reference source text is written anywhere.
 """
@@ -219,6 +223,45 @@ def gen_g5():
     print("g5", losses)
 
 
+def gen_g6():
+    """MyDataset.__getitem__ of the imported reference on hand-written samples."""
+    import pickle
+    if "nltk" not in sys.modules:                       # data_handler -> data_processor imports nltk.tokenize;
+        nltk = types.ModuleType("nltk")                 # neither is touched by MyDataset
+        tok = types.ModuleType("nltk.tokenize")
+        tok.word_tokenize = lambda s: s.split()
+        tok.RegexpTokenizer = type("RegexpTokenizer", (), {})
+        nltk.tokenize = tok
+        sys.modules["nltk"], sys.modules["nltk.tokenize"] = nltk, tok
+    if not hasattr(np, "int"):
+        np.int = int                                    # data_handler.py:191-204 predates numpy 1.24
+    import data_handler as ref_dh
+    from config import Config
+    fx = synth.dataset_fixture_inputs()
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "news_title.pkl"), "wb") as f:
+            pickle.dump(fx["id2title_dict"], f)
+        with open(os.path.join(td, "news_abst.pkl"), "wb") as f:
+            pickle.dump(fx["id2abst_dict"], f)
+        cfg = Config("g6")
+        cfg.data_path = td + "/"
+        cfg.mode = "large"
+        for k, v in fx["config"].items():
+            setattr(cfg, k, v)
+        for typ, samples in ((0, fx["train_samples"]), (1, fx["eval_samples"])):
+            ds = ref_dh.MyDataset(cfg, samples, type=typ)
+            assert len(ds) == len(samples)
+            for i in range(len(samples)):
+                item = ds[i]
+                assert len(item) == 13
+                for key, val in item.items():
+                    arr = val.numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+                    out["type%d/%d/%s" % (typ, i, key)] = arr
+    np.savez_compressed(os.path.join(HERE, "g6_dataset.npz"), **out)
+    print("g6", len(out), "arrays")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not present: fixtures can only be generated in the build container"
     sys.path.insert(0, REF)
@@ -228,6 +271,6 @@ if __name__ == "__main__":
     with tempfile.TemporaryDirectory() as td:
         os.chdir(td)            # the reference writes nothing, but keep its relative paths away from the repo
         try:
-            gen_g1(); gen_g2(); gen_g3(); gen_g4(); gen_g5()
+            gen_g1(); gen_g2(); gen_g3(); gen_g4(); gen_g5(); gen_g6()
         finally:
             os.chdir(cwd)

@@ -99,6 +99,13 @@ def test_train_evaluate_checkpoint_loop(tmp_path):
     m2 = Model(cfg, pretrained_word_embedding=corpus.embedding_table(cfg.word_embed_size)).to("cuda")
     m2.load_state_dict(sd)
     assert abs(train_eval.evaluate(cfg, m2, dl, dev_labels, verbose=False) - auc1) < 1e-9
+    # the evaluation above ran on the persistent news-vector cache (the batch dicts carry news ids): every news
+    # item was encoded once for the whole dev set; the plain path (every slot encoded) gives the same AUC
+    stats = m2.last_eval_cache
+    assert stats["encoded"] <= 301 and stats["lookups"] == 256 * (10 + 24), stats
+    m2.dedup_inference = False
+    assert abs(train_eval.evaluate(cfg, m2, dl, dev_labels, verbose=False) - auc1) < 1e-6
+    m2.dedup_inference = True
     out = train_eval.test(cfg, m2, dl, [len(y) for y in dev_labels], out_file=str(tmp_path / "sub.txt"))
     first = open(out).readline().split(" ", 1)
     assert first[0] == "1" and sorted(eval(first[1])) == list(range(1, len(dev_labels[0]) + 1))
@@ -139,3 +146,68 @@ def test_warmup_phase_against_oracle():
         if n.endswith("W_K.bias"):
             continue
         assert_params_close(sd[n], p[n], n)
+
+
+def test_eval_c300_scores_and_auc_against_oracle():
+    """End to end at the evaluation shape (C = max_candidate_size = 300 padded candidate slots, most of them
+    padding or repeats: data_handler.py:174-177): batch dict -> Model.forward in eval mode (unique-title path,
+    title keys hashed on the device) -> per-impression AUC kernel, against the oracle's scores and its
+    rank-statistic AUC on the same impressions."""
+    from oracle import nrms_oracle as orc
+    from pytorch_news_recommender_amd import train_eval
+    shape = synth.Shape(n_words=500, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=6, history_len=50, n_candidates=300, n_words_title=30)
+    params = synth.make_params(shape, seed=41)
+    rng = np.random.default_rng(42)
+    B, H, C, L = 6, 50, 300, 30
+    # a small corpus so that titles repeat across users and slots, as real impressions do
+    corpus = rng.integers(1, shape.n_words, size=(120, L))
+    corpus = np.where(np.arange(L)[None, :] < rng.integers(4, L + 1, size=(120, 1)), corpus, 0)
+    hist_len = rng.integers(3, H + 1, size=B)
+    shown = rng.integers(8, 60, size=B)
+    bt = np.zeros((B, H, L), dtype=np.int64)
+    ct = np.zeros((B, C, L), dtype=np.int64)
+    cm = np.zeros((B, C), dtype=np.uint8)
+    labels = []
+    for b in range(B):
+        bt[b, :hist_len[b]] = corpus[rng.integers(0, 120, size=hist_len[b])]
+        ct[b, :shown[b]] = corpus[rng.choice(120, size=shown[b], replace=False)]
+        cm[b, :shown[b]] = 1
+        y = (rng.random(shown[b]) < 0.2).astype(np.int64)
+        y[0], y[1] = 1, 0
+        labels.append(y.tolist())
+    batch = {"browsed_titles": bt, "candidate_titles": ct, "candidate_mask": cm}
+    model = _model(shape, params).eval()
+    with torch.no_grad():
+        scores = model({k: torch.from_numpy(v) for k, v in batch.items()}).cpu().numpy()
+    assert model.last_unique_titles <= 121 + 1                    # 120 corpus titles + the all-padding title
+    p = orc.to_torch(params)
+    with torch.no_grad():
+        o_scores, _ = orc.forward(p, batch, shape.num_attention_heads)
+    o_scores = o_scores.numpy()
+    valid = cm == 1
+    np.testing.assert_allclose(scores[valid], o_scores[valid], rtol=0, atol=1e-5)
+    assert (scores[~valid] == np.float32(-1e9)).all()
+    o_mean, o_aucs = orc.mean_impression_auc(o_scores, labels)
+    # the comparison is only meaningful where no positive/negative pair is closer than the score tolerance
+    for b in range(B):
+        s = np.sort(o_scores[b, :shown[b]])
+        assert np.diff(s).min() > 2e-5, "near-tie in the oracle scores: pick another seed"
+    auc = train_eval.evaluate(model.config, model, [{k: torch.from_numpy(v) for k, v in batch.items()}], labels,
+                              verbose=False)
+    assert abs(auc - o_mean) <= 1e-4, (auc, o_mean)               # north_star: AUC within 1e-4 (here: identical ranks)
+    assert abs(auc - o_mean) <= 1e-12
+
+
+def test_run_demo_entry_point_batch_32(tmp_path, monkeypatch):
+    """BASELINE.json config 0: the demo entry (run_demo -> run_v0.main) at batch 32, through the reference's
+    wrapper contract model.Model(config, args): a few training steps, a dev evaluation, finite loss."""
+    from pytorch_news_recommender_amd import run_demo, run_v0
+    monkeypatch.chdir(tmp_path)
+    argv = run_demo.demo_argv(["--synthetic_users", "256", "--epochs", "1", "--max_batches", "6", "--num_workers", "0",
+                               "--data_path", str(tmp_path / "data_processed"), "--save_path", str(tmp_path / "save")])
+    assert argv[argv.index("--batch_size") + 1] == "32"
+    hist = run_v0.main(argv)
+    assert len(hist["losses"]) == 6 and np.isfinite(hist["losses"]).all()
+    assert hist["aucs"] and 0.0 < hist["aucs"][-1][1] < 1.0
+    assert os.path.exists(tmp_path / "data_processed" / "all_word_embedding_v3.npz")

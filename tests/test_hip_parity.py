@@ -1,9 +1,13 @@
 """Parity of the HIP path (through the drop-in Model and the C ABI) against the golden fixtures
-generated from the imported reference, and against the oracle on seeded inputs.
+generated from the imported reference, and against the oracle on seeded inputs -- in EVERY precision mode
+the library offers for training (fp32 and the benchmarked split-bf16 mode; the reduced modes get their own
+test further down).
 
-Tolerances (fp32 MFMA path): scores / vectors 1e-5 absolute (north_star asks 1e-4), gradients
-rtol 1e-3 + atol 2e-6 (fp32, different summation order; embedding-gradient rows are float
-atomic sums)."""
+Tolerances, stated once (TOL):
+  scores / vectors / loss : absolute (north_star asks 1e-4);
+  gradients               : |got - ref| <= g_rtol |ref| + g_atol + g_scale max|ref| per tensor
+                            (fp32: summation order only; bf16x3: ~2^-16 relative per product on top).
+"""
 import os
 
 import numpy as np
@@ -14,11 +18,26 @@ from pytorch_news_recommender_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-SCORE_TOL = 1e-5
-GRAD_RTOL, GRAD_ATOL = 1e-3, 2e-6
+MODES = ["fp32", "bf16x3"]
+TOL = {
+    "fp32":   dict(score=1e-5, g_rtol=1e-3, g_atol=2e-6, g_scale=0.0),
+    "bf16x3": dict(score=2e-5, g_rtol=1e-3, g_atol=2e-6, g_scale=2e-5),     # measured: scores 4e-7 (g2), vectors of norm ~10: 1.1e-5
+}
+SCORE_TOL = TOL["fp32"]["score"]
+GRAD_RTOL, GRAD_ATOL = TOL["fp32"]["g_rtol"], TOL["fp32"]["g_atol"]
 
 
-def make_model(shape, params, dropout=0.0, device="cuda"):
+def assert_grad_close(got, ref, mode, name):
+    t = TOL[mode]
+    ref = np.asarray(ref)
+    bound = t["g_rtol"] * np.abs(ref) + t["g_atol"] + t["g_scale"] * float(np.abs(ref).max() if ref.size else 0.0)
+    diff = np.abs(np.asarray(got) - ref)
+    worst = float((diff - bound).max()) if diff.size else 0.0
+    assert worst <= 0.0, "%s [%s]: max |diff| %.3e exceeds the bound by %.3e (scale %.3e)" % (
+        name, mode, float(diff.max()), worst, float(np.abs(ref).max()))
+
+
+def make_model(shape, params, dropout=0.0, device="cuda", precision="fp32"):
     from pytorch_news_recommender_amd.config import Config
     from pytorch_news_recommender_amd.model.nrms_hip import Model
     cfg = Config("nrms_hip")
@@ -27,6 +46,7 @@ def make_model(shape, params, dropout=0.0, device="cuda"):
     cfg.num_attention_heads = shape.num_attention_heads
     cfg.query_vector_dim = shape.query_vector_dim
     cfg.dropout = dropout
+    cfg.precision = precision
     m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
     return m.to(device)
@@ -45,16 +65,29 @@ def fwd_bwd(model, batch):
     return scores.detach().cpu().numpy(), float(loss), grads
 
 
-def assert_params_close(got, want, name):
-    """Parameters after a few Adam steps.  Adam's update lr*m/(sqrt(v)+eps) is ill-conditioned
-    where |g| ~ eps=1e-8 (d(update)/dg ~ lr/eps there), so a handful of elements may move by a
-    fraction of one lr step on fp32 summation-order noise; the bulk must agree tightly."""
+ILL_CONDITIONED = ("W_K.bias", "additive_attention.linear.bias", "user_encoder.additive_attention.attention_query_vector")
+
+
+def assert_params_close(got, want, name, mode="fp32"):
+    """Parameters after a few Adam steps (lr = 1e-3) against the reference stepped by torch.optim.Adam.
+    The optimizer kernel itself is exact to 1e-7 on identical gradients (test_adam_step_kernel_alone), so what
+    is left is Adam's conditioning: update = lr * m / (sqrt(v) + eps) turns a RELATIVE gradient error r into
+    ~r * lr, except where |g| ~ eps = 1e-8, where it amplifies absolute noise by lr / eps.  Two tensors are
+    such by construction (documented in DESIGN.md section 1): W_K.bias (analytically zero gradient),
+    additive_attention.linear.bias (a cancelling sum, ~1e-2 relative fp32 noise already between the torch-CPU
+    oracle and the reference) and, on the 7-slot histories of the g5 shape, the user encoder's query vector
+    (d q = sum_s ds_s tanh(.)_s with sum_s ds_s = 0 over near-equal rows: the same cancellation; measured 1.4e-5
+    to 5.4e-5 on 2 to 16 of its 32 elements, every other tensor <= 1e-5 bar one or two elements); everything else must agree to the oracle's own bar, 1e-5 (tests/test_oracle_golden.py),
+    with a handful of near-zero-gradient elements (at most 3, or 0.2 % of a tensor) allowed up to 30 % of one step."""
     diff = np.abs(got - want)
-    # e.g. d(b_add) = sum_s ds_s q (1-T_s^2) with sum_s ds_s == 0: a cancelling sum whose fp32
-    # relative noise (~1e-2, also between the torch-CPU oracle and the reference: 5e-6 after 3 steps)
-    # Adam turns into ~1e-2 of a step.  So: bulk within 5% of one lr step, nothing beyond 30%.
-    assert np.median(diff) < 5e-5, (name, float(np.median(diff)))
-    assert diff.max() < 3e-4, (name, float(diff.max()))
+    if name.endswith(ILL_CONDITIONED):
+        assert np.median(diff) < 5e-5, (name, float(np.median(diff)))
+        assert diff.max() < 3.1e-3, (name, float(diff.max()))
+        return
+    n_bad = int((diff > 1e-5).sum())
+    print("  adam parity %-60s [%s] max %.2e  >1e-5: %d / %d" % (name, mode, float(diff.max()), n_bad, diff.size))
+    assert n_bad <= max(3, int(2e-3 * diff.size)), (name, mode, "elements off by more than 1e-5: %d of %d" % (n_bad, diff.size))
+    assert diff.max() < 3e-4, (name, mode, float(diff.max()))
 
 
 def load(golden_dir, name):
@@ -68,20 +101,22 @@ def test_library_loaded_and_native():
     assert os.path.basename(_lib.LIB_PATH) == "libnrms_hip.so"
 
 
-def test_g1_odd_golden(golden_dir):
+@pytest.mark.parametrize("mode", MODES)
+def test_g1_odd_golden(golden_dir, mode):
     g = load(golden_dir, "g1_odd.npz")
     shape = synth.G1_ODD
     params = synth.make_params(shape, seed=11, pad_row_zero=False)
     batch = synth.make_batch(shape, seed=12, ragged=True, min_title=1, empty_history_user=True,
                              all_pad_title=True, mask_some_candidates=True)
-    model = make_model(shape, params)
+    model = make_model(shape, params, precision=mode)
     model.train()                      # dropout=0: train mode == eval mode numerically
     scores, loss, grads = fwd_bwd(model, batch)
+    SCORE_TOL = TOL[mode]["score"]
     np.testing.assert_allclose(scores, g["scores"], rtol=0, atol=SCORE_TOL)
     assert abs(loss - float(g["loss"])) < SCORE_TOL
     assert (scores[batch["candidate_mask"] == 0] == np.float32(-1e9)).all()
     for n in synth.param_names():
-        np.testing.assert_allclose(grads[n], g["grad/" + n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+        assert_grad_close(grads[n], g["grad/" + n], mode, n)
     assert not grads["news_encoder.word_embedding.0.weight"][0].any()     # padding_idx = 0
     # helper API (nrms_v0.py:278-312)
     model.eval()
@@ -95,22 +130,25 @@ def test_g1_odd_golden(golden_dir):
     np.testing.assert_allclose(pred.cpu().numpy(), g["cand"][0] @ g["user"][0], atol=SCORE_TOL)
 
 
-def test_g2_mind_golden(golden_dir):
+@pytest.mark.parametrize("mode", MODES)
+def test_g2_mind_golden(golden_dir, mode):
     g = load(golden_dir, "g2_mind.npz")
     shape = synth.G2_MIND
     params = synth.make_params(shape, seed=21)
     batch = synth.make_batch(shape, seed=22, ragged=True)
-    model = make_model(shape, params)
+    model = make_model(shape, params, precision=mode)
     scores, loss, grads = fwd_bwd(model, batch)
+    SCORE_TOL = TOL[mode]["score"]
+    print("g2 [%s]: max |score - reference| = %.3e" % (mode, float(np.abs(scores - g["scores"]).max())))
     np.testing.assert_allclose(scores, g["scores"], rtol=0, atol=SCORE_TOL)
     assert abs(loss - float(g["loss"])) < SCORE_TOL
     emb = "news_encoder.word_embedding.0.weight"
     for n in synth.param_names():
-        if n == emb:
-            np.testing.assert_allclose(grads[n][g["rows"]], g["grad_rows/" + n], rtol=GRAD_RTOL, atol=GRAD_ATOL)
+        if n == emb:                    # 95 % of the gradient bytes: sampled rows element-wise + every row's sum
+            assert_grad_close(grads[n][g["rows"]], g["grad_rows/" + n], mode, n + "[rows]")
             np.testing.assert_allclose(grads[n].sum(axis=1), g["grad_rowsum/" + n], rtol=1e-3, atol=2e-5)
         else:
-            np.testing.assert_allclose(grads[n], g["grad/" + n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+            assert_grad_close(grads[n], g["grad/" + n], mode, n)
     # eval forward (no autograd) gives the same scores
     model.eval()
     with torch.no_grad():
@@ -118,15 +156,18 @@ def test_g2_mind_golden(golden_dir):
     np.testing.assert_allclose(s2, g["scores"], rtol=0, atol=SCORE_TOL)
 
 
-def test_train_mode_dropout_replayed_through_oracle():
-    """Dropout on: export the kernels' keep masks, replay them in the oracle, demand parity of
-    scores and every gradient.  Proves forward and backward use the same mask at both sites."""
+@pytest.mark.parametrize("mode", MODES)
+def test_train_mode_dropout_replayed_through_oracle(mode):
+    """Dropout on (the benchmarked configuration: dropout 0.2, padding tokens skipped): export the kernels' keep
+    masks, replay them in the oracle, demand parity of scores and every gradient, the embedding table included.
+    Proves forward and backward use the same mask at both sites."""
     from oracle import nrms_oracle as orc
     shape = synth.Shape(n_words=500, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
                         batch_size=6, history_len=9, n_candidates=4, n_words_title=12)
     params = synth.make_params(shape, seed=5)
     batch = synth.make_batch(shape, seed=6, ragged=True, min_title=2)
-    model = make_model(shape, params, dropout=0.2)
+    model = make_model(shape, params, dropout=0.2, precision=mode)
+    SCORE_TOL = TOL[mode]["score"]
     model.train()
     scores, loss, grads = fwd_bwd(model, batch)
     sv = model.engine._saved
@@ -139,23 +180,25 @@ def test_train_mode_dropout_replayed_through_oracle():
     frac = float(keep["embed"].float().mean())
     assert 0.77 < frac < 0.83, frac
     assert not torch.equal(keep["embed"], keep["ctx"])
+    assert model.engine.pad_row_zero is True               # the compact (padding-skipping) path is the one under test
     o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads, p_drop=0.2, keep=keep)
     np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
     assert abs(loss - o_loss) < SCORE_TOL
     for n in synth.param_names():
-        np.testing.assert_allclose(grads[n], o_grads[n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+        assert_grad_close(grads[n], o_grads[n], mode, n)
     # a second step draws a different mask
     s2, _, _ = fwd_bwd(model, batch)
     assert np.abs(s2 - scores).max() > 1e-6
 
 
-def test_g5_fused_train_steps(golden_dir):
+@pytest.mark.parametrize("mode", MODES)
+def test_g5_fused_train_steps(golden_dir, mode):
     """Model.train_step (HIP fwd + CE + bwd + fused Adam) x3 against the reference model stepped
     by torch.optim.Adam (fixture g5)."""
     g = load(golden_dir, "g5_adam.npz")
     shape = synth.G1_ODD
     params = synth.make_params(shape, seed=51)
-    model = make_model(shape, params)
+    model = make_model(shape, params, precision=mode)
     model.train()
     model.config.learning_rate = 1e-3
     losses = []
@@ -169,15 +212,16 @@ def test_g5_fused_train_steps(golden_dir):
         if n.endswith("W_K.bias"):       # analytically zero gradient: Adam amplifies rounding noise
             assert np.abs(sd[n] - params[n]).max() <= 3.1e-3
             continue
-        assert_params_close(sd[n], g["param/" + n], n)
+        assert_params_close(sd[n], g["param/" + n], n, mode)
 
 
-def test_autograd_path_with_torch_adam_matches_fused(golden_dir):
+@pytest.mark.parametrize("mode", MODES)
+def test_autograd_path_with_torch_adam_matches_fused(golden_dir, mode):
     """The drop-in loop of train_eval.py:111-127 (model(batch) -> CE -> backward -> torch Adam)."""
     g = load(golden_dir, "g5_adam.npz")
     shape = synth.G1_ODD
     params = synth.make_params(shape, seed=51)
-    model = make_model(shape, params)
+    model = make_model(shape, params, precision=mode)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = torch.nn.CrossEntropyLoss()
@@ -195,9 +239,37 @@ def test_autograd_path_with_torch_adam_matches_fused(golden_dir):
     for n in synth.param_names():
         if n.endswith("W_K.bias"):
             continue
-        assert_params_close(sd[n], g["param/" + n], n)
+        assert_params_close(sd[n], g["param/" + n], n, mode)
 
 
+def test_adam_step_kernel_alone():
+    """nrms_adam_step on its own, identical gradients on both sides, against oracle.adam_step (numpy fp32
+    restatement of torch.optim.Adam, pinned by fixture g5): 4 steps, also with grad_scale (the 1/world_size of
+    the data-parallel path).  Bar: 1e-7 relative to the parameter scale -- what is left of the g5 tolerance
+    after this is the gradients' conditioning, not the optimizer."""
+    from oracle import nrms_oracle as orc
+    model = make_model(synth.G1_ODD, synth.make_params(synth.G1_ODD, seed=1))
+    eng = model.engine
+    rng = np.random.default_rng(3)
+    n = 100_003                                     # not a multiple of 4: exercises the tail of the float4 pass
+    p0 = rng.normal(0, 0.3, n).astype(np.float32)
+    grads = [(rng.normal(0, 1, n) * 10.0 ** rng.uniform(-9, -1, n)).astype(np.float32) for _ in range(4)]
+    for gs in (1.0, 0.25):
+        p, m, v = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        dp, dm, dv = (torch.from_numpy(a.copy()).cuda() for a in (p0, m, v))
+        for t, g in enumerate(grads, start=1):
+            orc.adam_step(p, (g * np.float32(gs)).astype(np.float32), m, v, t, lr=1e-3)
+            eng.adam_step(dp, torch.from_numpy(g).cuda(), dm, dv, t, lr=1e-3, grad_scale=gs)
+        err = np.abs(dp.cpu().numpy() - p)
+        print("adam alone (grad_scale %g): max |dparam| = %.3e" % (gs, float(err.max())))
+        # torch's own formulation: the update is lr * m_hat / (sqrt(v_hat) + eps) <= ~lr per step; agreement to
+        # 1e-7 absolute on parameters of scale 0.3 is ~1 ulp
+        assert err.max() <= 1.5e-7, float(err.max())
+        np.testing.assert_allclose(dm.cpu().numpy(), m, rtol=2e-6, atol=2e-7 * float(np.abs(m).max()))
+        np.testing.assert_allclose(dv.cpu().numpy(), v, rtol=4e-6, atol=2e-7 * float(v.max()))
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("shape", [
     synth.Shape(n_words=300, word_embed_size=64, num_attention_heads=2, query_vector_dim=64,
                 batch_size=5, history_len=33, n_candidates=2, n_words_title=33),     # S > 32, d_k = 32
@@ -208,21 +280,23 @@ def test_autograd_path_with_torch_adam_matches_fused(golden_dir):
     synth.Shape(n_words=1000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                 batch_size=16, history_len=50, n_candidates=5, n_words_title=30),    # bench shape, small batch
 ])
-def test_shape_sweep_against_oracle(shape):
+def test_shape_sweep_against_oracle(shape, mode):
     from oracle import nrms_oracle as orc
     params = synth.make_params(shape, seed=101)
     batch = synth.make_batch(shape, seed=102, ragged=True, min_title=1, mask_some_candidates=shape.n_candidates > 1)
-    model = make_model(shape, params)
+    model = make_model(shape, params, precision=mode)
     scores, loss, grads = fwd_bwd(model, batch)
     o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads)
+    SCORE_TOL = TOL[mode]["score"]
     np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
     assert abs(loss - o_loss) < SCORE_TOL
     for n in synth.param_names():
-        np.testing.assert_allclose(grads[n], o_grads[n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+        assert_grad_close(grads[n], o_grads[n], mode, n)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", ["all_padding", "no_padding", "one_live_token", "nonzero_pad_row"])
-def test_live_row_compaction_edges(case):
+def test_live_row_compaction_edges(case, mode):
     """The X-gradient GEMM and the embedding scatter run on the compacted non-padding token rows
     (padding_idx rows get no gradient, nrms_v0.py:134-136): empty list, full list, a single live row,
     and a table whose row 0 is NOT zero (from_pretrained keeps it: pad tokens then carry signal forward
@@ -241,12 +315,12 @@ def test_live_row_compaction_edges(case):
         batch["candidate_titles"][3, 2, 0] = 17
     if case == "no_padding":
         assert (batch["candidate_titles"] != 0).all() and (batch["browsed_titles"] != 0).all()
-    model = make_model(shape, params)
+    model = make_model(shape, params, precision=mode)
     scores, loss, grads = fwd_bwd(model, batch)
     o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads)
-    np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
+    np.testing.assert_allclose(scores, o_scores, rtol=0, atol=TOL[mode]["score"])
     for n in synth.param_names():
-        np.testing.assert_allclose(grads[n], o_grads[n], rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=n)
+        assert_grad_close(grads[n], o_grads[n], mode, n)
     table_grad = grads["news_encoder.word_embedding.0.weight"]
     assert (table_grad[0] == 0).all()                       # padding_idx row
     if case == "all_padding":
@@ -293,10 +367,10 @@ def test_padding_token_skip_equals_dense_path(precision):
     assert model.engine.pad_row_zero is False
 
 
-@pytest.mark.parametrize("precision,score_tol,grad_rtol", [("bf16x3", 1e-4, 2e-3), ("bf16", 5e-3, 6e-2)])
+@pytest.mark.parametrize("precision,score_tol,grad_rtol", [("bf16", 5e-3, 6e-2)])
 def test_reduced_precision_modes(golden_dir, precision, score_tol, grad_rtol):
-    """Split-bf16 projections must stay inside north_star's 1e-4 score bar against the REFERENCE fixture
-    (they are expected ~1e-6); plain bf16 is reported with a loose bound (it cannot meet 1e-4)."""
+    """Plain bf16 projections against the REFERENCE fixture: reported with a loose bound (it cannot meet
+    north_star's 1e-4 score bar and is never a default).  bf16x3 is covered like fp32 by every test above."""
     g = load(golden_dir, "g2_mind.npz")
     shape = synth.G2_MIND
     params = synth.make_params(shape, seed=21)
@@ -314,5 +388,69 @@ def test_reduced_precision_modes(golden_dir, precision, score_tol, grad_rtol):
         ref = g["grad/" + n]
         scale = np.abs(ref).max()
         assert np.abs(grads[n] - ref).max() <= grad_rtol * scale + 2e-6, n
-    if precision == "bf16x3":
-        assert err < 2e-5, "split-bf16 should be ~1e-6 on scores, got %.3e" % err
+
+
+def test_out_of_range_word_id_is_reported():
+    """nn.Embedding raises on an index outside the table (nrms_v0.py:134-139); the HIP path replaces such ids by
+    the padding id on the device (no kernel indexes out of bounds) and raises NrmsError at the next check."""
+    from pytorch_news_recommender_amd._lib import NrmsError
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=11)
+    model = make_model(shape, params).eval()
+    good = synth.make_batch(shape, seed=12, ragged=True)
+    with torch.no_grad():
+        ref = model(tbatch(good)).cpu().numpy()
+    model.engine.check_ids()                                      # clean so far
+    for bad_id in (shape.n_words, -1, 2 ** 40):
+        batch = {k: v.copy() for k, v in good.items()}
+        batch["candidate_titles"][1, 0, 0] = bad_id
+        batch["browsed_titles"][0, 1, 2] = bad_id
+        with torch.no_grad():
+            s = model(tbatch(batch))
+        torch.cuda.synchronize()
+        assert np.isfinite(s.cpu().numpy()[batch["candidate_mask"] == 1]).all()
+        with pytest.raises(NrmsError, match="outside"):
+            model.engine.check_ids()
+        model.engine.check_ids()                                  # the count is consumed by the raise
+    # training path + deferred (non-blocking) report on a later call
+    model.train()
+    batch = {k: v.copy() for k, v in good.items()}
+    batch["browsed_titles"][0, 0, 0] = shape.n_words + 5
+    model.train_step(tbatch(batch))
+    torch.cuda.synchronize()
+    with pytest.raises(NrmsError, match="outside"):
+        model.train_step(tbatch(good))
+    model.engine.check_ids()                                      # reported once; clean input stays clean
+    model.eval()
+    with torch.no_grad():
+        assert np.isfinite(model(tbatch(good)).cpu().numpy()).all()
+    model.engine.check_ids()
+    assert ref.shape == (shape.batch_size, shape.n_candidates)
+
+
+def test_second_training_forward_invalidates_the_first_backward():
+    """One slot of saved activations: a backward for an earlier training forward must raise, not run on the
+    activations of a later one (the reference's autograd would keep both graphs).  Inference calls in between
+    (get_news_vector, an eval forward) use their own buffers and leave the pending backward intact."""
+    from pytorch_news_recommender_amd._lib import NrmsError
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=11)
+    batch = synth.make_batch(shape, seed=12, ragged=True)
+    model = make_model(shape, params).train()
+    s_ref, _, g_ref = fwd_bwd(model, batch)
+    model.zero_grad()
+    s1 = model(tbatch(batch))
+    with torch.no_grad():                                         # inference between forward and backward
+        model.get_news_vector(torch.from_numpy(batch["candidate_titles"][:, 0]))
+        model.eval()
+        model(tbatch(synth.make_batch(shape, seed=99, ragged=True)))
+        model.train()
+    torch.nn.functional.cross_entropy(s1, torch.zeros(len(s1), dtype=torch.long, device=s1.device)).backward()
+    for n, p in model.named_parameters():
+        np.testing.assert_array_equal(p.grad.cpu().numpy(), g_ref[n], err_msg=n)
+    model.zero_grad()
+    s1 = model(tbatch(batch))
+    s2 = model(tbatch(synth.make_batch(shape, seed=98, ragged=True)))
+    with pytest.raises(NrmsError, match="replaced"):
+        s1.sum().backward()
+    s2.sum().backward()                                           # the latest forward still backpropagates

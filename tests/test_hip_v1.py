@@ -8,11 +8,12 @@ import torch
 
 from pytorch_news_recommender_amd import synth
 
+from tests.test_hip_parity import MODES, TOL, assert_grad_close
+
 pytestmark = pytest.mark.gpu
-SCORE_TOL, GRAD_RTOL, GRAD_ATOL = 1e-5, 1e-3, 2e-6
 
 
-def make_v1(shape, params, title_heads, dropout=0.0):
+def make_v1(shape, params, title_heads, dropout=0.0, precision="fp32"):
     from pytorch_news_recommender_amd.config import Config
     from pytorch_news_recommender_amd.model.nrms_v1_hip import Model
     cfg = Config("nrms_v1")
@@ -20,6 +21,7 @@ def make_v1(shape, params, title_heads, dropout=0.0):
     cfg.word_embed_size, cfg.query_vector_dim = shape.word_embed_size, shape.query_vector_dim
     cfg.num_attention_heads, cfg.title_heads_num = shape.num_attention_heads, title_heads
     cfg.dropout = dropout
+    cfg.precision = precision
     m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
     return m.to("cuda")
@@ -33,17 +35,19 @@ def fwd_bwd(model, batch):
     return scores.detach().cpu().numpy(), float(loss.detach()), {n: p.grad.cpu().numpy() for n, p in model.named_parameters()}
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("shape,title_heads", [
     (synth.Shape(n_words=800, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                  batch_size=6, history_len=50, n_candidates=5, n_words_title=20), 6),       # res_logs.md:4 setup: L=20, h=6/10
     (synth.Shape(n_words=90, word_embed_size=48, num_attention_heads=4, query_vector_dim=16,
                  batch_size=3, history_len=5, n_candidates=2, n_words_title=7), 2),
 ])
-def test_v1_model_forward_backward_vs_oracle(shape, title_heads):
+def test_v1_model_forward_backward_vs_oracle(shape, title_heads, mode):
     from oracle import nrms_oracle as orc
+    SCORE_TOL = TOL[mode]["score"]
     params = synth.make_params_v1(shape, seed=71)
     batch = synth.make_batch(shape, seed=72, ragged=True, min_title=1, mask_some_candidates=True)
-    model = make_v1(shape, params, title_heads).train()
+    model = make_v1(shape, params, title_heads, precision=mode).train()
     assert len(list(model.parameters())) == 23
     scores, loss, grads = fwd_bwd(model, batch)
     o_scores, o_loss, o_grads, _ = orc.loss_and_grads(orc.v1_to_v0_names(params), batch, shape.num_attention_heads,
@@ -53,16 +57,18 @@ def test_v1_model_forward_backward_vs_oracle(shape, title_heads):
     o_grads = {k: v for k, v in o_grads.items()}
     back = {v: k for k, v in zip(params.keys(), orc.v1_to_v0_names(params).keys())}
     for v0name, g in o_grads.items():
-        np.testing.assert_allclose(grads[back[v0name]], g, rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=v0name)
+        assert_grad_close(grads[back[v0name]], g, mode, v0name)
 
 
-def test_v1_dropout_only_after_attention_replayed():
+@pytest.mark.parametrize("mode", MODES)
+def test_v1_dropout_only_after_attention_replayed(mode):
     from oracle import nrms_oracle as orc
+    SCORE_TOL = TOL[mode]["score"]
     shape = synth.Shape(n_words=300, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
                         batch_size=5, history_len=8, n_candidates=3, n_words_title=10)
     params = synth.make_params_v1(shape, seed=81)
     batch = synth.make_batch(shape, seed=82, ragged=True, min_title=2)
-    model = make_v1(shape, params, title_heads=3, dropout=0.25).train()
+    model = make_v1(shape, params, title_heads=3, dropout=0.25, precision=mode).train()
     scores, loss, grads = fwd_bwd(model, batch)
     sv = model.engine._saved
     assert sv["p_embed"] == 0.0 and sv["p"] == 0.25
@@ -75,11 +81,12 @@ def test_v1_dropout_only_after_attention_replayed():
     np.testing.assert_allclose(scores, o_scores, rtol=0, atol=SCORE_TOL)
     back = {v: k for k, v in zip(params.keys(), orc.v1_to_v0_names(params).keys())}
     for v0name, g in o_grads.items():
-        np.testing.assert_allclose(grads[back[v0name]], g, rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=v0name)
+        assert_grad_close(grads[back[v0name]], g, mode, v0name)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("mask_mode", [1, 2, 3])
-def test_masked_primitives_forward_backward(mask_mode):
+def test_masked_primitives_forward_backward(mask_mode, mode):
     """User encoder with v1's masks (UserEncoder.forward(news_vectors, attn_masks), nrms_v1.py:208-211):
     pairwise attention mask (bit 0) and masked additive attention (bit 1), including a fully masked
     sequence (uniform attention over its real positions, as masked_fill(-1e9) gives)."""
@@ -87,7 +94,8 @@ def test_masked_primitives_forward_backward(mask_mode):
     shape = synth.Shape(n_words=50, word_embed_size=300, num_attention_heads=6, query_vector_dim=200,
                         batch_size=5, history_len=11, n_candidates=2, n_words_title=4)
     params = synth.make_params_v1(shape, seed=31)
-    model = make_v1(shape, params, title_heads=6)
+    SCORE_TOL = TOL[mode]["score"]
+    model = make_v1(shape, params, title_heads=6, precision=mode)
     eng, flat = model.engine, model._flat
     rng = np.random.default_rng(5)
     X = rng.normal(0, 0.5, size=(5, 11, 300)).astype(np.float32)
@@ -104,10 +112,10 @@ def test_masked_primitives_forward_backward(mask_mode):
     o = orc.user_encoder(p, Xt, shape.num_attention_heads, mask=torch.from_numpy(mask), mask_mode=mask_mode)
     (o * torch.from_numpy(dout)).sum().backward()
     np.testing.assert_allclose(out.cpu().numpy(), o.detach().numpy(), rtol=0, atol=SCORE_TOL)
-    np.testing.assert_allclose(dx.cpu().numpy(), Xt.grad.numpy(), rtol=GRAD_RTOL, atol=GRAD_ATOL)
+    assert_grad_close(dx.cpu().numpy(), Xt.grad.numpy(), mode, "dx")
     back = {v: k for k, v in zip(params.keys(), orc.v1_to_v0_names(params).keys())}
     for v0name, t in p.items():
         if not v0name.startswith("user_encoder") or t.grad is None:
             continue
         got = model._layout.view(gflat, back[v0name]).cpu().numpy()
-        np.testing.assert_allclose(got, t.grad.numpy(), rtol=GRAD_RTOL, atol=GRAD_ATOL, err_msg=v0name)
+        assert_grad_close(got, t.grad.numpy(), mode, v0name)

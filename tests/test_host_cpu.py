@@ -216,3 +216,149 @@ def test_engine_scratch_bound_covers_library_sizes_and_flag_validation():
                            p_drop_ctx=0.0, precision=0, flags=4, seed=0)
     assert lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(bad)) == 0
     assert b"flags" in lib.nrms_last_error()
+
+
+# ---- data feed (SURVEY a-12, f-2) -------------------------------------------------------------------
+def _g6_cfg(tmp_path=None):
+    fx = synth.dataset_fixture_inputs()
+    cfg = Config("g6")
+    for k, v in fx["config"].items():
+        setattr(cfg, k, v)
+    if tmp_path is not None:
+        cfg.data_path = str(tmp_path) + "/"
+    return fx, cfg
+
+
+def _check_against_g6(ds_by_type, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g6_dataset.npz"), allow_pickle=False)
+    keys = sorted({k.split("/", 2)[2] for k in g.files})
+    assert len(keys) == 13
+    for typ, ds in ds_by_type.items():
+        for i in range(len(ds)):
+            item = ds[i]
+            assert sorted(item) == keys
+            for key in keys:
+                want = g["type%d/%d/%s" % (typ, i, key)]
+                got = item[key].numpy() if isinstance(item[key], torch.Tensor) else np.asarray(item[key])
+                assert got.dtype == want.dtype, (typ, i, key, got.dtype, want.dtype)
+                np.testing.assert_array_equal(got, want, err_msg="type%d/%d/%s" % (typ, i, key))
+            assert isinstance(item["browsed_mask"], torch.Tensor) and item["browsed_mask"].dtype == torch.uint8
+
+
+def test_mydataset_items_equal_the_reference_dataset(golden_dir):
+    """The 13 arrays per item (keys, dtypes, padding, truncation to sample_size+1 / max_candidate_size) against
+    what the IMPORTED reference MyDataset.__getitem__ produced on the same hand-written samples (fixture g6,
+    tests/golden/gen_golden.py::gen_g6; data_handler.py:185-250)."""
+    from pytorch_news_recommender_amd.data_handler import MyDataset
+    fx, cfg = _g6_cfg()
+    ds = {0: MyDataset(cfg, fx["train_samples"], type=0, id2title_dict=fx["id2title_dict"], id2abst_dict=fx["id2abst_dict"]),
+          1: MyDataset(cfg, fx["eval_samples"], type=1, id2title_dict=fx["id2title_dict"], id2abst_dict=fx["id2abst_dict"])}
+    assert ds[0].sample_size == 3 and ds[1].sample_size == 6
+    _check_against_g6(ds, golden_dir)
+
+
+def test_reference_data_files_are_read_like_the_reference(tmp_path, golden_dir):
+    """The reference's constructor signature MyDataset(config, datas, type) with the word dictionaries coming from
+    config.data_path: news_words.csv (headerless news_id,title,abstract list literals) -> cached news_title.pkl /
+    news_abst.pkl (data_handler.py:113-135); dev labels from dev_behaviors.csv:y_true (train_eval.py:36-39);
+    idx_<file> sample cache (data_handler.py:43-47); test list lengths (train_eval.py:287-298); best checkpoint
+    by file-name AUC (train_eval.py:301-308)."""
+    import csv
+    import pickle
+    from pytorch_news_recommender_amd import data_handler as dh, train_eval
+    fx, cfg = _g6_cfg(tmp_path)
+    with open(tmp_path / "news_words.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        for i in range(6):
+            w.writerow(["N%d" % (i + 1), str(fx["id2title_dict"][i]), str(fx["id2abst_dict"][i])])
+    ds = {0: dh.MyDataset(cfg, fx["train_samples"], type=0), 1: dh.MyDataset(cfg, fx["eval_samples"], 1)}
+    assert os.path.exists(tmp_path / "news_title.pkl") and os.path.exists(tmp_path / "news_abst.pkl")
+    _check_against_g6(ds, golden_dir)
+    _check_against_g6({0: dh.MyDataset(cfg, fx["train_samples"])}, golden_dir)          # now from the pickles
+    with open(tmp_path / "dev_behaviors.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["user_id", "time", "history", "impressions", "y_true"])
+        w.writerow(["U1", "t", "N1 N2", "N3-1 N4-0", "1 0"])
+        w.writerow(["U2", "t", "N2", "N1-0 N5-0 N6-1", "0 0 1"])
+    assert dh.read_dev_labels(cfg) == [[1, 0], [0, 0, 1]]
+    with open(tmp_path / "idx_train_datas.pkl", "wb") as f:
+        pickle.dump(fx["train_samples"], f)
+    assert dh.load_dataset(cfg, "train_datas.pkl", cfg.data_path, _type=0) == fx["train_samples"]
+    with pytest.raises(FileNotFoundError):
+        dh.load_dataset(cfg, "dev_datas.pkl", cfg.data_path, _type=1)
+    os.makedirs(tmp_path / "test")
+    cfg.test_path = str(tmp_path / "test") + "/"
+    with open(tmp_path / "test" / "behaviors.tsv", "w") as f:
+        f.write("1\tU1\tt\tN1 N2\tN3 N4 N5\n2\tU2\tt\tN2\tN1\n")
+    assert dh.get_Test_List(cfg) == [3, 1] and os.path.exists(tmp_path / "test_imps_list.pkl")
+    cfg.save_path = str(tmp_path / "save") + "/"
+    assert train_eval.best_checkpoint(cfg) is None
+    os.makedirs(cfg.save_path)
+    for name in ("T10-01_10.00_g6_epoch6_iter_100_auc_0.612.ckpt", "T10-01_11.00_g6_epoch6_iter_200_auc_0.655.ckpt",
+                 "T10-01_12.00_other_epoch6_iter_300_auc_0.700.ckpt", "T10-01_13.00_g6_epoch6_iter_400_auc_0.640.ckpt"):
+        open(os.path.join(cfg.save_path, name), "w").close()
+    assert train_eval.best_checkpoint(cfg) == "T10-01_11.00_g6_epoch6_iter_200_auc_0.655.ckpt"
+
+
+def test_loading_through_the_wrapper_resets_the_padding_row_flag(tmp_path):
+    """NRMS_FLAG_PAD_ROW_ZERO is a property of the loaded weights.  nn.Module.load_state_dict on a PARENT (the
+    dispatch wrapper of model/__init__.py, as run_v0 --test and train_eval.test do) never calls the child's
+    load_state_dict, so the reset must fire from a load_state_dict post-hook."""
+    import types
+    from pytorch_news_recommender_amd import model as model_pkg
+    shape = synth.G1_ODD
+    cfg = make_cfg(shape)
+    params = synth.make_params(shape, seed=3)
+    np.savez(tmp_path / "all_word_embedding_v3.npz", embeddings=params["news_encoder.word_embedding.0.weight"])
+    cfg.data_path = str(tmp_path) + "/"
+    w = model_pkg.Model(cfg, types.SimpleNamespace(model="nrms_v0", n_GPUs=1))
+    w.model._pad_zero = True                       # as established by an earlier forward on a zero padding row
+    nz = synth.make_params(shape, seed=4, pad_row_zero=False)
+    w.load_state_dict({"model." + k: torch.from_numpy(v) for k, v in nz.items()})
+    assert w.model._pad_zero is None               # re-evaluated on the next forward
+    w.model._pad_zero = True
+    w.model.load_state_dict({k: torch.from_numpy(v) for k, v in nz.items()})
+    assert w.model._pad_zero is None
+
+
+REF = "/root/reference/MIND_2020"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference only exists in the build container")
+def test_reference_side_binding_constructs_through_the_reference_wrapper(tmp_path):
+    """INTEGRATION.md section 2, executed: a one-line model/nrms_hip.py placed on the REFERENCE's model package
+    path, then the reference's own wrapper (model/__init__.py:13-23, imported, not copied) builds it exactly as
+    run_v0.py does.  CPU container: construction and checkpoint keys only (forward needs a GPU)."""
+    import subprocess
+    import sys
+    import textwrap
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=3)
+    os.makedirs(tmp_path / "data_processed")
+    np.savez(tmp_path / "data_processed" / "all_word_embedding_v3.npz",
+             embeddings=params["news_encoder.word_embedding.0.weight"])
+    os.makedirs(tmp_path / "binding")
+    (tmp_path / "binding" / "nrms_hip.py").write_text(
+        "from pytorch_news_recommender_amd.model.nrms_hip import Model  # noqa: F401\n")
+    prog = textwrap.dedent("""
+        import sys, types
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import model                                   # the reference's package
+        model.__path__.append(%r)                      # where the maintainer's one-line file lives
+        from config import Config                      # the reference's config
+        cfg = Config('nrms_hip'); cfg.__nrms__()
+        cfg.word_embed_size, cfg.num_attention_heads, cfg.query_vector_dim = %d, %d, %d
+        args = types.SimpleNamespace(model='NRMS_HIP', n_GPUs=1)
+        m = model.Model(cfg, args)
+        print('KEYS', ' '.join(sorted(m.state_dict())))
+        print('CLASS', type(m.model).__module__)
+    """) % (REF, ROOT, str(tmp_path / "binding"), shape.word_embed_size, shape.num_attention_heads,
+            shape.query_vector_dim)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", prog], cwd=str(tmp_path), capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    keys = [ln for ln in r.stdout.splitlines() if ln.startswith("KEYS ")][0].split()[1:]
+    assert keys == sorted("model." + n for n in synth.param_names())
+    assert "CLASS pytorch_news_recommender_amd.model.nrms_hip" in r.stdout
