@@ -38,13 +38,16 @@ extern "C" {
                                    v_mfma_f32_16x16x32_bf16, fp32 accumulate (~2^-16 relative per product);
                                    attention, softmaxes, pooling, loss, optimizer and all HBM tensors stay fp32 */
 #define NRMS_PRECISION_BF16   2 /* same kernels, hi*hi only: plain bf16 inputs, fp32 accumulate */
+#define NRMS_FP16_KP 320        /* fp16 mode: pitch of x (input features, zero padded) */
+#define NRMS_FP16_DP 320        /* pitch of ctx (32 per head, zero padded) */
+#define NRMS_FP16_QP 224        /* pitch of t */
 #define NRMS_PRECISION_FP16   3 /* fused path: one wavefront per sequence, every contraction on v_mfma_f32_32x32x16_f16
                                    (fp16 operands: 11 significant bits, fp32 accumulate), Q/K/V, attention probabilities
                                    and tanh(.) register-resident, activations kept for the backward in fp16.
                                    Restrictions: seq_len <= 32, d_model <= 320, d_k <= 32, n_heads <= 10, q_dim <= 224,
                                    no output projection, no masks (NRMS_EINVAL otherwise).  Activation buffers change
                                    meaning (see nrms_encoder_acts); context-dropout counters run over the padded
-                                   [M, 32 n_heads] layout (nrms_dropout_keep_mask with d = 32 n_heads). */
+                                   [M, NRMS_FP16_DP] layout, 32 columns per head (nrms_dropout_keep_mask with d = 320). */
 
 /* nrms_encoder_desc.flags */
 /* The caller guarantees that row 0 of `table` (the padding row, nn.Embedding padding_idx=0,
@@ -124,8 +127,8 @@ typedef struct nrms_encoder_acts {
     float* w;              /* [M]      additive-attention softmax weights (nrms_v0.py:110-112) */
     void*  scratch;        /* nrms_encoder_fwd_scratch_bytes(desc) bytes: head-major W_qkv copy, bf16 weight planes,
                               token compaction lists */
-    /* NRMS_PRECISION_FP16: x, ctx, t hold fp16 with padded pitches KP = 32 ceil(d/32), DP = 32 n_heads,
-     * QP = 32 ceil(q/32):  x [M, KP] (required for both encoders: gathered embeddings / the cast input),
+    /* NRMS_PRECISION_FP16: x, ctx, t hold fp16 with the FIXED pitches KP = 320, DP = 320, QP = 224
+     * (NRMS_FP16_KP / _DP / _QP):  x [M, KP] (required for both encoders: gathered embeddings / the cast input),
      * ctx [M, DP] (head-padded, internal order), t [M, QP]; w [M] fp32; qkv and attn are unused (may be NULL). */
 } nrms_encoder_acts;
 
@@ -186,9 +189,9 @@ int nrms_ce_loss_fwd_bwd(int32_t B, int32_t C, const float* scores, float* loss_
 
 /* torch.optim.Adam defaults (train_eval.py:48,127): one fused pass over a flat fp32 buffer.
  * g is multiplied by grad_scale first (1/world_size after a summing all-reduce).
- * step is 1-based. */
+ * step is 1-based.  lr / betas / eps are doubles, as torch holds them (1 - beta is rounded to fp32 once). */
 int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                   float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                   double lr, double beta1, double beta2, double eps, int32_t step, float grad_scale,
                    void* stream);
 
 /* Per-impression AUC of evaluate() (train_eval.py:219-227,255-271 + evaluation.py:26-27):

@@ -17,6 +17,7 @@ NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1
 NRMS_PRECISION_BF16 = 2
 NRMS_PRECISION_FP16 = 3
+NRMS_FP16_KP, NRMS_FP16_DP, NRMS_FP16_QP = 320, 320, 224     # fixed activation pitches of the fp16 mode (include/nrms_hip.h)
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 
 
@@ -66,8 +67,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_ce_loss_fwd_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                        C.c_void_p]),
-    "nrms_adam_step": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
-                                 C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "nrms_adam_step": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                 C.c_double, C.c_double, C.c_double, C.c_int32, C.c_float, C.c_void_p]),
     "nrms_impression_auc": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "nrms_dropout_keep_mask": (C.c_int, [C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p,

@@ -174,7 +174,7 @@ static FwdScratch fwd_scratch(const nrms_encoder_desc* d) {
 }
 
 // ---- fp16 mode: planes | live | pos | n_live | compaction scratch
-struct Fwd16Scratch { size_t planes, live, pos, n_live, cscr, total; };
+struct Fwd16Scratch { size_t planes, live, pos, n_live, cscr, order, order_cnt, total; };
 static Fwd16Scratch fwd16_scratch(const nrms_encoder_desc* d) {
     Fwd16Scratch f;
     const size_t M = (size_t)d->n_seq * d->seq_len;
@@ -184,7 +184,9 @@ static Fwd16Scratch fwd16_scratch(const nrms_encoder_desc* d) {
     f.pos = f.live + (gather ? align_up(M * sizeof(int), 256) : 0);
     f.n_live = f.pos + (gather ? align_up(M * sizeof(int), 256) : 0);
     f.cscr = f.n_live + (gather ? 256 : 0);
-    f.total = f.cscr + (gather ? align_up(compact_scratch_ints((long)M) * sizeof(int), 256) : 0);
+    f.order = f.cscr + (gather ? align_up(compact_scratch_ints((long)M) * sizeof(int), 256) : 0);
+    f.order_cnt = f.order + (gather ? align_up((size_t)2 * d->n_seq * sizeof(int), 256) : 0);
+    f.total = f.order_cnt + (gather ? 256 : 0);
     return f;
 }
 
@@ -215,6 +217,11 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
             if (rc) return rc;
             f.pos = pos;
             f.ids = ids;
+            int* order = (int*)(base + fs.order);
+            int* order_cnt = (int*)(base + fs.order_cnt);
+            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s);
+            if (rc) return rc;
+            f.order = order; f.order_cnt = order_cnt;
         } else {
             rc = launch_gather16(M, d, L.KP, ids, nullptr, nullptr, w->table, drop_e, acts->x, s);
             if (rc) return rc;

@@ -13,13 +13,15 @@
 // for the backward), the [n_seq, d] output.
 //
 // Layouts (all fp16 tensors are zero padded):
-//   x16    [rows][KP]      KP = d rounded up to 32; row = compact live-token index (pos[token]) or the token itself
+//   x16    [rows][KP]      KP = 320 (fixed pitch, d <= 320); row = compact live-token index (pos[token]) or the token itself
 //   wqkv16 [3h tiles][32][KP]   tile 3*head + {0,1,2} = the head's W_Q (pre-scaled by 1/sqrt(d_k)), W_K, W_V rows
-//   ctx16  [n_seq*S][DP]   DP = 32 h: head-padded features, and INSIDE every 16-feature block in "P16" order: memory
+//   ctx16  [n_seq*S][DP]   DP = 320 >= 32 h: head-padded features, and INSIDE every 16-feature block in "P16" order: memory
 //                          position 8*hh + j  <->  feature 16 b + 8 (j>>2) + 4 hh + (j&3).  That is exactly the order in
 //                          which a 32x32 accumulator hands its rows to the next MFMA as an operand (cdna guide, section 3),
 //                          so ctx^T goes from the PV product into the additive projection without any data movement.
-//   wadd16 [QP/32 tiles][32][DP]  columns in the same P16 order;   T16 [n_seq*S][QP] natural order
+//   wadd16 [QP/32 tiles][32][DP]  columns in the same P16 order (QP = 224 >= q);   T16 [n_seq*S][QP] natural order
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace nrms {
@@ -47,23 +49,30 @@ __device__ __forceinline__ int p16_pos(int fpad) {           // natural padded f
     return 16 * b + 8 * hh + j;
 }
 
-constexpr int F16_WAVES = 8;
-constexpr int F16_THREADS = 64 * F16_WAVES;
-constexpr int F16_KS = 20;            // k-steps of 16 input features held in registers: d <= 320
-constexpr int F16_CS = 20;            // ctx k-steps: DP = 32 h <= 320
-constexpr int F16_QT = 7;             // q tiles of 32: q <= 224
-constexpr int F16_STG = 3;            // 16-byte staging chunks per thread and tile: 32 * pitch / 8 <= 512 * 3
+constexpr int F16_WAVES = 4;            // waves (= sequences) per workgroup; two workgroups share a CU (one wave per SIMD each),
+constexpr int F16_THREADS = 64 * F16_WAVES;   // so the two waves of a SIMD are in different phases: one's MFMAs cover the other's VALU / waits
+// Pitches are compile-time constants (every inner loop fully unrolled, no guards: a guarded MFMA costs a branch
+// and a full LDS wait each).  Smaller models run zero padded at these sizes.
+constexpr int F16_KS = 20;            // k-steps of 16 input features held in registers: KP = 320 >= d
+constexpr int F16_CS = 20;            // ctx k-steps: DP = 320 >= 32 h
+constexpr int F16_QT = 7;             // q tiles of 32: QP = 224 >= q
+constexpr int F16_KP = 16 * F16_KS, F16_DP = 16 * F16_CS, F16_QP = 32 * F16_QT;
+constexpr int F16_PITCH = (F16_KP + 8) * 2;              // LDS row pitch in bytes: +16 B => conflict-free b128 reads
+constexpr int F16_SLOT = 32 * F16_PITCH;
+constexpr int F16_RC = F16_KP / 8;                       // 16-byte chunks per tile row
+static_assert(F16_KP == F16_DP, "one tile geometry for the head tiles and the additive tiles");
+constexpr int F16_STG = (32 * F16_RC + F16_THREADS - 1) / F16_THREADS;      // staging chunks (16 B) per thread and tile
+constexpr bool F16_STG_EXACT = 32 * F16_RC == F16_STG * F16_THREADS;
 
 struct Fwd16Args {
     int n_seq, S, d, h, dk, q;
-    int KP, DP, QP;
     const _Float16* x16;      // [rows][KP]
     const int* pos;           // [n_seq*S] token -> x16 row, -1 = padding token (zero row); null: row = token
     const int64_t* ids;       // news encoder with NRMS_FLAG_PAD_ROW_ZERO: all-padding titles take the closed form; else null
-    const int* order;         // optional [n_seq]: sequence handled by slot i (non-empty titles first); null = identity
-    const _Float16* wqkv16;   // [3h][32][KP]
+    const int* order;         // optional [2][n_seq]: the titles with a real token, then (second row) the all-padding
+    const int* order_cnt;     //          titles; order_cnt[0..1] = their numbers (device).  null = identity
+    const _Float16* wtiles;   // [3h + QP/32][32][KP]: the head tiles (Q pre-scaled | K | V per head), then the additive tiles
     const float* bqkv32;      // [3h][32]  (Q part pre-scaled)
-    const _Float16* wadd16;   // [QP/32][32][DP]
     const float* badd32;      // [QP]
     const float* qv32;        // [QP]
     _Float16* ctx16;          // [n_seq*S][DP]
@@ -71,24 +80,119 @@ struct Fwd16Args {
     float* w;                 // [n_seq*S] or null
     float* out;               // [n_seq][d]
     Dropout drop;             // context dropout (site 1, element index = token * DP + padded feature)
+    int dbg;                  // timing experiments only (NRMS_F16_DBG): 1 = no tile staging after the prologue
 };
 
+// ---- the weight-tile ring shared by the forward and the backward kernel: tile n lives in LDS slot n % 3; while
+// tile n is consumed, tile n + 2 travels global -> registers -> LDS.  One barrier per tile.
+struct TileRing {
+    char* smem;
+    const _Float16* src;          // tiles are contiguous [n_tiles][32][F16_KP]
+    int n_tiles, tid, l32, hh;
+    int dbg;
+    h8 stg[F16_STG];
+    __device__ __forceinline__ void load(int n) {
+        if (n >= n_tiles) return;
+        if (dbg & 1) return;
+        const _Float16* t = src + (long)n * (32 * F16_KP) + tid * 8;
+#pragma unroll
+        for (int i = 0; i < F16_STG; ++i)
+            if (F16_STG_EXACT || i + 1 < F16_STG || tid + F16_THREADS * i < 32 * F16_RC)
+                stg[i] = *reinterpret_cast<const h8*>(t + (long)F16_THREADS * 8 * i);
+    }
+    __device__ __forceinline__ void store(int n) {
+        if (n >= n_tiles) return;
+        if (dbg & 1) return;
+        char* dst = smem + (n % 3) * F16_SLOT;
+#pragma unroll
+        for (int i = 0; i < F16_STG; ++i) {
+            const int c = tid + F16_THREADS * i;
+            if (F16_STG_EXACT || i + 1 < F16_STG || c < 32 * F16_RC) {
+                const int row = c / F16_RC, col = c - row * F16_RC;
+                *reinterpret_cast<h8*>(dst + row * F16_PITCH + col * 16) = stg[i];
+            }
+        }
+    }
+    // row l32 of tile n, k-step s: 8 consecutive k for this lane half
+    __device__ __forceinline__ h8 frag(int n, int s) const {
+        return *reinterpret_cast<const h8*>(smem + (n % 3) * F16_SLOT + l32 * F16_PITCH + (16 * s + 8 * hh) * 2);
+    }
+};
+
+// acc += (W tile n) x (register operand), 20 k-steps as 5 groups of 4: the weight fragments of group g + 1 are read
+// from LDS while the MFMAs of group g issue (two named register sets; the scheduling barriers keep hipcc from hoisting
+// all twenty reads to the top, which spills).  W_IS_A: acc = W x^T (features x tokens); else acc = x W^T.
+template <bool W_IS_A, int NS>
+__device__ __forceinline__ void tile_mma(f32x16& acc, const TileRing& ring, int n, const h8 (&op)[NS]) {
+    static_assert(NS % 4 == 0, "k-steps in groups of 4");
+    h8 wa[4], wb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wa[i] = ring.frag(n, i);
+#pragma unroll
+    for (int g = 0; g < NS / 4; ++g) {
+        if (g + 1 < NS / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (g & 1) wa[i] = ring.frag(n, 4 * (g + 1) + i);
+                else wb[i] = ring.frag(n, 4 * (g + 1) + i);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const h8& w = (g & 1) ? wb[i] : wa[i];
+            acc = W_IS_A ? mfma32h(w, op[4 * g + i], acc) : mfma32h(op[4 * g + i], w, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// r[4g + e] = v[8g + 4hh + e]: a per-ROW vector (bias) in the accumulator's register order.  Loaded at the top of a
+// tile step and ADDED after the MFMAs: as the accumulator's initial value it would put a global-load latency in
+// front of every tile.
+__device__ __forceinline__ f32x16 rows_of(const float* v, int hh) {
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(v + 8 * g + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[4 * g + e] = bb[e];
+    }
+    return r;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = 0.f;
+    return r;
+}
+
 template <bool TRAIN>
-__global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a) {
+__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel(Fwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
-    const int S = a.S, KP = a.KP, DP = a.DP, QP = a.QP;
-    const int ks_n = KP >> 4, cs_n = DP >> 4, qt_n = QP >> 5;
-    const int pitch = ((KP > DP ? KP : DP) + 8) * 2;            // LDS row pitch in bytes: +16 B => conflict-free b128 reads
-    const int slot_bytes = 32 * pitch;
-    const int n_head_tiles = 3 * a.h, n_tiles = n_head_tiles + qt_n;
+    const int S = a.S;
+    constexpr int KP = F16_KP, DP = F16_DP, QP = F16_QP;
+    const int n_head_tiles = 3 * a.h;
 
-    // ---- which sequence this wave owns
-    const int slot_id = blockIdx.x * F16_WAVES + wave;
-    const bool valid = slot_id < a.n_seq;
-    const int seq = valid ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0;
+    // ---- which sequence this wave owns.  With an order list, workgroups [0, ceil(n_ne / 8)) take the titles that
+    // have a real token, the following ones the all-padding titles (closed form: no head tile is touched), so no
+    // wave idles through the head tiles next to a working one.
+    int slot_id = blockIdx.x * F16_WAVES + wave;
+    bool valid = slot_id < a.n_seq;
+    int seq = slot_id;
+    if (a.order != nullptr) {
+        const int n_ne = a.order_cnt[0], n_e = a.order_cnt[1];
+        const int g_ne = (n_ne + F16_WAVES - 1) / F16_WAVES;
+        if ((int)blockIdx.x < g_ne) { valid = slot_id < n_ne; seq = valid ? a.order[slot_id] : 0; }
+        else {
+            slot_id -= g_ne * F16_WAVES;
+            valid = slot_id < n_e;
+            seq = valid ? a.order[a.n_seq + slot_id] : 0;
+        }
+    }
+    if (!valid) seq = 0;
     const long tok0 = (long)seq * S;                             // first token of the sequence
     const bool tok_ok = valid && l32 < S;
     bool empty = false;                                          // all-padding title: attention is uniform over equal rows
@@ -96,50 +200,17 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a
         const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
         empty = __ballot(is_pad) == ~0ull;
     }
-    const bool skip_heads = __syncthreads_and((!valid || empty) ? 1 : 0) != 0;     // whole workgroup without a live title
+    const bool live = valid && !empty;
+    const bool skip_heads = __syncthreads_and(live ? 0 : 1) != 0;     // whole workgroup without a live title
     const int n_begin = skip_heads ? n_head_tiles : 0;
 
-    // ---- weight-tile ring: tile n lives in slot n % 3; tile n+2 is fetched while tile n is consumed
-    h8 stg[F16_STG];
-    auto tile_src = [&](int n, int& rowchunks) -> const _Float16* {
-        if (n < n_head_tiles) { rowchunks = KP >> 3; return a.wqkv16 + (long)n * 32 * KP; }
-        rowchunks = DP >> 3;
-        return a.wadd16 + (long)(n - n_head_tiles) * 32 * DP;
-    };
-    auto stage_load = [&](int n) {
-        if (n >= n_tiles) return;
-        int rc;
-        const _Float16* src = tile_src(n, rc);
-        const int total = 32 * rc;
-#pragma unroll
-        for (int i = 0; i < F16_STG; ++i) {
-            const int c = tid + F16_THREADS * i;
-            if (c < total) stg[i] = *reinterpret_cast<const h8*>(src + (long)c * 8);      // tiles are contiguous [32][rc*8]
-        }
-    };
-    auto stage_store = [&](int n) {
-        if (n >= n_tiles) return;
-        int rc;
-        (void)tile_src(n, rc);
-        const int total = 32 * rc;
-        char* dst = smem + (n % 3) * slot_bytes;
-#pragma unroll
-        for (int i = 0; i < F16_STG; ++i) {
-            const int c = tid + F16_THREADS * i;
-            if (c < total) {
-                const int row = c / rc, col = c - row * rc;
-                *reinterpret_cast<h8*>(dst + row * pitch + col * 16) = stg[i];
-            }
-        }
-    };
-    auto wfrag = [&](int n, int s) -> h8 {                      // rows l32 of tile n, k-step s
-        return *reinterpret_cast<const h8*>(smem + (n % 3) * slot_bytes + l32 * pitch + (16 * s + 8 * hh) * 2);
-    };
-
-    stage_load(n_begin);
-    stage_store(n_begin);
-    stage_load(n_begin + 1);
-    stage_store(n_begin + 1);
+    TileRing ring;
+    ring.dbg = 0;
+    ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_head_tiles + F16_QT; ring.tid = tid; ring.l32 = l32; ring.hh = hh;
+    ring.load(n_begin);
+    ring.store(n_begin);
+    ring.load(n_begin + 1);
+    ring.store(n_begin + 1);
 
     // ---- this lane's x fragments: token l32, features 16 s + 8 hh .. +7 (A operand of x W^T and B operand of W x^T)
     h8 xf[F16_KS];
@@ -148,73 +219,56 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a
         if (tok_ok && !empty) row = a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32;
         const _Float16* xr = a.x16 + (row < 0 ? 0 : row) * KP + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < F16_KS; ++s) {
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (s < ks_n && row >= 0) v = *reinterpret_cast<const h8*>(xr + 16 * s);
-            xf[s] = v;
+        for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
+        if (row < 0) {
+#pragma unroll
+            for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
     __syncthreads();
+    ring.dbg = a.dbg;
 
     const long ctx_row = (tok0 + l32) * (long)DP;                 // this lane's ctx16 row (token l32)
     int n = n_begin;
-    if (!skip_heads) {
-        for (int head = 0; head < a.h; ++head) {
+#pragma unroll 1
+    for (int head = 0; head < a.h; ++head) {
+        f32x16 ct;                                               // ctx^T[f][tok] of this head
+        if (!skip_heads) {
             f32x16 qt, kt, vv;
-            // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] + b
-            stage_load(n + 2);
+            // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] + b   (features in registers, tokens on lanes)
+            ring.load(n + 2);
             {
-                const float* b = a.bqkv32 + (n * 32);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) qt[4 * g + e] = bb[e];
-                }
-                if (valid && !empty) {
-#pragma unroll
-                    for (int s = 0; s < F16_KS; ++s)
-                        if (s < ks_n) qt = mfma32h(wfrag(n, s), xf[s], qt);
-                }
+                const f32x16 b = rows_of(a.bqkv32 + n * 32, hh);
+                qt = zero16();
+                if (live) tile_mma<true>(qt, ring, n, xf);
+                qt += b;
             }
-            stage_store(n + 2);
+            ring.store(n + 2);
             __syncthreads();
             ++n;
             // ---- tile K
-            stage_load(n + 2);
+            ring.load(n + 2);
             {
-                const float* b = a.bqkv32 + (n * 32);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) kt[4 * g + e] = bb[e];
-                }
-                if (valid && !empty) {
-#pragma unroll
-                    for (int s = 0; s < F16_KS; ++s)
-                        if (s < ks_n) kt = mfma32h(wfrag(n, s), xf[s], kt);
-                }
+                const f32x16 b = rows_of(a.bqkv32 + n * 32, hh);
+                kt = zero16();
+                if (live) tile_mma<true>(kt, ring, n, xf);
+                kt += b;
             }
-            stage_store(n + 2);
+            ring.store(n + 2);
             __syncthreads();
             ++n;
             // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k] + b   (bias per column = lane)
-            stage_load(n + 2);
+            ring.load(n + 2);
             {
                 const float bv = a.bqkv32[n * 32 + l32];
+                vv = zero16();
+                if (live) tile_mma<false>(vv, ring, n, xf);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) vv[r] = bv;
-                if (valid && !empty) {
-#pragma unroll
-                    for (int s = 0; s < F16_KS; ++s)
-                        if (s < ks_n) vv = mfma32h(xf[s], wfrag(n, s), vv);
-                }
+                for (int r = 0; r < 16; ++r) vv[r] += bv;
             }
-            stage_store(n + 2);
+            ring.store(n + 2);
             // ---- attention of this head, entirely in registers
-            f32x16 ct;                                   // ctx^T[f][tok]
-            if (valid && !empty) {
+            if (live) {
                 f32x16 st;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -224,16 +278,14 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a
                 float m = -3.0e38f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int j = crow32(r, hh);
-                    st[r] = j < S ? st[r] : -3.0e38f;        // rows beyond the sequence are not keys
+                    st[r] = crow32(r, hh) < S ? st[r] : -3.0e38f;        // rows beyond the sequence are not keys
                     m = fmaxf(m, st[r]);
                 }
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
                 float sum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int j = crow32(r, hh);
-                    const float p = j < S ? __expf(st[r] - m) : 0.f;
+                    const float p = crow32(r, hh) < S ? __expf(st[r] - m) : 0.f;
                     st[r] = p;
                     sum += p;
                 }
@@ -246,58 +298,33 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a
                 for (int r = 0; r < 16; ++r) ct[r] = 0.f;
                 ct = mfma32h(acc_frag(vv, 0), acc_frag(st, 0), ct);
                 ct = mfma32h(acc_frag(vv, 1), acc_frag(st, 1), ct);
-            } else {
-                // all-padding title: S equal rows V_j = b_v, uniform attention => ctx = b_v for every token
-                const float* b = a.bqkv32 + ((n) * 32);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ct[4 * g + e] = bb[e];
-                }
             }
-            if (TRAIN && a.drop.thresh != 0u) {
+        }
+        if (!live) ct = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh);    // all-padding title: ctx = b_v for every token
+        if (a.drop.thresh != 0u) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
-                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+            for (int g = 0; g < 4; ++g) {
+                const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
+                const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ct[4 * g + e] *= sc[e];
-                }
+                for (int e = 0; e < 4; ++e) ct[4 * g + e] *= sc[e];
             }
-            if (tok_ok) {
-                _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
-                *reinterpret_cast<h8*>(dst) = acc_frag(ct, 0);
-                *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct, 1);
-            }
+        }
+        if (tok_ok) {
+            _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
+            *reinterpret_cast<h8*>(dst) = acc_frag(ct, 0);
+            *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct, 1);
+        }
+        if (!skip_heads) {
             __syncthreads();
             ++n;
         }
-    } else {
-        // no live title in this workgroup: every sequence takes the closed form, no weight tile of the heads is needed
-        for (int head = 0; head < a.h; ++head) {
-            f32x16 ct;
-            const float* b = a.bqkv32 + ((3 * head + 2) * 32);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ct[4 * g + e] = bb[e];
-            }
-            if (TRAIN && a.drop.thresh != 0u) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
-                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ct[4 * g + e] *= sc[e];
-                }
-            }
-            if (tok_ok) {
-                _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
-                *reinterpret_cast<h8*>(dst) = acc_frag(ct, 0);
-                *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct, 1);
-            }
+    }
+    if (tok_ok) {                                                  // heads the model does not have: zero columns
+        for (int head = a.h; head < F16_CS / 2; ++head) {
+            _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
+            *reinterpret_cast<h8*>(dst) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<h8*>(dst + 16) = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
 
@@ -306,58 +333,45 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's ctx16 stores have landed
     h8 cf[F16_CS];
     {
-        const _Float16* src = a.ctx16 + ctx_row + 8 * hh;
+        const _Float16* src = a.ctx16 + (tok_ok ? ctx_row : 0) + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < F16_CS; ++s) {
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (s < cs_n && tok_ok) v = *reinterpret_cast<const h8*>(src + 16 * s);
-            cf[s] = v;
+        for (int s = 0; s < F16_CS; ++s) cf[s] = *reinterpret_cast<const h8*>(src + 16 * s);
+        if (!tok_ok) {
+#pragma unroll
+            for (int s = 0; s < F16_CS; ++s) cf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
     float score = 0.f;                                            // sum_q q_vec[q] tanh(.)[q][tok], per token = per lane
+#pragma unroll 1
+    for (int t = 0; t < F16_QT; ++t) {                            // (not unrolled: hipcc would software-pipeline the tanh
+                                                                  //  epilogues across tiles and spill their accumulators)
+        ring.load(n + 2);
+        const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
+        f32x16 tt = zero16();
+        if (valid) tile_mma<true>(tt, ring, n, cf);
 #pragma unroll
-    for (int t = 0; t < F16_QT; ++t) {
-        if (t < qt_n) {
-            stage_load(n + 2);
-            f32x16 tt;
-            const float* b = a.badd32 + 32 * t;
+        for (int g = 0; g < 4; ++g) {
+            h4 th;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tt[4 * g + e] = bb[e];
+            for (int e = 0; e < 4; ++e) {
+                const float v = fast_tanh(tt[4 * g + e] + ba[4 * g + e]);
+                score += qq[4 * g + e] * v;
+                th[e] = (_Float16)v;
             }
-            if (valid) {
-#pragma unroll
-                for (int s = 0; s < F16_CS; ++s)
-                    if (s < cs_n) tt = mfma32h(wfrag(n, s), cf[s], tt);
-            }
-            const float* qv = a.qv32 + 32 * t;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 qq = *reinterpret_cast<const f32x4*>(qv + 8 * g + 4 * hh);
-                h4 th;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fast_tanh(tt[4 * g + e]);
-                    score += qq[e] * v;
-                    th[e] = (_Float16)v;
-                }
-                if (TRAIN && a.t16 != nullptr && tok_ok)
-                    *reinterpret_cast<h4*>(a.t16 + (tok0 + l32) * (long)QP + 32 * t + 8 * g + 4 * hh) = th;
-            }
-            stage_store(n + 2);
-            __syncthreads();
-            ++n;
+            if (TRAIN && tok_ok)
+                *reinterpret_cast<h4*>(a.t16 + (tok0 + l32) * (long)QP + 32 * t + 8 * g + 4 * hh) = th;
         }
+        ring.store(n + 2);
+        __syncthreads();
+        ++n;
     }
     score += __shfl_xor(score, 32, 64);
     // softmax over the tokens of the sequence (lanes 0..S-1 of either half)
-    float sm = l32 < S ? score : -3.0e38f;
+    const float sm = l32 < S ? score : -3.0e38f;
     float mx = sm;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float ev = l32 < S ? __expf(sm - mx) : 0.f;
+    const float ev = l32 < S ? __expf(sm - mx) : 0.f;
     float es = ev;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
@@ -366,17 +380,26 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a
 
     // ---- pooling: out[f] = sum_tok w_tok ctx[tok][f].  Lane c owns the 16-byte chunk c of a ctx16 row (DP/8 chunks).
     if (valid) {
-        const int n_chunks = DP >> 3;
+        constexpr int n_chunks = DP >> 3;
         float acc8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
-        const _Float16* base = a.ctx16 + tok0 * (long)DP + lane * 8;
-        for (int t = 0; t < S; ++t) {
-            const float wt = __builtin_amdgcn_readlane(wgt, t);
-            if (lane < n_chunks) {
-                const h8 v = *reinterpret_cast<const h8*>(base + (long)t * DP);
+        const _Float16* base = a.ctx16 + tok0 * (long)DP + (lane < n_chunks ? lane : 0) * 8;
+        // 16 rows per batch: all loads of a batch are in flight together (one latency per batch, not per row); rows
+        // past the sequence re-read its last row with weight 0
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc8[j] += wt * (float)v[j];
+        for (int t0 = 0; t0 < 32; t0 += 16) {
+            if (t0 < S) {
+                h8 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const h8*>(base + (long)min(t0 + i, S - 1) * DP);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wgt), t0 + i));
+                    wt = t0 + i < S ? wt : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc8[j] += wt * (float)v[i][j];
+                }
             }
         }
         if (lane < n_chunks) {
@@ -385,7 +408,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16_kernel(Fwd16Args a
             for (int j = 0; j < 8; ++j) {
                 const int fpad = 16 * b16 + 8 * (j >> 2) + 4 * ch + (j & 3);
                 const int head = fpad >> 5, f = fpad & 31;
-                if (f < a.dk) a.out[(long)seq * a.d + head * a.dk + f] = acc8[j];
+                if (f < a.dk && head < a.h) a.out[(long)seq * a.d + head * a.dk + f] = acc8[j];
             }
         }
     }
@@ -445,6 +468,44 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
     }
 }
 
+// order[0][..] = titles with at least one non-padding token, order[1][..] = all-padding titles (each list in
+// whatever order the block counters resolve: titles are independent, results do not depend on it); cnt[0..1] = sizes.
+__global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, const int64_t* ids, int* order, int* cnt) {
+    __shared__ int flag[64];
+    __shared__ int base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t0 = blockIdx.x * 64;
+    for (int i = 0; i < 16; ++i) {
+        const int t = t0 + wave * 16 + i;
+        bool pad = true;
+        if (t < n_seq && lane < S) pad = ids[(long)t * S + lane] == 0;
+        const bool empty = __ballot(pad) == ~0ull;
+        if (lane == 0) flag[wave * 16 + i] = t < n_seq ? (empty ? 1 : 0) : -1;
+    }
+    __syncthreads();
+    int f = -1, rank = 0;
+    if (threadIdx.x < 64) {
+        f = flag[threadIdx.x];
+        const unsigned long long m_ne = __ballot(f == 0), m_e = __ballot(f == 1);
+        const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+        rank = f == 0 ? __popcll(m_ne & below) : __popcll(m_e & below);
+        if (threadIdx.x == 0) {
+            base[0] = atomicAdd(cnt + 0, __popcll(m_ne));
+            base[1] = atomicAdd(cnt + 1, __popcll(m_e));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && f >= 0) order[(long)f * n_seq + base[f] + rank] = t0 + threadIdx.x;
+}
+
+int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream) {
+    if (n_seq <= 0) return NRMS_OK;
+    if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) { set_error("title_order: memset failed"); return NRMS_ELAUNCH; }
+    TimingScope ts("title_order", stream);
+    hipLaunchKernelGGL(title_order_kernel, dim3(cdiv(n_seq, 64)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+    return check_launch("title_order");
+}
+
 // x16[r, :] = fp16(table[ids[t], :] * keep(t, :) / (1 - p)), t = live[r] (r < *n_live) or t = r (live == null);
 // columns d..KP-1 are zero.  Same Philox counters (site 0, element index t*d + c) as the fp32 gather.
 __global__ __launch_bounds__(256) void gather16_kernel(unsigned d4, unsigned kp4, long M, const int64_t* ids, const int* live,
@@ -486,23 +547,23 @@ bool fused16_supported(int S, int d, int h, int q, const char** why) {
     const int dk = d / h;
     const char* w = nullptr;
     if (S > 32) w = "seq_len <= 32";
-    else if (d > 16 * F16_KS) w = "d_model <= 320";
+    else if (d > F16_KP) w = "d_model <= 320";
     else if (dk > 32) w = "d_k <= 32";
-    else if (32 * h > 16 * F16_CS) w = "n_heads <= 10";
-    else if (q > 32 * F16_QT) w = "q_dim <= 224";
+    else if (32 * h > F16_DP) w = "n_heads <= 10";
+    else if (q > F16_QP) w = "q_dim <= 224";
     if (why) *why = w;
     return w == nullptr;
 }
 
 Fused16Layout fused16_layout(int d, int h, int q) {
     Fused16Layout L;
-    L.KP = cdiv(d, 32) * 32;
-    L.DP = 32 * h;
-    L.QP = cdiv(q, 32) * 32;
+    L.KP = F16_KP;                 // fixed pitches: see the constants at the top
+    L.DP = F16_DP;
+    L.QP = F16_QP;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
-    L.wqkv16 = take((size_t)3 * h * 32 * L.KP * 2);
-    L.wadd16 = take((size_t)L.QP * L.DP * 2);
+    L.wqkv16 = take((size_t)3 * h * 32 * L.KP * 2 + (size_t)L.QP * L.DP * 2);     // head tiles, then the additive tiles: ONE tile stream
+    L.wadd16 = L.wqkv16 + (size_t)3 * h * 32 * L.KP * 2;
     L.bqkv32 = take((size_t)3 * h * 32 * 4);
     L.badd32 = take((size_t)L.QP * 4);
     L.qv32 = take((size_t)L.QP * 4);
@@ -553,19 +614,18 @@ int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
     const char* base = (const char*)f.planes;
     Fwd16Args a{};
     a.n_seq = f.n_seq; a.S = f.S; a.d = f.d; a.h = f.h; a.dk = f.d / f.h; a.q = f.q;
-    a.KP = L.KP; a.DP = L.DP; a.QP = L.QP;
-    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.ids = f.ids; a.order = f.order;
-    a.wqkv16 = (const _Float16*)(base + L.wqkv16); a.bqkv32 = (const float*)(base + L.bqkv32);
-    a.wadd16 = (const _Float16*)(base + L.wadd16); a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
+    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
+    a.wtiles = (const _Float16*)(base + L.wqkv16); a.bqkv32 = (const float*)(base + L.bqkv32);
+    a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
     a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;
-    const int pitch = ((L.KP > L.DP ? L.KP : L.DP) + 8) * 2;
-    const size_t lds = (size_t)3 * 32 * pitch;
+    const size_t lds = (size_t)3 * F16_SLOT;
+    { const char* e = getenv("NRMS_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
     const bool train = f.t16 != nullptr;
     const void* fn = train ? (const void*)fused_fwd16_kernel<true> : (const void*)fused_fwd16_kernel<false>;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("fused_fwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
     TimingScope ts("fused_fwd16", stream);
-    const dim3 grid(cdiv(f.n_seq, F16_WAVES));
+    const dim3 grid(cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 1 : 0));    // two lists: one more partial group
     if (train) hipLaunchKernelGGL(fused_fwd16_kernel<true>, grid, dim3(F16_THREADS), lds, stream, a);
     else hipLaunchKernelGGL(fused_fwd16_kernel<false>, grid, dim3(F16_THREADS), lds, stream, a);
     return check_launch("fused_fwd16");

@@ -336,7 +336,8 @@ struct Fused16Fwd {
     const void* x16;          // [rows][KP] fp16
     const int* pos;           // token -> x16 row (-1: zero row) or null (row = token)
     const int64_t* ids;       // non-null: sequences whose ids are all 0 take the closed form (padding row is zero)
-    const int* order;         // optional permutation of the sequences
+    const int* order;         // optional [2][n_seq] from launch_title_order (+ order_cnt[2]): live titles, then all-padding ones
+    const int* order_cnt;
     void* ctx16;              // [n_seq*S][DP] fp16 (always written: the kernel reads it back)
     void* t16;                // [n_seq*S][QP] fp16 or null (inference)
     float* w;                 // [n_seq*S] or null
@@ -344,6 +345,7 @@ struct Fused16Fwd {
     Dropout drop;             // context dropout
 };
 int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream);
+int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream);
 
 // embed.hip
 // dst[i] = src[i] if 0 <= src[i] < vocab else 0; *n_bad += ids replaced (dst may alias src)

@@ -310,7 +310,7 @@ __global__ void ce_loss_kernel(int B, int C, const float* scores, float* loss_su
 }
 
 __global__ void adam_kernel(size_t n4, size_t n, float* p, const float* g, float* m, float* v, float step_size,
-                            float b1, float b2, float inv_sqrt_bc2, float eps, float gscale) {
+                            float b1, float b2, float omb1, float omb2, float inv_sqrt_bc2, float eps, float gscale) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
@@ -319,8 +319,8 @@ __global__ void adam_kernel(size_t n4, size_t n, float* p, const float* g, float
         f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            mv[e] = b1 * mv[e] + (1.0f - b1) * gv[e];
-            vv[e] = b2 * vv[e] + (1.0f - b2) * gv[e] * gv[e];
+            mv[e] = b1 * mv[e] + omb1 * gv[e];
+            vv[e] = b2 * vv[e] + omb2 * gv[e] * gv[e];
             const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
             pv[e] -= step_size * (mv[e] / denom);
         }
@@ -332,8 +332,8 @@ __global__ void adam_kernel(size_t n4, size_t n, float* p, const float* g, float
     const size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
         const float gv = g[t] * gscale;
-        const float mv = b1 * m[t] + (1.0f - b1) * gv;
-        const float vv = b2 * v[t] + (1.0f - b2) * gv * gv;
+        const float mv = b1 * m[t] + omb1 * gv;
+        const float vv = b2 * v[t] + omb2 * gv * gv;
         m[t] = mv; v[t] = vv;
         p[t] -= step_size * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
     }
@@ -430,16 +430,18 @@ extern "C" int nrms_ce_loss_fwd_bwd(int32_t B, int32_t C, const float* scores, f
     return check_launch("ce_loss");
 }
 
-extern "C" int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                              float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+extern "C" int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
+                              double beta1, double beta2, double eps, int32_t step, float grad_scale, void* stream) {
     NRMS_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad arguments");
     NRMS_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                  "adam_step: buffers must be 16-byte aligned");
     if (n == 0) return NRMS_OK;
     // torch.optim.Adam: step_size = lr / (1 - b1^t); denom = sqrt(v)/sqrt(1 - b2^t) + eps
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    // hyper-parameters arrive as doubles, as torch holds them: 1 - beta is formed in double and rounded once
+    // (float(1 - 0.999) != 1 - float(0.999): 1.3e-5 relative in exp_avg_sq)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     hipStream_t s = (hipStream_t)stream;
     const size_t n4 = n / 4;
@@ -448,7 +450,7 @@ extern "C" int nrms_adam_step(size_t n, float* param, const float* grad, float* 
     if (blocks < 1) blocks = 1;
     TimingScope ts("adam", s);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, n4, n, param, grad, exp_avg, exp_avg_sq, step_size,
-                       beta1, beta2, inv_sqrt_bc2, eps, grad_scale);
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), inv_sqrt_bc2, (float)eps, grad_scale);
     return check_launch("adam");
 }
 

@@ -182,7 +182,7 @@ class NRMSEngine:
         d, q = self.dims.word_embed_size, self.dims.query_vector_dim
         if desc is not None and desc.precision == _lib.NRMS_PRECISION_FP16:
             # fp16 activations with padded pitches (include/nrms_hip.h, nrms_encoder_acts)
-            KP, DP, QP = -(-d // 32) * 32, 32 * desc.n_heads, -(-q // 32) * 32
+            KP, DP, QP = _lib.NRMS_FP16_KP, _lib.NRMS_FP16_DP, _lib.NRMS_FP16_QP
             h = torch.float16
             x = self._buf(tag + ".x16", M * KP, h)
             ctx = self._buf(tag + ".ctx16", M * DP, h)
@@ -418,8 +418,8 @@ class NRMSEngine:
     def adam_step(self, flat, gflat, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                   grad_scale=1.0):
         rc = self.lib.nrms_adam_step(C.c_size_t(flat.numel()), _lib.ptr(flat), _lib.ptr(gflat), _lib.ptr(exp_avg),
-                                     _lib.ptr(exp_avg_sq), C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]),
-                                     C.c_float(eps), int(step), C.c_float(grad_scale), _stream())
+                                     _lib.ptr(exp_avg_sq), C.c_double(lr), C.c_double(betas[0]), C.c_double(betas[1]),
+                                     C.c_double(eps), int(step), C.c_float(grad_scale), _stream())
         _lib.check(rc, "nrms_adam_step")
 
     def impression_auc(self, scores, labels, lens):
@@ -526,8 +526,10 @@ class NRMSEngine:
             cand_mask = cand_mask.contiguous()
         return self.click_scores(cand, user, cand_mask)
 
-    def dropout_keep_mask(self, seed, site, n_rows, p_drop):
-        d = self.dims.word_embed_size
+    def dropout_keep_mask(self, seed, site, n_rows, p_drop, d=None):
+        """Keep mask of a dropout site over [n_rows, d] (d defaults to the model width; the fp16 mode's context
+        dropout runs over the padded width 32 * n_heads)."""
+        d = self.dims.word_embed_size if d is None else int(d)
         keep = torch.empty(n_rows * d, dtype=torch.uint8, device=self.device)
         rc = self.lib.nrms_dropout_keep_mask(C.c_uint64(seed), site, C.c_int64(n_rows), d, C.c_float(p_drop),
                                              _lib.ptr(keep), _stream())

@@ -1,0 +1,138 @@
+"""precision = "fp16": the fused one-wavefront-per-sequence kernels (csrc/fused16.hip) against the reference
+fixtures and the oracle.  fp16 operands carry 11 significant bits, so the bar here is north_star's own
+(scores within 1e-4 of the reference), not the 1e-5 of the fp32 / bf16x3 modes; the measured errors are printed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_news_recommender_amd import synth
+from tests.test_hip_parity import make_model, tbatch
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-4          # north_star: click scores within 1e-4 of the reference
+VEC_TOL = 1.5e-3          # news / user vectors (norm ~ 1..10): 2^-11 relative per rounding
+
+
+def _padded_to_model_cols(keep_padded, n_heads, dk):
+    """keep mask over the padded [.., 320] context layout (32 columns per head) -> the model's [.., n_heads * dk]."""
+    k = keep_padded.reshape(keep_padded.shape[0], 10, 32)[:, :n_heads, :dk]
+    return k.reshape(keep_padded.shape[0], n_heads * dk)
+
+
+def test_fp16_scores_within_bar_of_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_mind.npz"), allow_pickle=False)
+    shape = synth.G2_MIND
+    params = synth.make_params(shape, seed=21)
+    batch = synth.make_batch(shape, seed=22, ragged=True)
+    model = make_model(shape, params, precision="fp16").eval()
+    B, H, L = batch["browsed_titles"].shape
+    with torch.no_grad():
+        for dedup in (True, False):
+            model.dedup_inference = dedup
+            s = model(tbatch(batch)).cpu().numpy()
+            err = float(np.abs(s - g["scores"]).max())
+            print("fp16 g2 (dedup=%s): max |score - reference| = %.3e" % (dedup, err))
+            assert err < SCORE_TOL
+        hist = model.get_news_vector(torch.from_numpy(batch["browsed_titles"]).reshape(B * H, L)).view(B, H, -1)
+    verr = float(np.abs(hist.cpu().numpy() - g["hist"]).max())
+    print("fp16 g2: max |news vector - reference| = %.3e (scale %.2f)" % (verr, float(np.abs(g["hist"]).max())))
+    assert verr < VEC_TOL
+
+
+@pytest.mark.parametrize("case", ["g1_odd", "tiny", "bench_small", "all_padding", "nonzero_pad_row"])
+def test_fp16_forward_shapes_against_oracle(case):
+    """Both encoders through the fused kernel (histories of at most 32 slots) on awkward shapes: d_k = 6 with 10
+    heads (KP = 64, DP = 320, QP = 32), minimum sizes, all-padding titles (closed form), an empty-history user,
+    masked candidates, a table whose padding row is not zero (dense path)."""
+    from oracle import nrms_oracle as orc
+    kw = dict(seed=102, ragged=True, min_title=1, empty_history_user=True, all_pad_title=True, mask_some_candidates=True)
+    pad_zero = True
+    if case == "g1_odd":
+        shape = synth.G1_ODD
+    elif case == "tiny":
+        shape = synth.Shape(n_words=64, word_embed_size=8, num_attention_heads=2, query_vector_dim=4, batch_size=1,
+                            history_len=1, n_candidates=1, n_words_title=1)
+        kw = dict(seed=102, ragged=True, min_title=1)
+    elif case == "bench_small":
+        shape = synth.Shape(n_words=1000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                            batch_size=9, history_len=32, n_candidates=5, n_words_title=30)
+    elif case == "all_padding":
+        shape = synth.Shape(n_words=300, word_embed_size=60, num_attention_heads=6, query_vector_dim=32, batch_size=5,
+                            history_len=9, n_candidates=4, n_words_title=11)
+    else:
+        shape = synth.Shape(n_words=300, word_embed_size=120, num_attention_heads=6, query_vector_dim=64, batch_size=12,
+                            history_len=20, n_candidates=4, n_words_title=17)
+        pad_zero = False
+    params = synth.make_params(shape, seed=101, pad_row_zero=pad_zero)
+    batch = synth.make_batch(shape, **kw)
+    if case == "all_padding":
+        batch["browsed_titles"][:] = 0
+        batch["candidate_titles"][:] = 0
+    model = make_model(shape, params, precision="fp16").eval()
+    model.dedup_inference = False
+    with torch.no_grad():
+        s = model(tbatch(batch)).cpu().numpy()
+    assert model.engine.pad_row_zero is pad_zero
+    p = orc.to_torch(params)
+    with torch.no_grad():
+        o_scores, aux = orc.forward(p, batch, shape.num_attention_heads)
+    o_scores = o_scores.numpy()
+    valid = batch["candidate_mask"] == 1
+    err = float(np.abs(s - o_scores)[valid].max())
+    print("fp16 %s: max |score - oracle| = %.3e (score scale %.3f)" % (case, err, float(np.abs(o_scores[valid]).max())))
+    assert err < 3e-4 * max(1.0, float(np.abs(o_scores[valid]).max()) / 0.1)
+    assert (s[~valid] == np.float32(-1e9)).all()
+    # the encoders on their own
+    B, H, L = batch["browsed_titles"].shape
+    with torch.no_grad():
+        nv = model.get_news_vector(torch.from_numpy(batch["browsed_titles"]).reshape(B * H, L)).view(B, H, -1)
+        uv = model.get_user_vector(torch.from_numpy(aux["hist"].numpy()))
+    assert float(np.abs(nv.cpu().numpy() - aux["hist"].numpy()).max()) < VEC_TOL
+    assert float(np.abs(uv.cpu().numpy() - aux["user"].numpy()).max()) < VEC_TOL
+
+
+def test_fp16_train_mode_forward_replays_its_dropout_masks():
+    """Dropout on, no backward: the fused kernel's masks (embedding dropout: the fp32 path's counters; context
+    dropout: counters over the padded [tokens, 32 n_heads] layout) exported and replayed through the oracle."""
+    from oracle import nrms_oracle as orc
+    shape = synth.Shape(n_words=500, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
+                        batch_size=6, history_len=9, n_candidates=4, n_words_title=12)
+    params = synth.make_params(shape, seed=5)
+    batch = synth.make_batch(shape, seed=6, ragged=True, min_title=2, all_pad_title=True)
+    model = make_model(shape, params, dropout=0.2, precision="fp16").train()
+    tb = {k: v.cuda() for k, v in tbatch(batch).items()}
+    eng = model.engine
+    seed = 0x1234567
+    with torch.no_grad():
+        s = eng.forward(model._flat, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=False,
+                        p_drop=0.2, seed=seed).cpu().numpy()
+    n_titles = shape.batch_size * (shape.history_len + shape.n_candidates)
+    L, d, h = shape.n_words_title, shape.word_embed_size, shape.num_attention_heads
+    ke = eng.dropout_keep_mask(seed, 0, n_titles * L, 0.2).cpu().view(n_titles, L, d)
+    kc_pad = eng.dropout_keep_mask(seed, 1, n_titles * L, 0.2, d=320).cpu().numpy()
+    kc = torch.from_numpy(_padded_to_model_cols(kc_pad, h, d // h)).view(n_titles, L, d)
+    assert 0.77 < float(kc.float().mean()) < 0.83
+    pt = orc.to_torch(params)
+    with torch.no_grad():
+        o_scores, _ = orc.forward(pt, batch, h, p_drop=0.2, keep={"embed": ke, "ctx": kc})
+    err = float(np.abs(s - o_scores.numpy()).max())
+    print("fp16 dropout replay: max |score - oracle| = %.3e" % err)
+    assert err < 3e-4
+
+
+def test_fp16_mode_rejects_shapes_outside_the_fused_kernels():
+    """The C ABI refuses what the fused kernels do not cover (the engine routes such encoder passes to bf16x3)."""
+    import ctypes as C
+    from pytorch_news_recommender_amd import _lib
+    lib = _lib.load()
+    for kw in (dict(seq_len=33), dict(d_model=384, n_heads=12), dict(n_heads=5), dict(q_dim=256), dict(use_output_proj=1),
+               dict(mask_mode=1)):
+        f = dict(n_seq=4, seq_len=30, d_model=300, n_heads=10, q_dim=200, vocab=0, p_drop_embed=0.0, p_drop_ctx=0.0,
+                 precision=_lib.NRMS_PRECISION_FP16, use_output_proj=0, mask_mode=0, flags=0, seed=0)
+        f.update(kw)
+        desc = _lib.EncoderDesc(**f)
+        assert lib.nrms_encoder_fwd_scratch_bytes(C.byref(desc)) == 0
+        assert b"fp16" in lib.nrms_last_error()
