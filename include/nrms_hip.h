@@ -84,6 +84,10 @@ typedef struct nrms_encoder_desc {
                               bit 1: additive-attention mask -> -1e9 (nrms_v1.py:100-101); 0 = nrms_v0 */
     int32_t  flags;        /* NRMS_FLAG_*; 0 = none */
     uint64_t seed;         /* counter-based RNG key for the dropout masks (per step) */
+    float    loss_scale;   /* NRMS_PRECISION_FP16 backward only: the fp16 gradient tensors are carried multiplied by this
+                              power of two and the results divided by it (<= 0: 65536).  Pick ~128 x the global batch:
+                              d(scores) is O(1/batch) and fp16 runs out of range below 6e-5 */
+    int32_t  reserved;     /* 0 */
 } nrms_encoder_desc;
 
 /* Parameters, in the reference's own tensor layout ([out,in] Linear weights).

@@ -30,7 +30,7 @@ class EncoderDesc(C.Structure):
                 ("n_heads", C.c_int32), ("q_dim", C.c_int32), ("vocab", C.c_int32),
                 ("p_drop_embed", C.c_float), ("p_drop_ctx", C.c_float), ("precision", C.c_int32),
                 ("use_output_proj", C.c_int32), ("mask_mode", C.c_int32), ("flags", C.c_int32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("loss_scale", C.c_float), ("reserved", C.c_int32)]
 
 
 class EncoderWeights(C.Structure):

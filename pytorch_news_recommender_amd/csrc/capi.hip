@@ -233,6 +233,83 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     return launch_fused_fwd16(f, s);
 }
 
+// ---- fp16 backward workspace: fused16_bwd_layout | live | pos | n_live | compaction scratch | order | order_cnt |
+//      compact dX (news encoder) | scatter scratch
+struct Bwd16Layout { size_t fused, live, pos, n_live, cscr, order, order_cnt, dxc, sscr, total; };
+static Bwd16Layout bwd16_layout(const nrms_encoder_desc* d) {
+    Bwd16Layout L;
+    const size_t M = (size_t)d->n_seq * d->seq_len;
+    const bool gather = d->vocab > 0;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.fused = take(fused16_bwd_layout((long)M, d->n_seq).total);
+    L.live = take(gather ? M * sizeof(int) : 0);
+    L.pos = take(gather ? M * sizeof(int) : 0);
+    L.n_live = take(gather ? 256 : 0);
+    L.cscr = take(gather ? compact_scratch_ints((long)M) * sizeof(int) : 0);
+    L.order = take(gather ? (size_t)2 * d->n_seq * sizeof(int) : 0);
+    L.order_cnt = take(gather ? 256 : 0);
+    L.dxc = take(gather ? M * d->d_model * sizeof(float) : 0);
+    L.sscr = take(gather ? scatter_grouped_scratch_ints((long)M, d->vocab) * sizeof(int) : 0);
+    L.total = off;
+    return L;
+}
+
+static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids, const float* x,
+                         const nrms_encoder_acts* acts, const float* dout, const nrms_encoder_grads* grads, float* dx,
+                         void* workspace, size_t workspace_bytes, hipStream_t s) {
+    NRMS_REQUIRE(w && acts && dout && grads && workspace, "encoder_bwd(fp16): null argument");
+    NRMS_REQUIRE(acts->x && acts->ctx && acts->t && acts->w, "encoder_bwd(fp16): acts.x, ctx, t, w are required");
+    NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec, "encoder_bwd(fp16): null gradient buffer");
+    const bool gather = desc->vocab > 0;
+    NRMS_REQUIRE(gather ? (ids != nullptr && grads->table != nullptr) : (dx != nullptr), "encoder_bwd(fp16): %s missing",
+                 gather ? "ids / grads.table" : "dx");
+    const Bwd16Layout L = bwd16_layout(desc);
+    if (workspace_bytes < L.total) { set_error("encoder_bwd(fp16): workspace %zu < required %zu bytes", workspace_bytes, L.total); return NRMS_EWORKSPACE; }
+    NRMS_REQUIRE(((uintptr_t)workspace & 255) == 0, "encoder_bwd(fp16): workspace must be 256-byte aligned");
+    if (desc->n_seq == 0) return NRMS_OK;
+    const int S = desc->seq_len, d = desc->d_model;
+    const long M = (long)desc->n_seq * S;
+    char* base = (char*)workspace;
+    Fused16Bwd f{};
+    f.n_seq = desc->n_seq; f.S = S; f.d = d; f.h = desc->n_heads; f.q = desc->q_dim;
+    f.workspace = base + L.fused;
+    f.w_qkv = w->w_qkv; f.b_qkv = w->b_qkv; f.w_add = w->w_add; f.q_vec = w->q_vec;
+    f.x16 = acts->x; f.ctx16 = acts->ctx; f.t16 = acts->t; f.w = acts->w; f.dout = dout;
+    f.loss_scale = desc->loss_scale > 0.f ? desc->loss_scale : 65536.f;
+    f.drop = make_dropout(desc->seed, desc->p_drop_ctx);
+    f.dw_qkv = grads->w_qkv; f.db_qkv = grads->b_qkv; f.dw_add = grads->w_add; f.db_add = grads->b_add; f.dq_vec = grads->q_vec;
+    int rc;
+    int* live = (int*)(base + L.live);
+    int* n_live = (int*)(base + L.n_live);
+    if (gather) {
+        // the token lists of the forward live in ITS scratch, which later forward calls reuse: rebuild them
+        int* pos = (int*)(base + L.pos);
+        rc = launch_compact_live_rows(M, ids, live, pos, n_live, (int*)(base + L.cscr), s);
+        if (rc) return rc;
+        if (skip_pad_rows(desc)) {
+            int* order = (int*)(base + L.order);
+            int* order_cnt = (int*)(base + L.order_cnt);
+            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s);
+            if (rc) return rc;
+            f.pos = pos; f.n_rows_dev = n_live; f.ids = ids; f.order = order; f.order_cnt = order_cnt;
+        }
+        f.dx = (float*)(base + L.dxc);
+    } else {
+        f.dx = dx;
+    }
+    rc = launch_fused_bwd16(f, s);
+    if (rc) return rc;
+    if (gather) {
+        const Dropout drop_e = make_dropout(desc->seed, desc->p_drop_embed);
+        if (skip_pad_rows(desc))
+            rc = launch_scatter_grouped(M, desc->vocab, d, ids, live, n_live, f.dx, drop_e, grads->table, (int*)(base + L.sscr), s);
+        else       // dense rows (one per token): the atomic scatter walks the live list over the dense rows
+            rc = launch_scatter_dense_rows(M, d, ids, live, n_live, f.dx, drop_e, grads->table, s);
+    }
+    return rc;
+}
+
 extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids,
                                 const float* x, const uint8_t* mask, const nrms_encoder_acts* acts, float* out,
                                 void* stream) {
@@ -328,7 +405,7 @@ extern "C" size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc) 
 
 extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc) {
     if (validate_desc(desc, "encoder_bwd_workspace_bytes")) return 0;
-    if (desc->precision == NRMS_PRECISION_FP16) { set_error("encoder_bwd: the fp16 backward is not built yet"); return 0; }
+    if (desc->precision == NRMS_PRECISION_FP16) return bwd16_layout(desc).total;
     return bwd_layout(desc).total;
 }
 
@@ -350,7 +427,7 @@ extern "C" int nrms_encoder_bwd_wqkv(const nrms_encoder_desc* desc, const int64_
                                      size_t workspace_bytes, void* stream) {
     int rc = validate_desc(desc, "encoder_bwd_wqkv");
     if (rc) return rc;
-    NRMS_REQUIRE(desc->precision != NRMS_PRECISION_FP16, "encoder_bwd_wqkv: the fp16 backward is not built yet");
+    if (desc->precision == NRMS_PRECISION_FP16) return NRMS_OK;      // fp16 mode: nrms_encoder_bwd has done everything
     NRMS_REQUIRE(acts && grads && workspace, "encoder_bwd_wqkv: null argument");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv, "encoder_bwd_wqkv: null gradient buffer");
     const bool gather = desc->vocab > 0;
@@ -369,7 +446,8 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
                                 void* stream) {
     int rc = validate_desc(desc, "encoder_bwd");
     if (rc) return rc;
-    NRMS_REQUIRE(desc->precision != NRMS_PRECISION_FP16, "encoder_bwd: the fp16 backward is not built yet");
+    if (desc->precision == NRMS_PRECISION_FP16)
+        return encoder_bwd16(desc, w, ids, x, acts, dout, grads, dx, workspace, workspace_bytes, (hipStream_t)stream);
     NRMS_REQUIRE(w && acts && dout && grads && workspace, "encoder_bwd: null argument");
     NRMS_REQUIRE(acts->qkv && acts->ctx && acts->t && acts->w, "encoder_bwd: all saved activations are required");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec,

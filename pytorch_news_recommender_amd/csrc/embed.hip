@@ -201,6 +201,32 @@ __global__ __launch_bounds__(256) void scatter_dropout_compact_kernel(unsigned d
     }
 }
 
+// dtable[ids[t], :] += dx[t, :] * keep(t, :) / (1 - p) for the live tokens t = live[r], r < *n_live (dx has one row per
+// TOKEN): the fp16 mode's dense path (embedding row 0 not zero).  Float atomics: order-dependent in the last bits.
+__global__ __launch_bounds__(256) void scatter_dense_rows_kernel(unsigned d, const int64_t* ids, const int* live,
+                                                                 const int* n_live, const float* dx, Dropout drop, float* dtable) {
+    const unsigned long total = (unsigned long)(*n_live) * d;
+    const unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const unsigned long r = i / d;
+        const unsigned c = (unsigned)(i - r * d);
+        const long t = live[r];
+        float v = dx[t * (long)d + c];
+        if (drop.thresh != 0u) v *= dropout_scale1(drop.seed, 0u, (uint64_t)(t * d + c), drop.thresh, drop.inv_keep);
+        atomicAdd(dtable + ids[t] * (long)d + c, v);
+    }
+}
+
+int launch_scatter_dense_rows(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
+                              const Dropout& drop, float* dtable, hipStream_t stream) {
+    if (M <= 0) return NRMS_OK;
+    int blocks = cdiv(M * d, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    TimingScope ts("scatter_dropout", stream);
+    hipLaunchKernelGGL(scatter_dense_rows_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)d, ids, live, n_live, dx, drop, dtable);
+    return check_launch("scatter_dense_rows");
+}
+
 int launch_scatter_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
                                    const Dropout& drop, float* dtable, hipStream_t stream) {
     if (M <= 0) return NRMS_OK;

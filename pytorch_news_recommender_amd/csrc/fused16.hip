@@ -22,47 +22,9 @@
 //   wadd16 [QP/32 tiles][32][DP]  columns in the same P16 order (QP = 224 >= q);   T16 [n_seq*S][QP] natural order
 #include <stdlib.h>
 
-#include "gemm.h"
+#include "fused16.h"
 
 namespace nrms {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x16 mfma32h(const h8& a, const h8& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// registers 8s..8s+7 of a 32x32 accumulator as the fp16 operand of k-step s (rows of the accumulator = k)
-__device__ __forceinline__ h8 acc_frag(const f32x16& x, int s) {
-    h8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (_Float16)x[8 * s + j];
-    return r;
-}
-
-// padded feature index held by register r of lane-half hh (accumulator row), and the P16 memory position of it
-__device__ __forceinline__ int p16_pos(int fpad) {           // natural padded feature -> position inside its row
-    const int b = fpad >> 4, t = fpad & 15;
-    const int hh = (t >> 2) & 1, j = ((t >> 3) << 2) | (t & 3);
-    return 16 * b + 8 * hh + j;
-}
-
-constexpr int F16_WAVES = 4;            // waves (= sequences) per workgroup; two workgroups share a CU (one wave per SIMD each),
-constexpr int F16_THREADS = 64 * F16_WAVES;   // so the two waves of a SIMD are in different phases: one's MFMAs cover the other's VALU / waits
-// Pitches are compile-time constants (every inner loop fully unrolled, no guards: a guarded MFMA costs a branch
-// and a full LDS wait each).  Smaller models run zero padded at these sizes.
-constexpr int F16_KS = 20;            // k-steps of 16 input features held in registers: KP = 320 >= d
-constexpr int F16_CS = 20;            // ctx k-steps: DP = 320 >= 32 h
-constexpr int F16_QT = 7;             // q tiles of 32: QP = 224 >= q
-constexpr int F16_KP = 16 * F16_KS, F16_DP = 16 * F16_CS, F16_QP = 32 * F16_QT;
-constexpr int F16_PITCH = (F16_KP + 8) * 2;              // LDS row pitch in bytes: +16 B => conflict-free b128 reads
-constexpr int F16_SLOT = 32 * F16_PITCH;
-constexpr int F16_RC = F16_KP / 8;                       // 16-byte chunks per tile row
-static_assert(F16_KP == F16_DP, "one tile geometry for the head tiles and the additive tiles");
-constexpr int F16_STG = (32 * F16_RC + F16_THREADS - 1) / F16_THREADS;      // staging chunks (16 B) per thread and tile
-constexpr bool F16_STG_EXACT = 32 * F16_RC == F16_STG * F16_THREADS;
 
 struct Fwd16Args {
     int n_seq, S, d, h, dk, q;
@@ -82,89 +44,6 @@ struct Fwd16Args {
     Dropout drop;             // context dropout (site 1, element index = token * DP + padded feature)
     int dbg;                  // timing experiments only (NRMS_F16_DBG): 1 = no tile staging after the prologue
 };
-
-// ---- the weight-tile ring shared by the forward and the backward kernel: tile n lives in LDS slot n % 3; while
-// tile n is consumed, tile n + 2 travels global -> registers -> LDS.  One barrier per tile.
-struct TileRing {
-    char* smem;
-    const _Float16* src;          // tiles are contiguous [n_tiles][32][F16_KP]
-    int n_tiles, tid, l32, hh;
-    int dbg;
-    h8 stg[F16_STG];
-    __device__ __forceinline__ void load(int n) {
-        if (n >= n_tiles) return;
-        if (dbg & 1) return;
-        const _Float16* t = src + (long)n * (32 * F16_KP) + tid * 8;
-#pragma unroll
-        for (int i = 0; i < F16_STG; ++i)
-            if (F16_STG_EXACT || i + 1 < F16_STG || tid + F16_THREADS * i < 32 * F16_RC)
-                stg[i] = *reinterpret_cast<const h8*>(t + (long)F16_THREADS * 8 * i);
-    }
-    __device__ __forceinline__ void store(int n) {
-        if (n >= n_tiles) return;
-        if (dbg & 1) return;
-        char* dst = smem + (n % 3) * F16_SLOT;
-#pragma unroll
-        for (int i = 0; i < F16_STG; ++i) {
-            const int c = tid + F16_THREADS * i;
-            if (F16_STG_EXACT || i + 1 < F16_STG || c < 32 * F16_RC) {
-                const int row = c / F16_RC, col = c - row * F16_RC;
-                *reinterpret_cast<h8*>(dst + row * F16_PITCH + col * 16) = stg[i];
-            }
-        }
-    }
-    // row l32 of tile n, k-step s: 8 consecutive k for this lane half
-    __device__ __forceinline__ h8 frag(int n, int s) const {
-        return *reinterpret_cast<const h8*>(smem + (n % 3) * F16_SLOT + l32 * F16_PITCH + (16 * s + 8 * hh) * 2);
-    }
-};
-
-// acc += (W tile n) x (register operand), 20 k-steps as 5 groups of 4: the weight fragments of group g + 1 are read
-// from LDS while the MFMAs of group g issue (two named register sets; the scheduling barriers keep hipcc from hoisting
-// all twenty reads to the top, which spills).  W_IS_A: acc = W x^T (features x tokens); else acc = x W^T.
-template <bool W_IS_A, int NS>
-__device__ __forceinline__ void tile_mma(f32x16& acc, const TileRing& ring, int n, const h8 (&op)[NS]) {
-    static_assert(NS % 4 == 0, "k-steps in groups of 4");
-    h8 wa[4], wb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wa[i] = ring.frag(n, i);
-#pragma unroll
-    for (int g = 0; g < NS / 4; ++g) {
-        if (g + 1 < NS / 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (g & 1) wa[i] = ring.frag(n, 4 * (g + 1) + i);
-                else wb[i] = ring.frag(n, 4 * (g + 1) + i);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const h8& w = (g & 1) ? wb[i] : wa[i];
-            acc = W_IS_A ? mfma32h(w, op[4 * g + i], acc) : mfma32h(op[4 * g + i], w, acc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// r[4g + e] = v[8g + 4hh + e]: a per-ROW vector (bias) in the accumulator's register order.  Loaded at the top of a
-// tile step and ADDED after the MFMAs: as the accumulator's initial value it would put a global-load latency in
-// front of every tile.
-__device__ __forceinline__ f32x16 rows_of(const float* v, int hh) {
-    f32x16 r;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(v + 8 * g + 4 * hh);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[4 * g + e] = bb[e];
-    }
-    return r;
-}
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = 0.f;
-    return r;
-}
 
 template <bool TRAIN>
 __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel(Fwd16Args a) {

@@ -1,0 +1,804 @@
+// fp16 mode, backward: one wavefront per sequence, mirroring fused16.hip.
+//
+//   dout [n_seq, d] fp32 --(dout16_kernel: x loss scale, fp16, head-padded P16 order)--> fused_bwd16:
+//     pooling backward (ds, dZ = ds q (1 - T^2)) -> dZ16 (for d(w_add)), column sums -> d(q_vec), d(b_add)
+//     per head: d(ctx)^T = Wadd_h^T dZ^T + w (x) dout, dropout mask;  Q^T, K^T, V^T recomputed from x16;
+//               P^T recomputed; dP^T = V d(ctx)^T; dS^T = P^T o (dP^T - delta);
+//               dV^T = d(ctx)^T P, dQ^T = K^T dS^T, dK^T = Q^T dS  -> dqkv16 rows of the live tokens, d(b_qkv) sums
+//   then  gemm16_dx:  dX = dQKV W'_qkv (live rows, fp32 out for the embedding scatter / the user encoder's input gradient)
+//         gemm16_tn:  d(W_qkv) = dQKV^T X,  d(W_add) = dZ^T ctx   (contraction over token rows: ds_read_b64_tr_b16 operands)
+//
+// Every product whose contraction index sits in the REGISTERS of a 32x32 accumulator takes that accumulator as an
+// operand directly (acc_frag); where the contraction index sits on the LANES, the tile is first transposed by one
+// extra product with a (k-permuted) identity, which costs 2 MFMAs and no LDS traffic.
+// Replaces autograd through model/nrms_v0.py:13-23,46-76,100-126,154-176,188-199 (`loss.backward()`, train_eval.py:126).
+#include <stdlib.h>
+
+#include "fused16.h"
+
+namespace nrms {
+
+constexpr int B16_RED_QKV = 3 * 10 * 32;                  // d(b_qkv) sums, [tile][32]
+constexpr int B16_RED = B16_RED_QKV + 2 * F16_QP;         // + d(b_add)[QP] + d(q_vec)[QP]
+constexpr int B16_DQ = 96 * 10;                           // dqkv16 row pitch: [head][Q|K|V][32]
+
+struct Bwd16Args {
+    int n_seq, S, d, h, dk, q;
+    int n_groups;               // ceil(n_seq / F16_WAVES) (+1 with an order list)
+    const _Float16* x16;        // [rows][KP]
+    const int* pos;             // token -> x16 / dqkv16 row, -1 = padding token; null: row = token
+    const int64_t* ids;         // non-null: all-padding titles take the closed form
+    const int* order;           // as in the forward
+    const int* order_cnt;
+    const _Float16* btiles;     // [4h][32][KP]: per head  Wadd_h^T (32 features x QP) | W'_q | W_k | W_v
+    const float* bqkv32;        // [3h][32]
+    const _Float16* qv16;       // [QP]
+    const _Float16* ctx16;      // [n_seq*S][DP]   (forward)
+    const _Float16* t16;        // [n_seq*S][QP]   (forward)
+    const float* w;             // [n_seq*S]       (forward)
+    const _Float16* dout16;     // [n_seq][DP]  x loss scale, P16 order
+    _Float16* dz16;             // [n_seq*S][QP]
+    _Float16* dqkv16;           // [rows][B16_DQ]
+    float* red;                 // [gridDim.x][B16_RED] per-workgroup column sums (reduced afterwards, fixed order)
+    Dropout drop;
+};
+
+// X^T for a 32x32 accumulator X: one product with the k-permuted identity (idf[s][j] = (n == row held as element j))
+__device__ __forceinline__ f32x16 transpose32(const f32x16& x, const h8 (&idf)[2]) {
+    f32x16 z = mfma32h(acc_frag(x, 0), idf[0], zero16());
+    return mfma32h(acc_frag(x, 1), idf[1], z);
+}
+
+// sum over the 16 rows a lane holds
+__device__ __forceinline__ float regsum(const f32x16& x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { s0 += x[4 * g]; s1 += x[4 * g + 1]; s2 += x[4 * g + 2]; s3 += x[4 * g + 3]; }
+    return (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_kernel(Bwd16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem + 3 * F16_SLOT);         // [B16_RED] column sums of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int S = a.S;
+    constexpr int KP = F16_KP, DP = F16_DP, QP = F16_QP;
+
+    for (int i = tid; i < B16_RED; i += F16_THREADS) red[i] = 0.f;
+
+    // constant operands: transposition identity (k-permuted) and the column selectors of the token reductions
+    h8 idf[2], sel[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            idf[s][j] = (_Float16)(l32 == 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3) ? 1.0f : 0.0f);
+            sel[s][j] = (_Float16)(l32 == 16 * s + 8 * hh + j ? 1.0f : 0.0f);
+        }
+
+    int n_ne = a.n_seq, n_e = 0, g_ne = a.n_groups;
+    if (a.order != nullptr) {
+        n_ne = a.order_cnt[0];
+        n_e = a.order_cnt[1];
+        g_ne = (n_ne + F16_WAVES - 1) / F16_WAVES;
+    }
+    TileRing ring;
+    ring.smem = smem; ring.src = a.btiles; ring.n_tiles = 4 * a.h; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
+
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
+        // ---- which sequence this wave owns in this group
+        int slot_id = grp * F16_WAVES + wave;
+        bool valid;
+        int seq;
+        if (grp < g_ne) { valid = slot_id < n_ne; seq = valid ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0; }
+        else {
+            slot_id -= g_ne * F16_WAVES;
+            valid = slot_id < n_e;
+            seq = valid ? a.order[a.n_seq + slot_id] : 0;
+        }
+        const long tok0 = (long)seq * S;
+        const bool tok_ok = valid && l32 < S;
+        bool empty = false;
+        if (a.ids != nullptr && valid) {
+            const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
+            empty = __ballot(is_pad) == ~0ull;
+        }
+        const bool live = valid && !empty;
+        const bool only_add = __syncthreads_and(live ? 0 : 1) != 0;     // no live title: only the Wadd_h^T tiles are needed
+        // the ring restarts per group: tiles 0 and 1 of this group's stream (stride 4 for an all-padding group)
+        const int tstep = only_add ? 4 : 1;
+        const int n_end = 4 * a.h;
+        ring.n_tiles = n_end;
+        ring.load(0); ring.store(0);                       // slot 0
+        if (!only_add) { ring.load(1); ring.store(1); }    // slot 1
+        // (an all-padding group walks tiles 0, 4, 8, ...; it stages them one ahead, synchronously -- they are rare)
+
+        const long trow = tok0 + (tok_ok ? l32 : 0);                    // clamped token row for loads
+        const float wgt = tok_ok ? a.w[tok0 + l32] : 0.f;
+
+        // ================= pooling backward =================
+        // dw_tok = <dout, ctx_tok>: A = dout (the same row in every lane), B = ctx fragments; all rows of the result equal
+        float dw;
+        {
+            f32x16 acc = zero16();
+            const _Float16* dsrc = a.dout16 + (long)seq * DP + 8 * hh;
+            const _Float16* csrc = a.ctx16 + trow * DP + 8 * hh;
+#pragma unroll
+            for (int g = 0; g < F16_CS / 4; ++g) {
+                h8 da[4], cb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    da[i] = *reinterpret_cast<const h8*>(dsrc + 16 * (4 * g + i));
+                    cb[i] = *reinterpret_cast<const h8*>(csrc + 16 * (4 * g + i));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = mfma32h(da[i], cb[i], acc);
+            }
+            dw = acc[0];
+        }
+        float aw = wgt * dw;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) aw += __shfl_xor(aw, o, 64);
+        const float ds = wgt * (dw - aw);                                // 0 for lanes beyond the sequence (wgt = 0)
+
+        // dZ[tok][q] = ds q_vec[q] (1 - T^2),  U[tok][q] = ds T  (column sums of U = d(q_vec), of dZ = d(b_add))
+#pragma unroll 1
+        for (int t = 0; t < F16_QT; ++t) {
+            f32x16 accz = zero16(), accu = zero16();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int s = 2 * t + s2;
+                const h8 tf = *reinterpret_cast<const h8*>(a.t16 + trow * QP + 16 * s + 8 * hh);
+                const h8 qf = *reinterpret_cast<const h8*>(a.qv16 + 16 * s + 8 * hh);
+                h8 dz, u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float tv = (float)tf[j];
+                    dz[j] = (_Float16)(ds * (float)qf[j] * (1.0f - tv * tv));
+                    u[j] = (_Float16)(ds * tv);
+                }
+                if (tok_ok) *reinterpret_cast<h8*>(a.dz16 + (tok0 + l32) * (long)QP + 16 * s + 8 * hh) = dz;
+                // transposing products: D[tok][n] = X[tok][q = 32 t + n]  (rows = tokens in registers)
+                accz = mfma32h(dz, sel[s2], accz);
+                accu = mfma32h(u, sel[s2], accu);
+            }
+            if (valid) {
+                atomicAdd(red + B16_RED_QKV + 32 * t + l32, regsum(accz));
+                atomicAdd(red + B16_RED_QKV + QP + 32 * t + l32, regsum(accu));
+            }
+        }
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");             // own dz16 rows are re-read per head below
+
+        const long drow = tok_ok && live ? (a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32) : -1;   // dqkv16 row
+        __syncthreads();
+
+        int n = 0;                                    // tile cursor of this group's stream
+#pragma unroll 1
+        for (int head = 0; head < a.h; ++head) {
+            // ---- tile Wadd_h^T: d(ctx)^T[f][tok] = sum_q Wadd[q][f] dZ[tok][q] + w_tok dout[f], then the dropout mask
+            f32x16 dct;
+            {
+                if (only_add) { if (head + 1 < a.h) ring.load(n + 4); }
+                else ring.load(n + 2);
+                h8 zf[16];
+                const _Float16* zsrc = a.dz16 + trow * QP + 8 * hh;
+#pragma unroll
+                for (int s = 0; s < 14; ++s) zf[s] = *reinterpret_cast<const h8*>(zsrc + 16 * s);
+                zf[14] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                zf[15] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (!tok_ok) {
+#pragma unroll
+                    for (int s = 0; s < 14; ++s) zf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+                const h8 d0 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 8 * hh);
+                const h8 d1 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 16 + 8 * hh);
+                dct = zero16();
+                tile_mma<true>(dct, ring, n, zf);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    dct[r] += wgt * (float)d0[r];
+                    dct[8 + r] += wgt * (float)d1[r];
+                }
+                if (a.drop.thresh != 0u) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
+                        const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
+                    }
+                }
+                if (only_add) { if (head + 1 < a.h) ring.store(n + 4); }
+                else ring.store(n + 2);
+                __syncthreads();
+                n += tstep;
+            }
+            if (only_add || !live) {
+                // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
+                const f32x16 dctx = transpose32(dct, idf);               // [tok][f]
+                if (valid) atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx));
+                if (!only_add) {                                         // keep the barrier schedule of the live waves
+                    ring.load(n + 2); ring.store(n + 2); __syncthreads(); ++n;
+                    ring.load(n + 2); ring.store(n + 2); __syncthreads(); ++n;
+                    ring.load(n + 2); ring.store(n + 2); __syncthreads(); ++n;
+                }
+                continue;
+            }
+            // ---- tiles W'_q, W_k, W_v: Q^T, K^T, V^T [f][tok].  The x fragments are re-read per head (640 B per token,
+            // L2 resident): held across the whole head they would push the attention algebra below into scratch
+            f32x16 qt, kt, vt;
+            h8 xf[F16_KS];
+            {
+                const _Float16* xr = a.x16 + (drow < 0 ? 0 : drow) * KP + 8 * hh;
+#pragma unroll
+                for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
+                if (drow < 0) {
+#pragma unroll
+                    for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+            ring.load(n + 2);
+            { const f32x16 b = rows_of(a.bqkv32 + (3 * head) * 32, hh); qt = zero16(); tile_mma<true>(qt, ring, n, xf); qt += b; }
+            ring.store(n + 2);
+            __syncthreads();
+            ++n;
+            ring.load(n + 2);
+            { const f32x16 b = rows_of(a.bqkv32 + (3 * head + 1) * 32, hh); kt = zero16(); tile_mma<true>(kt, ring, n, xf); kt += b; }
+            ring.store(n + 2);
+            __syncthreads();
+            ++n;
+            ring.load(n + 2);
+            { const f32x16 b = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh); vt = zero16(); tile_mma<true>(vt, ring, n, xf); vt += b; }
+            ring.store(n + 2);
+
+            // ---- P^T (rows = keys, columns = queries), as in the forward
+            f32x16 pt = mfma32h(acc_frag(kt, 0), acc_frag(qt, 0), zero16());
+            pt = mfma32h(acc_frag(kt, 1), acc_frag(qt, 1), pt);
+            {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pt[r] = crow32(r, hh) < S ? pt[r] : -3.0e38f;
+                    m = fmaxf(m, pt[r]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = crow32(r, hh) < S ? __expf(pt[r] - m) : 0.f;
+                    pt[r] = p;
+                    sum += p;
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pt[r] *= inv;
+            }
+            // ---- dP^T[j][i] = sum_f V^T[f][j] d(ctx)^T[f][i];  dS^T = P^T o (dP^T - delta_i)
+            f32x16 dst = mfma32h(acc_frag(vt, 0), acc_frag(dct, 0), zero16());
+            dst = mfma32h(acc_frag(vt, 1), acc_frag(dct, 1), dst);
+            {
+                float delta = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) delta += pt[r] * dst[r];
+                delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[r] = pt[r] * (dst[r] - delta);
+            }
+            _Float16* orow = a.dqkv16 + (drow < 0 ? 0 : drow) * (long)B16_DQ + head * 96 + 8 * hh;
+            // ---- dV^T[f][j] = sum_i d(ctx)[i][f] P[i][j]
+            {
+                const f32x16 p = transpose32(pt, idf);                    // [i][j]
+                const f32x16 dctx = transpose32(dct, idf);                // [i][f]
+                atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx)); // d(b_v) = sum_j dV_j = sum_i d(ctx)_i (rows of P sum to 1)
+                f32x16 dv = mfma32h(acc_frag(dctx, 0), acc_frag(p, 0), zero16());
+                dv = mfma32h(acc_frag(dctx, 1), acc_frag(p, 1), dv);
+                if (drow >= 0) {
+                    *reinterpret_cast<h8*>(orow + 64) = acc_frag(dv, 0);
+                    *reinterpret_cast<h8*>(orow + 64 + 16) = acc_frag(dv, 1);
+                }
+            }
+            // ---- dQ'^T[f][i] = sum_j K[j][f] dS^T[j][i]
+            {
+                const f32x16 k = transpose32(kt, idf);                    // [j][f]
+                f32x16 dq = mfma32h(acc_frag(k, 0), acc_frag(dst, 0), zero16());
+                dq = mfma32h(acc_frag(k, 1), acc_frag(dst, 1), dq);
+                if (drow >= 0) {
+                    *reinterpret_cast<h8*>(orow) = acc_frag(dq, 0);
+                    *reinterpret_cast<h8*>(orow + 16) = acc_frag(dq, 1);
+                }
+                atomicAdd(red + (3 * head) * 32 + l32, regsum(transpose32(dq, idf)));
+            }
+            // ---- dK^T[f][j] = sum_i Q'[i][f] dS[i][j]
+            {
+                const f32x16 q = transpose32(qt, idf);                    // [i][f]
+                const f32x16 dsn = transpose32(dst, idf);                 // [i][j]
+                f32x16 dk = mfma32h(acc_frag(q, 0), acc_frag(dsn, 0), zero16());
+                dk = mfma32h(acc_frag(q, 1), acc_frag(dsn, 1), dk);
+                if (drow >= 0) {
+                    *reinterpret_cast<h8*>(orow + 32) = acc_frag(dk, 0);
+                    *reinterpret_cast<h8*>(orow + 32 + 16) = acc_frag(dk, 1);
+                }
+                atomicAdd(red + (3 * head + 1) * 32 + l32, regsum(transpose32(dk, idf)));
+            }
+            __syncthreads();
+            ++n;
+        }
+        if (drow >= 0) {                                          // heads the model does not have: zero columns (dX contracts over all 960)
+            for (int head = a.h; head < 10; ++head) {
+                _Float16* orow = a.dqkv16 + drow * (long)B16_DQ + head * 96 + 8 * hh;
+#pragma unroll
+                for (int c = 0; c < 96; c += 16) *reinterpret_cast<h8*>(orow + c) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        __syncthreads();                                          // the ring restarts: nobody may still read a slot
+    }
+    __syncthreads();
+    float* out = a.red + (long)blockIdx.x * B16_RED;
+    for (int i = tid; i < B16_RED; i += F16_THREADS) out[i] = red[i];
+}
+
+// dout16[n][P16(padded f)] = fp16(dout[n][f] * scale), zero in the padding columns
+__global__ __launch_bounds__(256) void dout16_kernel(long n_seq, int d, int h, int dk, float scale, const float* dout, _Float16* dout16) {
+    const long total = n_seq * F16_DP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / F16_DP;
+        const int p = (int)(i - r * F16_DP);
+        const int b16 = p >> 4, t = p & 15, hh = t >> 3, jj = t & 7;
+        const int fpad = 16 * b16 + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+        const int head = fpad >> 5, f = fpad & 31;
+        float v = 0.f;
+        if (head < h && f < dk) v = dout[r * d + head * dk + f] * scale;
+        dout16[i] = (_Float16)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward weight planes: tile stream of the fused kernel, the dX weight tiles, q_vec in fp16
+struct Prep16bArgs {
+    int d, h, dk, q;
+    const float* w_qkv;   // [3d][d]
+    const float* b_qkv;   // [3d]
+    const float* w_add;   // [q][d]
+    const float* q_vec;   // [q]
+    float* bqkv32;        // [3h][32] (Q part pre-scaled)
+    _Float16* btiles;     // [4h][32][KP]
+    _Float16* xtiles;     // dX GEMM: [2 halves][3 chunks][5][32 rows = input feature][KP cols = dqkv16 column within the chunk]
+    _Float16* qv16;       // [QP]
+};
+
+__global__ __launch_bounds__(256) void prep16b_kernel(Prep16bArgs a) {
+    const float qscale = 1.0f / sqrtf((float)a.dk);
+    constexpr int KP = F16_KP;
+    const long n1 = (long)4 * a.h * 32 * KP, n2 = (long)30 * 32 * KP, n3 = F16_QP, n4 = (long)3 * a.h * 32;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2 + n3 + n4; i += (long)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const int c = (int)(i % KP);
+            const long r = i / KP;
+            const int f = (int)(r & 31), tile = (int)(r >> 5), head = tile >> 2, which = tile & 3;
+            float v = 0.f;
+            if (which == 0) {                                   // Wadd_h^T: row f, column q (natural order)
+                if (f < a.dk && c < a.q) v = a.w_add[(long)c * a.d + head * a.dk + f];
+            } else if (f < a.dk && c < a.d) {
+                v = a.w_qkv[((long)(which - 1) * a.d + head * a.dk + f) * a.d + c] * (which == 1 ? qscale : 1.0f);
+            }
+            a.btiles[i] = (_Float16)v;
+        } else if (i < n1 + n2) {
+            const long j = i - n1;
+            const int c = (int)(j % KP);                        // column inside the 320-wide contraction chunk
+            const long r = j / KP;
+            const int krow = (int)(r & 31);
+            int tile = (int)(r >> 5);                           // ((half * 3) + chunk) * 5 + nt
+            const int nt = tile % 5; tile /= 5;
+            const int chunk = tile % 3, half = tile / 3;
+            const int k = (half * 5 + nt) * 32 + krow;          // input feature (output column of dX)
+            const int m = chunk * KP + c;                       // dqkv16 column
+            const int head = m / 96, rem = m - head * 96, which = rem >> 5, p = rem & 31;
+            const int s = p >> 4, t = p & 15, hh = t >> 3, jj = t & 7;
+            const int f = 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);       // feature held at memory position p (acc_frag order)
+            float v = 0.f;
+            if (head < a.h && f < a.dk && k < a.d)
+                v = a.w_qkv[((long)which * a.d + head * a.dk + f) * a.d + k] * (which == 0 ? qscale : 1.0f);
+            a.xtiles[j] = (_Float16)v;
+        } else if (i < n1 + n2 + n3) {
+            const long j = i - n1 - n2;
+            a.qv16[j] = (_Float16)(j < a.q ? a.q_vec[j] : 0.f);
+        } else {
+            const long j = i - n1 - n2 - n3;
+            const int f = (int)(j & 31), tile = (int)(j >> 5), head = tile / 3, which = tile - 3 * head;
+            a.bqkv32[j] = f < a.dk ? a.b_qkv[which * a.d + head * a.dk + f] * (which == 0 ? qscale : 1.0f) : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dX[r][k] = inv_scale * sum_m dqkv16[r][m] W'[m][k]  for rows r < *n_rows (compact live rows) -- fp32 [rows][ldc].
+// One wave per 32 rows; two passes of 5 output tiles (80 accumulator registers) over 3 contraction chunks of 320.
+struct Dx16Args {
+    int M;                    // upper bound of the rows (sizes the grid)
+    const int* m_dev;         // rows actually present (device), or null
+    const _Float16* a16;      // [rows][B16_DQ]
+    const _Float16* xtiles;   // [30][32][KP]
+    float* c;                 // [rows][ldc]
+    int ldc, d;
+    float inv_scale;
+};
+
+__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void gemm16_dx_kernel(Dx16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
+    const int row0 = (blockIdx.x * F16_WAVES + wave) * 32;
+    if (blockIdx.x * F16_WAVES * 32 >= M) return;                       // whole workgroup beyond the rows (uniform)
+    TileRing ring;
+    ring.smem = smem; ring.src = a.xtiles; ring.n_tiles = 30; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
+    ring.load(0); ring.store(0);
+    ring.load(1); ring.store(1);
+    const int arow = min(row0 + l32, M - 1);                           // clamped: rows past the end are computed, not stored
+    const _Float16* ar = a.a16 + (long)arow * B16_DQ + 8 * hh;
+    __syncthreads();
+    int n = 0;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        f32x16 acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = zero16();
+#pragma unroll 1
+        for (int chunk = 0; chunk < 3; ++chunk) {
+            h8 af[F16_KS];
+#pragma unroll
+            for (int s = 0; s < F16_KS; ++s) af[s] = *reinterpret_cast<const h8*>(ar + chunk * F16_KP + 16 * s);
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) {
+                ring.load(n + 2);
+                tile_mma<false>(acc[nt], ring, n, af);                 // D[row][k] : rows in registers, k on lanes
+                ring.store(n + 2);
+                __syncthreads();
+                ++n;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            const int k = (half * 5 + nt) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + crow32(r, hh);
+                if (row < M && k < a.d) a.c[(long)row * a.ldc + k] = acc[nt][r] * a.inv_scale;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[n][k] = sum_m A[m][n] B[m][k] over the token rows m (fp16 operands, fp32 accumulate): d(W_qkv) = dQKV^T X and
+// d(W_add) = dZ^T ctx.  The contraction runs over ROWS of both row-major operands, so each MFMA operand needs 8
+// consecutive m of one column: 32 rows are staged in LDS as they arrive ([32 m][cols], pitch 8*odd dwords) and read back
+// with ds_read_b64_tr_b16 (a 16-lane group reads 4 rows x 16 columns and gets them column-major).  8 waves = 4 (n) x 2 (k),
+// NTN x NTK tiles of 16x16 per wave (v_mfma_f32_16x16x32_f16: one staged block = one k-step); M is split over
+// workgroups into partial slabs, summed in fixed order by tn16_reduce_kernel (which also maps the internal row /
+// column order back to the reference's parameter layout and removes the loss scale).
+constexpr int T16_MC = 32, T16_THREADS = 512;
+constexpr int T16_AW = 320, T16_BW = 160;                 // staged columns per workgroup: n x k output block
+constexpr int T16_PA = 336, T16_PB = 176;                 // pitches in halves (168 / 88 dwords = 8 * odd)
+constexpr int T16_A_BYTES = T16_MC * T16_PA * 2, T16_B_BYTES = T16_MC * T16_PB * 2;
+constexpr int T16_STAGE = T16_A_BYTES + T16_B_BYTES;
+constexpr int T16_A_IT = (T16_MC * T16_AW / 8 + T16_THREADS - 1) / T16_THREADS;      // 16-byte chunks per thread: 3 (2.5)
+constexpr int T16_B_IT = (T16_MC * T16_BW / 8 + T16_THREADS - 1) / T16_THREADS;      // 2 (1.25)
+constexpr int T16_NTN = 5, T16_NTK = 5;
+
+struct Tn16Args {
+    int M;                    // upper bound of the rows
+    const int* m_dev;         // rows present (device) or null
+    const _Float16* A; int lda, N;       // [M][lda], N used columns (multiple of 16)
+    const _Float16* B; int ldb, K;       // [M][ldb], K used columns (multiple of 16)
+    float* partial;           // [splits][N][K]
+    int splits, n_blk, k_blk; // output blocks of T16_AW x T16_BW
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ h8 tr16_frag(const char* plane, int pitch_b, int col0, int lane) {
+    // operand fragment for columns col0..col0+15: element j of lane (c = lane&15, kq = lane>>4) = image[m(kq, j)][col0 + c],
+    // m(kq, j) = 4 kq + j (j < 4), 16 + 4 kq + (j - 4)
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int q = l16 >> 2, p = l16 & 3;
+    const char* a0 = plane + (4 * kq + q) * pitch_b + (col0 + 4 * p) * 2;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 16 * pitch_b));
+    s16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = lo4[i]; r[4 + i] = hi4[i]; }
+    return __builtin_bit_cast(h8, r);
+}
+
+__global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int out_blocks = a.n_blk * a.k_blk;
+    const int blk = blockIdx.x % out_blocks, split = blockIdx.x / out_blocks;
+    const int bn = blk % a.n_blk, bk = blk / a.n_blk;
+    const int ncol0 = bn * T16_AW, kcol0 = bk * T16_BW;
+    const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
+    const int rps = (((M + a.splits - 1) / a.splits) + T16_MC - 1) / T16_MC * T16_MC;
+    const int m_begin = split * rps, m_end = min(M, m_begin + rps);
+
+    // staging slots (16-byte chunks); loads are unconditional from clamped addresses, zeroed when written to LDS
+    h8 ra[T16_A_IT], rb[T16_B_IT];
+    auto load_stage = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < T16_A_IT; ++i) {
+            const int sl = tid + T16_THREADS * i;
+            const int r = min(sl / (T16_AW / 8), T16_MC - 1), c = (sl % (T16_AW / 8)) * 8;
+            const long m = min(m0 + r, max(m_end - 1, 0));
+            ra[i] = *reinterpret_cast<const h8*>(a.A + m * a.lda + min(ncol0 + c, a.N - 8));
+        }
+#pragma unroll
+        for (int i = 0; i < T16_B_IT; ++i) {
+            const int sl = tid + T16_THREADS * i;
+            const int r = min(sl / (T16_BW / 8), T16_MC - 1), c = (sl % (T16_BW / 8)) * 8;
+            const long m = min(m0 + r, max(m_end - 1, 0));
+            rb[i] = *reinterpret_cast<const h8*>(a.B + m * a.ldb + min(kcol0 + c, a.K - 8));
+        }
+    };
+    const h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto store_stage = [&](int m0, char* st) {
+#pragma unroll
+        for (int i = 0; i < T16_A_IT; ++i) {
+            const int sl = tid + T16_THREADS * i;
+            const int r = sl / (T16_AW / 8), c = (sl % (T16_AW / 8)) * 8;
+            if (r < T16_MC) {
+                const bool ok = m0 + r < m_end && ncol0 + c < a.N;
+                *reinterpret_cast<h8*>(st + (r * T16_PA + c) * 2) = ok ? ra[i] : z8;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < T16_B_IT; ++i) {
+            const int sl = tid + T16_THREADS * i;
+            const int r = sl / (T16_BW / 8), c = (sl % (T16_BW / 8)) * 8;
+            if (r < T16_MC) {
+                const bool ok = m0 + r < m_end && kcol0 + c < a.K;
+                *reinterpret_cast<h8*>(st + T16_A_BYTES + (r * T16_PB + c) * 2) = ok ? rb[i] : z8;
+            }
+        }
+    };
+    f32x4 acc[T16_NTN][T16_NTK];
+#pragma unroll
+    for (int i = 0; i < T16_NTN; ++i)
+#pragma unroll
+        for (int j = 0; j < T16_NTK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const char* st) {
+        h8 bf[T16_NTK];
+#pragma unroll
+        for (int j = 0; j < T16_NTK; ++j) bf[j] = tr16_frag(st + T16_A_BYTES, T16_PB * 2, (wk * T16_NTK + j) * 16, lane);
+#pragma unroll
+        for (int i = 0; i < T16_NTN; ++i) {
+            const h8 af = tr16_frag(st, T16_PA * 2, (wn * T16_NTN + i) * 16, lane);
+#pragma unroll
+            for (int j = 0; j < T16_NTK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int n_stage = m_end > m_begin ? (m_end - m_begin + T16_MC - 1) / T16_MC : 0;
+    if (n_stage > 0) {
+        load_stage(m_begin);
+        store_stage(m_begin, smem);
+        __syncthreads();
+        for (int s = 0; s < n_stage; ++s) {
+            load_stage(m_begin + (s + 1) * T16_MC);
+            compute(smem + (s & 1) * T16_STAGE);
+            store_stage(m_begin + (s + 1) * T16_MC, smem + ((s + 1) & 1) * T16_STAGE);
+            __syncthreads();
+        }
+    }
+    // partial slab [split][N][K]
+    float* slab = a.partial + (long)split * a.N * a.K;
+    const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < T16_NTN; ++i)
+#pragma unroll
+        for (int j = 0; j < T16_NTK; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int nn = ncol0 + (wn * T16_NTN + i) * 16 + 4 * kq + reg;
+                const int kk = kcol0 + (wk * T16_NTK + j) * 16 + r16;
+                if (nn < a.N && kk < a.K) slab[(long)nn * a.K + kk] = acc[i][j][reg];
+            }
+}
+
+// dW[nmap[n]][kmap[k]] += scale[n] * sum_splits partial[.][n][k]   (maps: -1 = padding, dropped)
+__global__ void tn16_reduce_kernel(const float* partial, int splits, int N, int K, const int* nmap, const int* kmap,
+                                   const float* nscale, int ldw, float* dW) {
+    const long total = (long)N * K;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / K), k = (int)(idx - (long)n * K);
+        const int nd = nmap[n], kd = kmap[k];
+        if (nd < 0 || kd < 0) continue;
+        const float* pp = partial + idx;
+        float s0 = 0.f, s1 = 0.f;
+        int sp = 0;
+        for (; sp + 1 < splits; sp += 2) { s0 += pp[(long)sp * total]; s1 += pp[(long)(sp + 1) * total]; }
+        if (sp < splits) s0 += pp[(long)sp * total];
+        dW[(long)nd * ldw + kd] += (s0 + s1) * nscale[n];
+    }
+}
+
+// bias / q_vec gradients from the per-workgroup column sums of the fused kernel (fixed order)
+__global__ void red16_kernel(const float* red, int n_wg, int h, int dk, int d, int q, float inv_scale, float qscale,
+                             float* db_qkv, float* db_add, float* dq_vec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B16_RED) return;
+    float s0 = 0.f, s1 = 0.f;
+    int g = 0;
+    for (; g + 1 < n_wg; g += 2) { s0 += red[(long)g * B16_RED + i]; s1 += red[(long)(g + 1) * B16_RED + i]; }
+    if (g < n_wg) s0 += red[(long)g * B16_RED + i];
+    const float s = (s0 + s1) * inv_scale;
+    if (i < B16_RED_QKV) {
+        const int tile = i >> 5, f = i & 31, head = tile / 3, which = tile - 3 * head;
+        if (head < h && f < dk) db_qkv[which * d + head * dk + f] += s * (which == 0 ? qscale : 1.0f);
+    } else if (i < B16_RED_QKV + F16_QP) {
+        const int qq = i - B16_RED_QKV;
+        if (qq < q) db_add[qq] += s;
+    } else {
+        const int qq = i - B16_RED_QKV - F16_QP;
+        if (qq < q) dq_vec[qq] += s;
+    }
+}
+
+// index maps of the reduce: rows of d(W_qkv) (dqkv16 column order), columns of d(W_add) (ctx16 column order)
+__global__ void maps16_kernel(int d, int h, int dk, int q, float inv_scale, float qscale, int* nmap_qkv, float* nscale_qkv,
+                              int* kmap_x, int* nmap_add, float* nscale_add, int* kmap_ctx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B16_DQ) {
+        const int head = i / 96, rem = i - head * 96, which = rem >> 5, p = rem & 31;
+        const int s = p >> 4, t = p & 15, hh = t >> 3, jj = t & 7;
+        const int f = 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+        nmap_qkv[i] = (head < h && f < dk) ? which * d + head * dk + f : -1;
+        nscale_qkv[i] = inv_scale * (which == 0 ? qscale : 1.0f);
+    }
+    if (i < F16_KP) kmap_x[i] = i < d ? i : -1;
+    if (i < F16_QP) { nmap_add[i] = i < q ? i : -1; nscale_add[i] = inv_scale; }
+    if (i < F16_DP) {
+        const int b16 = i >> 4, t = i & 15, hh = t >> 3, jj = t & 7;
+        const int fpad = 16 * b16 + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+        const int head = fpad >> 5, f = fpad & 31;
+        kmap_ctx[i] = (head < h && f < dk) ? head * dk + f : -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
+    Fused16BwdLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
+    L.n_wg = 512;
+    L.btiles = take((size_t)40 * 32 * F16_KP * 2);
+    L.xtiles = take((size_t)30 * 32 * F16_KP * 2);
+    L.qv16 = take((size_t)F16_QP * 2);
+    L.bqkv32 = take((size_t)30 * 32 * 4);
+    L.dout16 = take((size_t)n_seq * F16_DP * 2);
+    L.dz16 = take((size_t)M * F16_QP * 2);
+    L.dqkv16 = take((size_t)(M + 32) * B16_DQ * 2);
+    L.red = take((size_t)L.n_wg * B16_RED * 4);
+    L.maps = take((size_t)(B16_DQ * 2 + F16_KP + F16_QP * 2 + F16_DP) * 4);
+    // TN partial slabs (one workgroup per CU and round): the larger of the two products
+    L.tn_splits_qkv = 42;      // x 6 output blocks of 320 x 160
+    L.tn_splits_add = 128;     // x 2
+    const size_t p1 = (size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4, p2 = (size_t)L.tn_splits_add * F16_QP * F16_DP * 4;
+    L.partial = take(p1 > p2 ? p1 : p2);
+    L.total = off;
+    return L;
+}
+
+static int launch_tn16(const _Float16* A, int lda, int N, const _Float16* B, int ldb, int K, int M, const int* m_dev,
+                       float* partial, int splits, const int* nmap, const int* kmap, const float* nscale, int ldw, float* dW,
+                       hipStream_t stream, const char* name) {
+    Tn16Args t{};
+    t.M = M; t.m_dev = m_dev; t.A = A; t.lda = lda; t.N = N; t.B = B; t.ldb = ldb; t.K = K; t.partial = partial;
+    t.splits = splits; t.n_blk = cdiv(N, T16_AW); t.k_blk = cdiv(K, T16_BW);
+    const size_t lds = 2 * (size_t)T16_STAGE;
+    const hipError_t e = hipFuncSetAttribute((const void*)gemm16_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    {
+        TimingScope ts(name, stream);
+        hipLaunchKernelGGL(gemm16_tn_kernel, dim3(splits * t.n_blk * t.k_blk), dim3(T16_THREADS), lds, stream, t);
+    }
+    int rc = check_launch(name);
+    if (rc) return rc;
+    TimingScope ts("tn_reduce", stream);
+    hipLaunchKernelGGL(tn16_reduce_kernel, dim3(cdiv((long)N * K, 256)), dim3(256), 0, stream, partial, splits, N, K, nmap, kmap,
+                       nscale, ldw, dW);
+    return check_launch("tn16_reduce");
+}
+
+int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
+    if (f.n_seq <= 0) return NRMS_OK;
+    const long M = (long)f.n_seq * f.S;
+    const Fused16BwdLayout L = fused16_bwd_layout(M, f.n_seq);
+    char* base = (char*)f.workspace;
+    const int dk = f.d / f.h;
+    const float qscale = 1.0f / sqrtf((float)dk), inv_scale = 1.0f / f.loss_scale;
+    _Float16* btiles = (_Float16*)(base + L.btiles);
+    _Float16* xtiles = (_Float16*)(base + L.xtiles);
+    _Float16* qv16 = (_Float16*)(base + L.qv16);
+    float* bqkv32 = (float*)(base + L.bqkv32);
+    _Float16* dout16 = (_Float16*)(base + L.dout16);
+    _Float16* dz16 = (_Float16*)(base + L.dz16);
+    _Float16* dqkv16 = (_Float16*)(base + L.dqkv16);
+    float* red = (float*)(base + L.red);
+    int* nmap_qkv = (int*)(base + L.maps);
+    float* nscale_qkv = (float*)(nmap_qkv + B16_DQ);
+    int* kmap_x = (int*)(nscale_qkv + B16_DQ);
+    int* nmap_add = kmap_x + F16_KP;
+    float* nscale_add = (float*)(nmap_add + F16_QP);
+    int* kmap_ctx = (int*)(nscale_add + F16_QP);
+    float* partial = (float*)(base + L.partial);
+    {
+        Prep16bArgs p{};
+        p.d = f.d; p.h = f.h; p.dk = dk; p.q = f.q; p.w_qkv = f.w_qkv; p.b_qkv = f.b_qkv; p.w_add = f.w_add; p.q_vec = f.q_vec;
+        p.btiles = btiles; p.xtiles = xtiles; p.qv16 = qv16; p.bqkv32 = bqkv32;
+        TimingScope ts("prep16", stream);
+        hipLaunchKernelGGL(prep16b_kernel, dim3(2048), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(maps16_kernel, dim3(cdiv(B16_DQ, 256)), dim3(256), 0, stream, f.d, f.h, dk, f.q, inv_scale, qscale,
+                           nmap_qkv, nscale_qkv, kmap_x, nmap_add, nscale_add, kmap_ctx);
+        hipLaunchKernelGGL(dout16_kernel, dim3(cdiv((long)f.n_seq * F16_DP, 256) > 4096 ? 4096 : cdiv((long)f.n_seq * F16_DP, 256)),
+                           dim3(256), 0, stream, (long)f.n_seq, f.d, f.h, dk, f.loss_scale, f.dout, dout16);
+        int rc = check_launch("prep16b");
+        if (rc) return rc;
+    }
+    Bwd16Args a{};
+    a.n_seq = f.n_seq; a.S = f.S; a.d = f.d; a.h = f.h; a.dk = dk; a.q = f.q;
+    a.n_groups = cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 1 : 0);
+    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
+    a.btiles = btiles; a.bqkv32 = bqkv32; a.qv16 = qv16;
+    a.ctx16 = (const _Float16*)f.ctx16; a.t16 = (const _Float16*)f.t16; a.w = f.w; a.dout16 = dout16;
+    a.dz16 = dz16; a.dqkv16 = dqkv16; a.red = red; a.drop = f.drop;
+    const int n_wg = a.n_groups < L.n_wg ? a.n_groups : L.n_wg;
+    {
+        const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4;
+        const hipError_t e = hipFuncSetAttribute((const void*)fused_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("fused_bwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+        TimingScope ts("fused_bwd16", stream);
+        hipLaunchKernelGGL(fused_bwd16_kernel, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+        int rc = check_launch("fused_bwd16");
+        if (rc) return rc;
+    }
+    {
+        TimingScope ts("red16", stream);
+        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 256)), dim3(256), 0, stream, red, n_wg, f.h, dk, f.d, f.q, inv_scale,
+                           qscale, f.db_qkv, f.db_add, f.dq_vec);
+        int rc = check_launch("red16");
+        if (rc) return rc;
+    }
+    // d(W_add)[q][f] = sum_tok dZ[tok][q] ctx[tok][f]
+    int rc = launch_tn16(dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, (int)M, nullptr, partial, L.tn_splits_add,
+                         nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, stream, "dwadd_bwd");
+    if (rc) return rc;
+    // d(W_qkv)[n][k] = sum_rows dQKV[r][n] x[r][k]   (live rows only)
+    rc = launch_tn16(dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial, L.tn_splits_qkv,
+                     nmap_qkv, kmap_x, nscale_qkv, f.d, f.dw_qkv, stream, "dwqkv_bwd");
+    if (rc) return rc;
+    // dX = dQKV W'  -> fp32 rows
+    {
+        Dx16Args g{};
+        g.M = (int)M; g.m_dev = f.n_rows_dev; g.a16 = dqkv16; g.xtiles = xtiles; g.c = f.dx; g.ldc = f.d; g.d = f.d;
+        g.inv_scale = inv_scale;
+        const size_t lds = (size_t)3 * F16_SLOT;
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm16_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("gemm16_dx: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+        TimingScope ts("dx_bwd", stream);
+        hipLaunchKernelGGL(gemm16_dx_kernel, dim3(cdiv(M, 32 * F16_WAVES)), dim3(F16_THREADS), lds, stream, g);
+        rc = check_launch("gemm16_dx");
+    }
+    return rc;
+}
+
+}  // namespace nrms

@@ -347,6 +347,28 @@ struct Fused16Fwd {
 int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream);
 int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream);
 
+// fused16_bwd.hip: the backward of the above.  `workspace` holds the backward weight planes, dout16, dZ16, dQKV16, the
+// per-workgroup column sums and the split-M partial slabs (fused16_bwd_layout(M, n_seq).total bytes).
+struct Fused16BwdLayout { int n_wg, tn_splits_qkv, tn_splits_add; size_t btiles, xtiles, qv16, bqkv32, dout16, dz16, dqkv16, red, maps, partial, total; };
+Fused16BwdLayout fused16_bwd_layout(long M, int n_seq);
+struct Fused16Bwd {
+    int n_seq, S, d, h, q;
+    void* workspace;
+    const float* w_qkv; const float* b_qkv; const float* w_add; const float* q_vec;      // reference layout, fp32
+    const void* x16;          // forward: [rows][KP]
+    const int* pos;           // token -> row (x16 and dQKV16), -1 = padding token; null: row = token
+    const int* n_rows_dev;    // number of rows (device) when pos != null, else null (= n_seq * S)
+    const int64_t* ids;       // non-null: all-padding sequences take the closed form
+    const int* order; const int* order_cnt;
+    const void* ctx16; const void* t16; const float* w;         // forward activations
+    const float* dout;        // [n_seq][d]
+    float loss_scale;         // power of two: fp16 gradients are carried multiplied by it
+    Dropout drop;             // context dropout
+    float* dw_qkv; float* db_qkv; float* dw_add; float* db_add; float* dq_vec;           // accumulated
+    float* dx;                // [rows][d] fp32 (rows as pos / tokens): gradient w.r.t. the encoder input
+};
+int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream);
+
 // embed.hip
 // dst[i] = src[i] if 0 <= src[i] < vocab else 0; *n_bad += ids replaced (dst may alias src)
 int launch_sanitize_ids(long n, const int64_t* src, int64_t* dst, int vocab, int* n_bad, hipStream_t stream);
@@ -370,6 +392,9 @@ int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* pos, in
 size_t scatter_grouped_scratch_ints(long M, int V);
 int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
                            const Dropout& drop, float* dtable, int* scratch, hipStream_t stream);
+// dx has one row per token; the live tokens' rows are scatter-added (float atomics)
+int launch_scatter_dense_rows(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
+                              const Dropout& drop, float* dtable, hipStream_t stream);
 // same as launch_scatter_dropout for a COMPACT dx: row r of dx belongs to token live[r], r < *n_live
 int launch_scatter_dropout_compact(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
                                    const Dropout& drop, float* dtable, hipStream_t stream);

@@ -114,7 +114,8 @@ class NRMSEngine:
             raise _lib.NrmsError("the NRMS HIP engine needs a GPU device (got %s); there is no CPU path" % device)
         self._bufs = {}
         self._saved = None
-        self.fp16_backward = False         # the fused fp16 backward (training in fp16 mode)
+        self.fp16_backward = True          # training in fp16 mode runs the fused fp16 backward (csrc/fused16_bwd.hip)
+        self.loss_scale = 65536.0          # fp16 backward: power of two ~128 x the global batch (set per step)
         self._gen = 0                      # generation stamp of _saved (checked by the autograd backward)
         # out-of-range word ids: counted on the device by nrms_sanitize_ids, surfaced without a host sync
         # (the count is copied to pinned memory behind the kernel and looked at on a later call)
@@ -163,7 +164,7 @@ class NRMSEngine:
                                 precision=_lib.PRECISIONS[prec], use_output_proj=int(d.output_proj),
                                 mask_mode=int(mask_mode),
                                 flags=(_lib.NRMS_FLAG_PAD_ROW_ZERO if (self.pad_row_zero and enc == "news_encoder") else 0),
-                                seed=int(seed))
+                                seed=int(seed), loss_scale=float(self.loss_scale), reserved=0)
 
     def _ptrs(self, cls, flat, enc):
         b = self.layout.blocks[enc]
@@ -385,6 +386,7 @@ class NRMSEngine:
         B, H, Cn, L = sv["B"], sv["H"], sv["C"], sv["L"]
         d = self.dims.word_embed_size
         N = B * (H + Cn)
+        self.loss_scale = float(2 ** math.ceil(math.log2(128.0 * max(B, 1))))     # fp16 mode: d(scores) ~ 1 / batch
         nv, user = sv["nv"], sv["user"]
         hist = nv[:B * H]
         cand = nv[B * H:]

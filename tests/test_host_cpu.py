@@ -37,8 +37,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # field order / widths of the POD structs (x86-64 SysV): desc = 8 x 4 bytes + u64
-    assert ctypes.sizeof(_lib.EncoderDesc) == 56
-    assert _lib.EncoderDesc.seed.offset == 48
+    assert ctypes.sizeof(_lib.EncoderDesc) == 64
+    assert _lib.EncoderDesc.seed.offset == 48 and _lib.EncoderDesc.loss_scale.offset == 56
     assert ctypes.sizeof(_lib.EncoderWeights) == 64 and ctypes.sizeof(_lib.EncoderGrads) == 64
     assert ctypes.sizeof(_lib.EncoderActs) == 56
 
