@@ -8,9 +8,11 @@ MIND shapes hist=50 cand=5 title_len=30 d=300 V=45800, 512 users per GPU).
 
 One step = forward + CE(label 0) + backward + [RCCL all-reduce of the flat gradient] + fused
 Adam over all 14.4 M parameters, dropout 0.2 on, synthetic batch already resident in HBM.
-Rank 0 prints ONE JSON line; `roofline` is the dominant kernel's measured MFMA rate (HIP events
-on the launch stream, over the timed region), `cpu_baseline` is the oracle's reference-shaped
-train step timed on this box's host cores (N=1 only, bounded sample).
+Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (HIP events on the launch
+stream, a second pass over the same K steps), `roofline.step_frac` the whole step against the dense
+fp16/bf16 MFMA peak by BASELINE.md's formula, `cpu_baseline` the oracle's reference-shaped train
+step timed on this box's host cores (N=1 only, bounded sample), `modes` the other precision modes
+and the drop-in autograd + torch.optim.Adam loop on the same batch.
 """
 import argparse
 import json
@@ -30,55 +32,74 @@ from pytorch_news_recommender_amd.config import Config
 from pytorch_news_recommender_amd.model.nrms_hip import Model
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32-input MFMA, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA
-# split-bf16 spends 3 bf16 MFMAs per fp32-equivalent MFMA step BY CONSTRUCTION, so the roofline for
-# algorithmic (fp32-equivalent) flops in that mode is the bf16 peak / 3
+PEAK_16_MFMA_TFLOPS = 2500.0        # dense bf16 / fp16 MFMA
 PEAK_HBM_GBPS = 8000.0              # HBM3E spec (6300 measured achievable)
-PEAKS = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16": PEAK_BF16_MFMA_TFLOPS}
+# split-bf16 spends 3 bf16 MFMAs per fp32-equivalent MFMA step BY CONSTRUCTION: its kernels are priced against peak / 3
+PEAKS = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_16_MFMA_TFLOPS / 3.0, "bf16": PEAK_16_MFMA_TFLOPS,
+         "fp16": PEAK_16_MFMA_TFLOPS}
 DTYPES = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA inputs hi+lo, fp32 accumulate, fp32 storage)",
-          "bf16": "bf16 (MFMA inputs), fp32 accumulate, fp32 storage"}
+          "bf16": "bf16 (MFMA inputs), fp32 accumulate, fp32 storage",
+          "fp16": "f16 (MFMA inputs and saved activations; fp32 accumulate, softmax, loss, master weights and Adam)"}
+PARITY = {"fp32": "<=1.5e-7", "bf16x3": "<=5e-7", "bf16": "~3e-4 (fails 1e-4)", "fp16": "4.4e-5 (inside 1e-4)"}
+FLOP_PER_USER_TRAIN = 3558309000.0  # BASELINE.md section 2 / SURVEY 8d: nrms_v0, H=50, C=5, L=30, d=300, h=10, q=200
 
 
-def kernel_work(shape, B, live_frac=1.0, compact_qkv=False, allpad_frac=0.0):
-    """Per kernel: (declared bound, algorithmic flop per step, algorithmic HBM bytes per step), summed over
-    the news-encoder and user-encoder launches.  flop = 2mnk of the contractions; bytes =
-    every activation tensor the kernel must read or write once, fp32 (weights are negligible).
-    live_frac = share of the news-encoder token rows whose id is not the padding id: the X-gradient GEMM and
-    the embedding scatter only process those (padding_idx rows receive no gradient), so only they count.
-    allpad_frac = share of the titles without any real token: with compact_qkv the attention kernels take the
-    closed form for them (no Q|K|V read, no products)."""
+def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news):
+    """Per kernel timer: (declared bound, algorithmic flop per step, algorithmic HBM bytes per step).
+    flop = 2mnk of the contractions the kernel owns, counted on what cannot be skipped exactly:
+    Q|K|V projection / d(w_qkv) / dX on the non-padding token rows, attention on the titles with a real token, the
+    additive projection on every token.  bytes = every tensor the kernel must read or write once."""
     H, C, L = shape.history_len, shape.n_candidates, shape.n_words_title
     d, q = shape.word_embed_size, shape.query_vector_dim
-    Ms = (B * (H + C) * L, B * H)             # rows: news tokens, user-encoder rows
-    seqs = ((B * (H + C), L), (B, H))
-    M = float(sum(Ms))
-    qkv = 2.0 * M * d * 3 * d
-    add = 2.0 * M * d * q
-    att = sum(n * 2.0 * 2 * S * S * d for n, S in seqs)        # QK^T + PV over all heads
-    Md, Mq = 4.0 * M * d, 4.0 * M * q
-    ap = allpad_frac if compact_qkv else 0.0
-    att_live = seqs[0][0] * (1.0 - ap) * 2.0 * 2 * L * L * d + seqs[1][0] * 2.0 * 2 * H * H * d
-    Md_live = 4.0 * (Ms[0] * (1.0 - ap) + Ms[1]) * d      # Q|K|V rows the attention kernels actually read
-    Mlx = Ms[0] * live_frac + Ms[1]           # token rows that are not padding (user-encoder rows all count)
-    Ml = Mlx if compact_qkv else M            # rows the Q|K|V projection / d(w_qkv) / compact dQKV touch
+    Mn, Mu = B * (H + C) * L, B * H                       # token rows: news encoder, user encoder
+    Nn = B * (H + C)
+    ap = allpad_frac if compact else 0.0
+    lf = live_frac if compact else 1.0
+    att_n = Nn * (1.0 - ap) * 2.0 * 2 * L * L * d           # QK^T + PV, all heads
+    att_u = B * 2.0 * 2 * H * H * d
+    qkv_n, qkv_u = 2.0 * Mn * lf * d * 3 * d, 2.0 * Mu * d * 3 * d
+    add_n, add_u = 2.0 * Mn * d * q, 2.0 * Mu * d * q
+    dx_n = 2.0 * Mn * live_frac * d * 3 * d
     n_params = shape.n_words * d + 2 * (3 * d * d + 3 * d + q * d + 2 * q)
-    Mn_d = 4.0 * Ms[0] * d
-    return {
-        # padding tokens skipped (NRMS_FLAG_PAD_ROW_ZERO): the projection reads the live x rows and still writes
-        # every qkv row; d(w_qkv) reads the live rows of dQKV and x
-        "qkv_proj_fwd": ("mfma", 2.0 * Ml * d * 3 * d, 4.0 * Ml * d + 3 * Md),
-        "dwqkv_bwd": ("mfma", 2.0 * Ml * d * 3 * d, 16.0 * Ml * d),
-        "dx_bwd": ("mfma", 2.0 * Mlx * d * 3 * d, 16.0 * Mlx * d),
-        "addattn_fwd": ("mfma", add, Md + Mq),
-        "dctx_bwd": ("mfma", add, Mq + Md),
-        "dwadd_bwd": ("mfma", add, Mq + Md),
-        "attn_fwd": ("hbm", att_live, 3 * Md_live + Md),
-        "attn_bwd": ("hbm", 2.5 * att_live, 3 * Md_live + Md + 12.0 * Ml * d),
-        "addattn_bwd_rows": ("hbm", 0.0, Md + Mq),
-        "gather_dropout": ("hbm", 0.0, 2 * Mn_d * (live_frac if compact_qkv else 1.0)),
-        "scatter_dropout": ("hbm", 0.0, 2 * Mn_d * live_frac),
-        "adam": ("hbm", 0.0, 28.0 * n_params),
-    }
+    live_rows = Mn * live_frac
+    w = {}
+    if fp16_news:
+        # news encoder in the fused fp16 kernels (fp16 activations: 2 B per element, padded pitches 320 / 224)
+        w["fused_fwd16"] = ("mfma", qkv_n + att_n + add_n, 2.0 * (live_rows * 320 + Mn * 320 + Mn * 224))
+        w["fused_bwd16"] = ("mfma", add_n + 2.0 * att_n, 2.0 * (live_rows * 320 + Mn * 320 + 2 * Mn * 224 + live_rows * 960))
+        w["dwqkv_bwd"] = ("mfma", qkv_n + qkv_u, 2.0 * live_rows * (960 + 320) + 16.0 * Mu * d)
+        w["dx_bwd"] = ("mfma", dx_n + qkv_u, 2.0 * live_rows * 960 + 4.0 * live_rows * d + 16.0 * Mu * d)
+        w["dwadd_bwd"] = ("mfma", add_n + add_u, 2.0 * Mn * (224 + 320) + 4.0 * Mu * (d + q))
+        w["gather_dropout"] = ("hbm", 0.0, live_rows * (4.0 * d + 2.0 * 320))
+        # user encoder (histories of 50 > 32 rows) runs in the bf16x3 kernels
+        w["qkv_proj_fwd"] = ("mfma", qkv_u, 16.0 * Mu * d)
+        w["addattn_fwd"] = ("mfma", add_u, 4.0 * Mu * (d + q))
+        w["dctx_bwd"] = ("mfma", add_u, 4.0 * Mu * (d + q))
+        w["attn_fwd"] = ("hbm", att_u, 16.0 * Mu * d)
+        w["attn_bwd"] = ("hbm", 2.5 * att_u, 28.0 * Mu * d)
+        w["addattn_bwd_rows"] = ("hbm", 0.0, 4.0 * Mu * (d + q))
+    else:
+        M = float(Mn + Mu)
+        Md, Mq = 4.0 * M * d, 4.0 * M * q
+        Ml = Mn * lf + Mu
+        Md_live = 4.0 * (Mn * (1.0 - ap) + Mu) * d
+        w["qkv_proj_fwd"] = ("mfma", qkv_n + qkv_u, 4.0 * Ml * d + 3 * Md)
+        w["dwqkv_bwd"] = ("mfma", qkv_n + qkv_u, 16.0 * Ml * d)
+        w["dx_bwd"] = ("mfma", dx_n + qkv_u, 16.0 * (Mn * live_frac + Mu) * d)
+        w["addattn_fwd"] = ("mfma", add_n + add_u, Md + Mq)
+        w["dctx_bwd"] = ("mfma", add_n + add_u, Mq + Md)
+        w["dwadd_bwd"] = ("mfma", add_n + add_u, Mq + Md)
+        w["attn_fwd"] = ("hbm", att_n + att_u, 3 * Md_live + Md)
+        w["attn_bwd"] = ("hbm", 2.5 * (att_n + att_u), 3 * Md_live + Md + 12.0 * Ml * d)
+        w["addattn_bwd_rows"] = ("hbm", 0.0, Md + Mq)
+        w["gather_dropout"] = ("hbm", 0.0, 8.0 * Mn * d * lf)
+    w["scatter_dropout"] = ("hbm", 0.0, 8.0 * Mn * d * live_frac)
+    w["adam"] = ("hbm", 0.0, 28.0 * n_params)
+    return w
+
+
+OTHER_TIMERS = ("tn_reduce", "red16", "prep16", "title_order", "cast16", "split_planes", "click", "ce_loss", "transpose", "colsum",
+                "permute_rows", "compact_rows", "sanitize_ids", "fill_pad_rows", "padsum")
 
 
 def log(msg):
@@ -120,20 +141,77 @@ def cpu_baseline(shape, sample_users=64, steps=3):
             "ms_per_step": dt * 1e3}
 
 
+def timed(fn, n, sync=True):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    if sync:
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def eval_path_leg(model, dev):
+    """SURVEY f-1: evaluation impressions padded to max_candidate_size = 300 (data_handler.py:174-177), 4 batches of 128
+    impressions drawn from a 4000-news corpus: every slot encoded (as the reference does), distinct titles per batch
+    (device hash), and the persistent news-vector cache keyed by the batch dict's news ids."""
+    from torch.utils.data import DataLoader
+    from pytorch_news_recommender_amd.data_handler import MyDataset, SyntheticMind
+    cfg = model.config
+    cfg.max_candidate_size, cfg.history_len = 300, 50
+    corpus = SyntheticMind(cfg, n_news=4000, seed=3)
+    samples, _ = corpus.eval_samples(512, max_shown=70)
+    ds = MyDataset(cfg, samples, type=1, id2title_dict=corpus.id2title_dict)
+    batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+               for b in DataLoader(ds, batch_size=128, shuffle=False, num_workers=0)]
+    model.eval()
+    eng = model.engine
+    ev = {}
+    with torch.no_grad():
+        def run_all():
+            for b in batches:
+                model(b)
+        model.dedup_inference = False
+        run_all()
+        ev["all_slots_impressions_per_s"] = 512 * 3 / timed(run_all, 3)
+        model.dedup_inference = True
+        strip = [{k: v for k, v in b.items() if k not in ("browsed_ids", "candidate_ids")} for b in batches]
+
+        def run_hash():
+            for b in strip:
+                model(b)
+        run_hash()
+        ev["unique_titles_impressions_per_s"] = 512 * 3 / timed(run_hash, 3)
+        ev["unique_title_fraction"] = model.last_unique_titles / float(128 * 350)
+
+        def run_cached():
+            eng.news_cache_begin()
+            for b in batches:
+                model(b)
+            return eng.news_cache_end()
+        run_cached()
+        t = timed(run_cached, 3)
+        stats = run_cached()
+        ev["news_cache_impressions_per_s"] = 512 * 3 / t
+        ev["news_cache_encoded_titles"] = stats["encoded"]
+        ev["news_cache_lookups"] = stats["lookups"]
+    model.train()
+    return ev
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--users-per-gpu", type=int, default=512)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the secondary legs")
     ap.add_argument("--dense-padding", action="store_true",
                     help="diagnostics: process padding tokens densely (as if embedding row 0 were not zero)")
     ap.add_argument("--cpu-sample-users", type=int, default=64)
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
-                    help="bf16x3 (default) is the fastest mode inside the 1e-4 score-parity bar (measured 5e-7); "
-                         "fp32 = exact f32 MFMA; bf16 misses the bar (3e-4) and is never the default")
-    ap.add_argument("--also-fp32", action="store_true", help="time the exact-fp32 mode too and report it under modes")
+    ap.add_argument("--precision", default="fp16", choices=["fp32", "bf16x3", "bf16", "fp16"],
+                    help="fp16 (default): fused one-wave-per-title kernels, scores 4.4e-5 from the reference (bar 1e-4); "
+                         "bf16x3: split-bf16 projections (5e-7); fp32 = exact f32 MFMA; bf16 misses the bar (3e-4)")
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.init_process_group(os.environ.get("NRMS_DIST_BACKEND"))
@@ -144,8 +222,6 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     shape = synth.BENCH
-    if os.environ.get("NRMS_BENCH_D"):            # diagnostics only: alignment experiments
-        shape = synth.Shape(word_embed_size=int(os.environ["NRMS_BENCH_D"]))
     B = args.users_per_gpu
     cfg = Config("nrms_hip")
     cfg.__nrms__()
@@ -171,7 +247,7 @@ def main():
     def step():
         return model.train_step(batch, world_size=world, all_reduce=reduce)
 
-    log("model ready on %s (rank %d/%d), %d users/GPU" % (dev, rank, world, B))
+    log("model ready on %s (rank %d/%d), %d users/GPU, precision %s" % (dev, rank, world, B, args.precision))
     for i in range(args.warmup):
         step()
         if i == 0:
@@ -180,9 +256,9 @@ def main():
     torch.cuda.synchronize()
     log("warm-up done")
     # ---- the timed region: EXACTLY K un-instrumented steps.  (The per-kernel HIP-event timers -- two events
-    # created and recorded around each of the ~50 launches of a step -- slow a step by ~8 %, so they are
-    # NOT on during the timed region; the per-kernel durations of `kernels` / `roofline` come from a second,
-    # instrumented pass over the same K steps right after it, on every rank so collectives stay aligned.)
+    # created and recorded around each launch of a step -- slow a step by a few %, so they are NOT on during the
+    # timed region; the per-kernel durations of `kernels` / `roofline` come from a second, instrumented pass over
+    # the same K steps right after it, on every rank so collectives stay aligned.)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -194,6 +270,7 @@ def main():
     dt = parallel.max_over_ranks(dt, dev)
     loss = float(loss_sum) / B
     log("timed region: %d steps in %.3f s" % (args.steps, dt))
+    eng.check_ids()
     eng.timing_reset()
     eng.timing(True)
     torch.cuda.synchronize()
@@ -206,15 +283,54 @@ def main():
     eng.timing(False)
     log("instrumented pass: %d steps in %.3f s" % (args.steps, dt_instr))
 
+    # ---- data-parallel facts (every rank takes part; rank 0 reports)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        ref = model._flat.clone()
+        dist.broadcast(ref, src=0)
+        diff = torch.tensor([float((model._flat - ref).abs().max())], device=dev)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        g = torch.zeros_like(model._flat)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reduce(g)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        evs[0].record()
+        for _ in range(5):
+            reduce(g)
+        evs[1].record()
+        torch.cuda.synchronize()
+        ar_ms = evs[0].elapsed_time(evs[1]) / 5
+        os.environ["NRMS_NO_OVERLAP"] = "1"
+        for _ in range(2):
+            step()
+        parallel.barrier()
+        t_no = parallel.max_over_ranks(timed(step, max(3, args.steps // 2)), dev) / max(3, args.steps // 2)
+        del os.environ["NRMS_NO_OVERLAP"]
+        parallel.barrier()
+        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+              "allreduce_ms": ar_ms, "allreduce_bytes": int(model._flat.numel() * 4),
+              "allreduce_algbw_GBps": model._flat.numel() * 4 / ar_ms / 1e6,
+              "ms_per_step_without_overlap": t_no * 1e3, "overlap_ms": t_no * 1e3 - dt / args.steps * 1e3,
+              "replicas_identical_after_timed_region": bool(diff.item() == 0.0),
+              "max_abs_param_diff_vs_rank0": float(diff.item())}
+
+    out = None
     if rank == 0:
         live = float((batch_np["browsed_titles"] != 0).sum() + (batch_np["candidate_titles"] != 0).sum())
         live_frac = live / float(B * (shape.history_len + shape.n_candidates) * shape.n_words_title)
-        compact_qkv = bool(eng.pad_row_zero)
+        compact = bool(eng.pad_row_zero)
         titles = np.concatenate([batch_np["browsed_titles"].reshape(-1, shape.n_words_title),
                                  batch_np["candidate_titles"].reshape(-1, shape.n_words_title)])
-        allpad_frac = float((titles != 0).any(axis=1).mean())
-        allpad_frac = 1.0 - allpad_frac
-        work = kernel_work(shape, B, live_frac, compact_qkv, allpad_frac)
+        allpad_frac = 1.0 - float((titles != 0).any(axis=1).mean())
+        fp16_news = args.precision == "fp16"
+        work = kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news)
+        # which arithmetic each timer's kernels run in (fp16 mode: the user encoder's kernels are bf16x3)
+        kprec = {k: args.precision for k in work}
+        if fp16_news:
+            for k in ("qkv_proj_fwd", "addattn_fwd", "dctx_bwd"):
+                kprec[k] = "bf16x3"
         kernels = {}
         for name, (bound, fl, by) in work.items():
             ms, n = eng.timing_read(name)
@@ -223,30 +339,33 @@ def main():
             sec = ms / args.steps * 1e-3
             kernels[name] = {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps, "bound": bound,
                              "tflops": fl / sec / 1e12, "gbps": by / sec / 1e9}
-        for name in ("tn_reduce", "split_planes", "click", "ce_loss", "transpose", "colsum", "permute_rows", "compact_rows"):
+            if bound == "mfma":
+                kernels[name]["frac_of_mfma_peak"] = fl / sec / 1e12 / PEAKS[kprec[name]]
+            else:
+                kernels[name]["frac_of_hbm_peak"] = by / sec / 1e9 / PEAK_HBM_GBPS
+        for name in OTHER_TIMERS:
             ms, n = eng.timing_read(name)
             if n:
                 kernels[name] = {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps}
         dom = max((k for k in kernels if "bound" in kernels[k]), key=lambda k: kernels[k]["ms_per_step"])
         dom_ms, dom_n = eng.timing_read(dom)
         bound, fl, by = work[dom]
-        peak = PEAKS[args.precision] if bound == "mfma" else PEAK_HBM_GBPS
-        if dom.startswith("attn"):
-            mfma_peak_note = "attention runs on exact f32 MFMA in every mode; it is HBM/latency-bound"
+        peak = PEAKS[kprec[dom]] if bound == "mfma" else PEAK_HBM_GBPS
         achieved = (fl / 1e12 if bound == "mfma" else by / 1e9) / (dom_ms / args.steps * 1e-3)
-        # measured HBM bytes of the news-encoder launch of that kernel (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE,
-        # separate passes, collected at this workload and committed under profiles/): null if not on file
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_bf16x3_hbm_traffic.json")
-        if args.precision == "bf16x3" and B == 512 and os.path.exists(tfile):
+        # measured HBM bytes of that kernel's largest launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
+        # tools/profile_round.sh at this workload, committed under profiles/): null if not on file
+        traffic, tfile = None, os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % args.precision)
+        if B == 512 and os.path.exists(tfile):
             try:
                 traffic = json.load(open(tfile))["by_timer"].get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         total_users = B * world * args.steps
+        users_per_s = total_users / dt
+        per_gpu = users_per_s / world
         out = {
             "metric": "users/sec (train step) NRMS MIND-small hist=50 cand=5",
-            "value": total_users / dt, "unit": "users/s", "n_gpus": world, "steps": args.steps,
+            "value": users_per_s, "unit": "users/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1] shapes: NRMS(nrms_v0) train step, %d users/GPU, hist=50, "
@@ -255,81 +374,78 @@ def main():
                        "non_padding_token_fraction": round(live_frac, 4),
                        "all_padding_title_fraction": round(allpad_frac, 4),
                        "padding_tokens_skipped": ("dX + embedding scatter (dead values); Q|K|V projection and d(w_qkv) too: "
-                                                  "embedding row 0 is zero" if compact_qkv else
+                                                  "embedding row 0 is zero" if compact else
                                                   "dX + embedding scatter (dead values)"),
                        "parallelism": "dp%d" % world, "precision": args.precision,
-                       "score_parity_vs_reference": {"fp32": "<=1.5e-7", "bf16x3": "<=5e-7", "bf16": "~3e-4 (fails 1e-4)"}[args.precision]},
+                       "score_parity_vs_reference": PARITY[args.precision]},
             "loss": loss,
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_note": "bytes of the news-encoder launch (largest of the kernel's launches per step), "
-                                         "profiles/r01_bf16x3_hbm_traffic.json",
-                         "peak_note": ("HBM3E spec 8 TB/s (6.3 TB/s measured achievable); algorithmic bytes = each "
-                                       "activation tensor read/written once, fp32") if bound == "hbm" else
-                                      {"fp32": "f32-input MFMA dense peak", "bf16": "bf16 MFMA dense peak",
-                                       "bf16x3": "bf16 dense peak / 3: algorithmic (fp32-equivalent) flops cost 3 bf16 "
-                                                 "MFMAs each by construction"}[args.precision],
+                         "traffic_note": "HBM bytes of that kernel's largest launch, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, "
+                                         "profiles/r02_%s_hbm_traffic.json" % args.precision,
+                         "peak_note": ("HBM3E spec 8 TB/s (6.3 TB/s measured achievable)" if bound == "hbm" else
+                                       {"fp32": "f32-input MFMA dense peak", "bf16": "bf16 MFMA dense peak", "fp16": "fp16 MFMA dense peak",
+                                        "bf16x3": "bf16 dense peak / 3 (3 bf16 MFMAs per fp32-equivalent step by construction)"}[kprec[dom]]),
                          "avg_launch_ms": dom_ms / max(dom_n, 1),
                          "timing_note": "kernel durations: HIP events on the launch stream, recorded in a second pass of the "
                                         "same %d steps right after the (un-instrumented) timed region; that pass ran at "
                                         "%.2f ms/step" % (args.steps, dt_instr / args.steps * 1e3),
-                         "algorithmic_per_step": by if bound == "hbm" else fl},
-            "top_mfma_kernel": (lambda k: {"kernel": k, "tflops": kernels[k]["tflops"], "peak": PEAKS[args.precision],
-                                           "frac": kernels[k]["tflops"] / PEAKS[args.precision]})(
-                max((k for k in kernels if kernels[k].get("bound") == "mfma"), key=lambda k: kernels[k]["ms_per_step"])),
+                         "algorithmic_per_step": by if bound == "hbm" else fl,
+                         # the WHOLE step by BASELINE.md section 2: users/s x 3.558309e9 flop / peak (per GPU)
+                         "step_frac": per_gpu * FLOP_PER_USER_TRAIN / (PEAK_16_MFMA_TFLOPS * 1e12),
+                         "step_frac_note": "users/s per GPU x 3 558 309 000 flop (reference algorithm, padding included) / 2.5e15 "
+                                           "(dense fp16/bf16 MFMA peak, undivided)",
+                         "step_tflops_equiv": per_gpu * FLOP_PER_USER_TRAIN / 1e12},
             "kernels": kernels,
         }
+        mf = [k for k in kernels if kernels[k].get("bound") == "mfma"]
+        if mf:
+            k = max(mf, key=lambda kk: kernels[kk]["ms_per_step"])
+            out["top_mfma_kernel"] = {"kernel": k, "tflops": kernels[k]["tflops"], "peak": PEAKS[kprec[k]],
+                                      "frac": kernels[k]["tflops"] / PEAKS[kprec[k]]}
+        if dp is not None:
+            out["data_parallel"] = dp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, sample_users=args.cpu_sample_users)
-    # secondary: evaluation path (SURVEY f-1): impressions padded to max_candidate_size=300 as data_handler.py:174-177
-    # does, ~37 shown candidates each; plain forward (all 350 slots encoded, as the reference does) vs the
-    # unique-title forward
+    # secondary (N = 1, outside the timed region of `value`): the other modes on the same batch
     if world == 1 and not args.no_cpu_baseline and rank == 0:
-        try:
-            ev_shape = synth.Shape(n_candidates=300, batch_size=128)
-            evb = synth.make_batch(ev_shape, seed=5, batch_size=128)
-            shown = np.random.default_rng(6).integers(5, 70, size=128)
-            evb["candidate_mask"] = (np.arange(300)[None, :] < shown[:, None]).astype(np.uint8)
-            evb["candidate_titles"] = np.where(evb["candidate_mask"][..., None] > 0, evb["candidate_titles"], 0)
-            evt = {k: torch.from_numpy(v).to(dev) for k, v in evb.items()}
-            model.eval()
-            ev = {}
-            with torch.no_grad():
-                for name, dd in (("unique_titles", True), ("all_slots", False)):
-                    model.dedup_inference = dd
-                    model(evt)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(5):
-                        model(evt)
-                    torch.cuda.synchronize()
-                    ev[name + "_impressions_per_s"] = 128 * 5 / (time.perf_counter() - t1)
-            ev["unique_title_fraction"] = model.last_unique_titles / float(128 * 350)
-            model.dedup_inference = True
-            model.train()
-            out["eval_path"] = ev
-        except Exception as e:       # secondary leg only: never lose the headline line
-            out["eval_path"] = {"error": repr(e)}
-    # secondary: the other precision modes on the same batch (outside the timed region of `value`)
-    if world == 1 and (args.also_fp32 or not args.no_cpu_baseline):
         modes = {}
-        for prec in ("fp32", "bf16"):
-            if prec == args.precision:
-                continue
-            cfg.precision = prec
+        n = max(3, args.steps // 2)
+        try:
+            for prec in ("bf16x3", "fp32", "fp16"):
+                if prec == args.precision:
+                    continue
+                cfg.precision = prec
+                for _ in range(2):
+                    step()
+                modes[prec] = {"users_per_s": B * n / timed(step, n), "steps": n, "score_parity_vs_reference": PARITY[prec]}
+            cfg.precision = args.precision
+            # dense padding (as for a table whose row 0 is not zero: only the dead dX rows are skipped)
+            cfg.skip_padding_tokens = False
             for _ in range(2):
                 step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n = max(3, args.steps // 2)
-            for _ in range(n):
-                step()
-            torch.cuda.synchronize()
-            modes[prec] = {"users_per_s": B * n / (time.perf_counter() - t1), "steps": n,
-                           "score_parity_vs_reference": "<=1.5e-7" if prec == "fp32" else "~3e-4 (fails the 1e-4 bar)"}
-        cfg.precision = args.precision
-        if rank == 0:
-            out["modes"] = modes
+            modes["dense_padding"] = {"users_per_s": B * n / timed(step, n), "steps": n, "precision": args.precision}
+            cfg.skip_padding_tokens = not args.dense_padding
+            # the drop-in loop of train_eval.py:111-127: model(batch) -> CE -> loss.backward() -> torch.optim.Adam.step
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            crit = torch.nn.CrossEntropyLoss()
+
+            def ref_loop():
+                outp = model(batch)
+                model.zero_grad()
+                crit(outp, torch.zeros(len(outp), dtype=torch.long, device=outp.device)).backward()
+                opt.step()
+            for _ in range(2):
+                ref_loop()
+            modes["autograd_torch_adam"] = {"users_per_s": B * n / timed(ref_loop, n), "steps": n, "precision": args.precision,
+                                            "note": "reference-compatible sequence (INTEGRATION.md section 2) through the same kernels"}
+        except Exception as e:
+            modes["error"] = repr(e)
+        out["modes"] = modes
+        try:
+            out["eval_path"] = eval_path_leg(model, dev)
+        except Exception as e:       # secondary leg only: never lose the headline line
+            out["eval_path"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     parallel.barrier()

@@ -629,16 +629,21 @@ __global__ void tn16_reduce_kernel(const float* partial, int splits, int N, int 
     }
 }
 
-// bias / q_vec gradients from the per-workgroup column sums of the fused kernel (fixed order)
-__global__ void red16_kernel(const float* red, int n_wg, int h, int dk, int d, int q, float inv_scale, float qscale,
-                             float* db_qkv, float* db_add, float* dq_vec) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B16_RED) return;
-    float s0 = 0.f, s1 = 0.f;
-    int g = 0;
-    for (; g + 1 < n_wg; g += 2) { s0 += red[(long)g * B16_RED + i]; s1 += red[(long)(g + 1) * B16_RED + i]; }
-    if (g < n_wg) s0 += red[(long)g * B16_RED + i];
-    const float s = (s0 + s1) * inv_scale;
+// bias / q_vec gradients from the per-workgroup column sums of the fused kernel (fixed order: 8 row groups per
+// column, each summed in ascending workgroup order, then combined in a fixed tree)
+__global__ __launch_bounds__(256) void red16_kernel(const float* red, int n_wg, int h, int dk, int d, int q, float inv_scale,
+                                                    float qscale, float* db_qkv, float* db_add, float* dq_vec) {
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (i < B16_RED)
+        for (int g = rg; g < n_wg; g += 8) s += red[(long)g * B16_RED + i];
+    part[rg][c] = s;
+    __syncthreads();
+    if (rg != 0 || i >= B16_RED) return;
+    s = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+    s *= inv_scale;
     if (i < B16_RED_QKV) {
         const int tile = i >> 5, f = i & 31, head = tile / 3, which = tile - 3 * head;
         if (head < h && f < dk) db_qkv[which * d + head * dk + f] += s * (which == 0 ? qscale : 1.0f);
@@ -773,7 +778,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     }
     {
         TimingScope ts("red16", stream);
-        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 256)), dim3(256), 0, stream, red, n_wg, f.h, dk, f.d, f.q, inv_scale,
+        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 32)), dim3(256), 0, stream, red, n_wg, f.h, dk, f.d, f.q, inv_scale,
                            qscale, f.db_qkv, f.db_add, f.dq_vec);
         int rc = check_launch("red16");
         if (rc) return rc;

@@ -475,15 +475,24 @@ class NRMSEngine:
 
     # persistent news-vector cache across evaluation batches, keyed by the news ids the batch dict carries
     # (browsed_ids / candidate_ids, data_handler.py:204-222; 0 = padding slot = all-padding title)
-    def news_cache_begin(self, capacity=1 << 16):
+    def news_cache_begin(self, capacity=1 << 14):
         d = self.dims.word_embed_size
-        self._news_cache = dict(vec=torch.zeros(capacity, d, dtype=torch.float32, device=self.device),
-                                have=torch.zeros(capacity, dtype=torch.bool, device=self.device), encoded=0, hits=0)
+        old = getattr(self, "_news_cache_store", None)
+        if old is not None and old[0].shape[1] == d:                  # buffers are kept between evaluations; only the
+            vec, have = old                                           # validity bits are cleared (weights changed)
+            have.zero_()
+        else:
+            vec = torch.empty(capacity, d, dtype=torch.float32, device=self.device)
+            have = torch.zeros(capacity, dtype=torch.bool, device=self.device)
+        self._news_cache = dict(vec=vec, have=have, encoded=0, hits=0)
 
     def news_cache_end(self):
         st = getattr(self, "_news_cache", None)
         self._news_cache = None
-        return None if st is None else dict(encoded=st["encoded"], lookups=st["hits"])
+        if st is None:
+            return None
+        self._news_cache_store = (st["vec"], st["have"])
+        return dict(encoded=st["encoded"], lookups=st["hits"])
 
     def forward_cached(self, flat, hist_ids, cand_ids, hist_news, cand_news, cand_mask):
         """forward(training=False) for batches that carry news ids: a news item is encoded the first time it is
@@ -498,7 +507,7 @@ class NRMSEngine:
         top = int(news.max().item()) + 1 if N else 1
         if top > st["vec"].shape[0]:                                  # grow (amortised doubling)
             cap = max(top, 2 * st["vec"].shape[0])
-            vec = torch.zeros(cap, d, dtype=torch.float32, device=self.device)
+            vec = torch.empty(cap, d, dtype=torch.float32, device=self.device)
             have = torch.zeros(cap, dtype=torch.bool, device=self.device)
             vec[:st["vec"].shape[0]] = st["vec"]
             have[:st["have"].shape[0]] = st["have"]
