@@ -30,7 +30,7 @@ struct Bwd16Args {
     const int64_t* ids;         // non-null: all-padding titles take the closed form
     const int* order;           // as in the forward
     const int* order_cnt;
-    const _Float16* btiles;     // [4h][32][KP]: per head  Wadd_h^T (32 features x QP) | W'_q | W_k | W_v
+    const _Float16* btiles;     // [4h][32][KP]: the h tiles Wadd_h^T (32 features x QP), then per head W'_q | W_k | W_v
     const float* bqkv32;        // [3h][32]
     const _Float16* qv16;       // [QP]
     const _Float16* ctx16;      // [n_seq*S][DP]   (forward)
@@ -38,6 +38,7 @@ struct Bwd16Args {
     const float* w;             // [n_seq*S]       (forward)
     const _Float16* dout16;     // [n_seq][DP]  x loss scale, P16 order
     _Float16* dz16;             // [n_seq*S][QP]
+    _Float16* dctx16;           // [n_seq*S][DP]  d(ctx) after the dropout mask, P16 order (written and re-read per wave)
     _Float16* dqkv16;           // [rows][B16_DQ]
     float* red;                 // [gridDim.x][B16_RED] per-workgroup column sums (reduced afterwards, fixed order)
     Dropout drop;
@@ -57,7 +58,13 @@ __device__ __forceinline__ float regsum(const f32x16& x) {
     return (s0 + s1) + (s2 + s3);
 }
 
-__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_kernel(Bwd16Args a) {
+// X^T from the two operand fragments of X (rows of X = k): one product with the k-permuted identity per fragment
+__device__ __forceinline__ f32x16 transpose_frags(const h8& x0, const h8& x1, const h8 (&idf)[2]) {
+    f32x16 z = mfma32h(x0, idf[0], zero16());
+    return mfma32h(x1, idf[1], z);
+}
+
+__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_kernel(Bwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 3 * F16_SLOT);         // [B16_RED] column sums of this workgroup
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,13 +115,11 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_kernel
         }
         const bool live = valid && !empty;
         const bool only_add = __syncthreads_and(live ? 0 : 1) != 0;     // no live title: only the Wadd_h^T tiles are needed
-        // the ring restarts per group: tiles 0 and 1 of this group's stream (stride 4 for an all-padding group)
-        const int tstep = only_add ? 4 : 1;
-        const int n_end = 4 * a.h;
-        ring.n_tiles = n_end;
-        ring.load(0); ring.store(0);                       // slot 0
-        if (!only_add) { ring.load(1); ring.store(1); }    // slot 1
-        // (an all-padding group walks tiles 0, 4, 8, ...; it stages them one ahead, synchronously -- they are rare)
+        // tile stream of a group: the h tiles Wadd_h^T (stream index 0..h-1), then per head W'_q, W_k, W_v (h + 3 head + i).
+        // btiles holds them in that order.
+        (void)only_add;
+        ring.n_tiles = a.h;
+        ring.load(0);                                                   // lands while the pooling backward runs
 
         const long trow = tok0 + (tok_ok ? l32 : 0);                    // clamped token row for loads
         const float wgt = tok_ok ? a.w[tok0 + l32] : 0.f;
@@ -144,185 +149,256 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_kernel
         for (int o = 16; o > 0; o >>= 1) aw += __shfl_xor(aw, o, 64);
         const float ds = wgt * (dw - aw);                                // 0 for lanes beyond the sequence (wgt = 0)
 
-        // dZ[tok][q] = ds q_vec[q] (1 - T^2),  U[tok][q] = ds T  (column sums of U = d(q_vec), of dZ = d(b_add))
-#pragma unroll 1
-        for (int t = 0; t < F16_QT; ++t) {
-            f32x16 accz = zero16(), accu = zero16();
+        // dZ[tok][q] = ds q_vec[q] (1 - T^2),  U[tok][q] = ds T  (column sums of U = d(q_vec), of dZ = d(b_add)).
+        // The dZ fragments stay in registers: they are the B operand of every head's d(ctx) product below.
+        h8 zf[16];
+        {
+            const _Float16* tsrc = a.t16 + trow * QP + 8 * hh;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int s = 2 * t + s2;
-                const h8 tf = *reinterpret_cast<const h8*>(a.t16 + trow * QP + 16 * s + 8 * hh);
-                const h8 qf = *reinterpret_cast<const h8*>(a.qv16 + 16 * s + 8 * hh);
-                h8 dz, u;
+            for (int s = 0; s < 14; ++s) zf[s] = *reinterpret_cast<const h8*>(tsrc + 16 * s);     // tanh(.) first, dZ in place
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float tv = (float)tf[j];
-                    dz[j] = (_Float16)(ds * (float)qf[j] * (1.0f - tv * tv));
-                    u[j] = (_Float16)(ds * tv);
+            for (int t = 0; t < F16_QT; ++t) {
+                f32x16 accz = zero16(), accu = zero16();
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int s = 2 * t + s2;
+                    const h8 qf = *reinterpret_cast<const h8*>(a.qv16 + 16 * s + 8 * hh);
+                    h8 dz, u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float tv = (float)zf[s][j];
+                        dz[j] = (_Float16)(ds * (float)qf[j] * (1.0f - tv * tv));
+                        u[j] = (_Float16)(ds * tv);
+                    }
+                    zf[s] = dz;
+                    if (tok_ok) *reinterpret_cast<h8*>(a.dz16 + (tok0 + l32) * (long)QP + 16 * s + 8 * hh) = dz;
+                    // transposing products: D[tok][n] = X[tok][q = 32 t + n]  (rows = tokens in registers)
+                    accz = mfma32h(dz, sel[s2], accz);
+                    accu = mfma32h(u, sel[s2], accu);
                 }
-                if (tok_ok) *reinterpret_cast<h8*>(a.dz16 + (tok0 + l32) * (long)QP + 16 * s + 8 * hh) = dz;
-                // transposing products: D[tok][n] = X[tok][q = 32 t + n]  (rows = tokens in registers)
-                accz = mfma32h(dz, sel[s2], accz);
-                accu = mfma32h(u, sel[s2], accu);
+                if (valid) {
+                    atomicAdd(red + B16_RED_QKV + 32 * t + l32, regsum(accz));
+                    atomicAdd(red + B16_RED_QKV + QP + 32 * t + l32, regsum(accu));
+                }
             }
-            if (valid) {
-                atomicAdd(red + B16_RED_QKV + 32 * t + l32, regsum(accz));
-                atomicAdd(red + B16_RED_QKV + QP + 32 * t + l32, regsum(accu));
-            }
+            zf[14] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            zf[15] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
-        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");             // own dz16 rows are re-read per head below
-
-        const long drow = tok_ok && live ? (a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32) : -1;   // dqkv16 row
+        ring.store(0);
+        ring.load(1);
+        ring.store(1);
         __syncthreads();
 
-        int n = 0;                                    // tile cursor of this group's stream
+        // ================= d(ctx)^T per head -> dctx16 (this wave's rows; read back head by head below) =================
+        // d(ctx)^T[f][tok] = sum_q Wadd[q][f] dZ[tok][q] + w_tok dout[f], then the forward's dropout mask
+        _Float16* dcrow = a.dctx16 + (tok0 + l32) * (long)DP + 8 * hh;
+        int n = 0;
 #pragma unroll 1
         for (int head = 0; head < a.h; ++head) {
-            // ---- tile Wadd_h^T: d(ctx)^T[f][tok] = sum_q Wadd[q][f] dZ[tok][q] + w_tok dout[f], then the dropout mask
-            f32x16 dct;
+            ring.load(n + 2);
+            const h8 d0 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 8 * hh);
+            const h8 d1 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 16 + 8 * hh);
+            f32x16 dct = zero16();
+            tile_mma<true>(dct, ring, n, zf);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                dct[r] += wgt * (float)d0[r];
+                dct[8 + r] += wgt * (float)d1[r];
+            }
+            if (a.drop.thresh != 0u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
+                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
+                }
+            }
+            if (tok_ok) {
+                *reinterpret_cast<h8*>(dcrow + head * 32) = acc_frag(dct, 0);
+                *reinterpret_cast<h8*>(dcrow + head * 32 + 16) = acc_frag(dct, 1);
+            }
+            if (!live && valid) {
+                // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
+                atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(transpose32(dct, idf)));
+            }
+            ring.store(n + 2);
+            __syncthreads();
+            ++n;
+        }
+        __syncthreads();                                          // the ring restarts: nobody may still read a slot
+    }
+    __syncthreads();
+    float* out = a.red + (long)blockIdx.x * B16_RED;
+    for (int i = tid; i < B16_RED; i += F16_THREADS) out[i] = red[i];
+}
+
+
+// The attention part of the backward, on the titles with a real token only (the first g_ne groups of the order list).
+__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_kernel(Bwd16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem + 3 * F16_SLOT);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int S = a.S;
+    constexpr int KP = F16_KP, DP = F16_DP;
+    for (int i = tid; i < B16_RED; i += F16_THREADS) red[i] = 0.f;
+    h8 idf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)(l32 == 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3) ? 1.0f : 0.0f);
+    int n_ne = a.n_seq, g_ne = a.n_groups;
+    if (a.order != nullptr) {
+        n_ne = a.order_cnt[0];
+        g_ne = (n_ne + F16_WAVES - 1) / F16_WAVES;
+    }
+    TileRing ring;
+    ring.smem = smem; ring.src = a.btiles + (long)a.h * 32 * KP; ring.n_tiles = 3 * a.h; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < g_ne; grp += gridDim.x) {
+        const int slot_id = grp * F16_WAVES + wave;
+        const bool valid = slot_id < n_ne;
+        const int seq = valid ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0;
+        const long tok0 = (long)seq * S;
+        const bool tok_ok = valid && l32 < S;
+        bool empty = false;
+        if (a.ids != nullptr && valid) {
+            const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
+            empty = __ballot(is_pad) == ~0ull;
+        }
+        const bool live = valid && !empty;
+        const long trow = tok0 + (tok_ok ? l32 : 0);
+        ring.load(0); ring.store(0);
+        ring.load(1); ring.store(1);
+        int n = 0;
+        const long drow = tok_ok && live ? (a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32) : -1;   // x16 / dqkv16 row
+        h8 xf[F16_KS];
+        {
+            const _Float16* xr = a.x16 + (drow < 0 ? 0 : drow) * KP + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
+            if (drow < 0) {
+#pragma unroll
+                for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        const _Float16* dcsrc = a.dctx16 + trow * DP + 8 * hh;
+#pragma unroll 1
+        for (int head = 0; head < a.h; ++head) {
+            // d(ctx)^T of this head as operand fragments (rows f = k); zero beyond the sequence
+            h8 dc0 = *reinterpret_cast<const h8*>(dcsrc + head * 32);
+            h8 dc1 = *reinterpret_cast<const h8*>(dcsrc + head * 32 + 16);
+            if (!tok_ok) { dc0 = h8{0, 0, 0, 0, 0, 0, 0, 0}; dc1 = dc0; }
+            // ---- tiles W'_q, W_k, W_v: Q^T, K^T, V^T [f][tok], kept as operand fragments only
+            h8 q0, q1, k0, k1, v0, v1;
+            ring.load(n + 2);
             {
-                if (only_add) { if (head + 1 < a.h) ring.load(n + 4); }
-                else ring.load(n + 2);
-                h8 zf[16];
-                const _Float16* zsrc = a.dz16 + trow * QP + 8 * hh;
+                const f32x16 b = rows_of(a.bqkv32 + (3 * head) * 32, hh);
+                f32x16 t = zero16();
+                if (live) tile_mma<true>(t, ring, n, xf);
+                t += b;
+                q0 = acc_frag(t, 0); q1 = acc_frag(t, 1);
+            }
+            ring.store(n + 2);
+            __syncthreads();
+            ++n;
+            ring.load(n + 2);
+            {
+                const f32x16 b = rows_of(a.bqkv32 + (3 * head + 1) * 32, hh);
+                f32x16 t = zero16();
+                if (live) tile_mma<true>(t, ring, n, xf);
+                t += b;
+                k0 = acc_frag(t, 0); k1 = acc_frag(t, 1);
+            }
+            ring.store(n + 2);
+            __syncthreads();
+            ++n;
+            ring.load(n + 2);
+            {
+                const f32x16 b = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh);
+                f32x16 t = zero16();
+                if (live) tile_mma<true>(t, ring, n, xf);
+                t += b;
+                v0 = acc_frag(t, 0); v1 = acc_frag(t, 1);
+            }
+            ring.store(n + 2);
+            if (live) {
+                // ---- P^T (rows = keys, columns = queries), as in the forward
+                f32x16 pt = mfma32h(k0, q0, zero16());
+                pt = mfma32h(k1, q1, pt);
+                {
+                    float m = -3.0e38f;
 #pragma unroll
-                for (int s = 0; s < 14; ++s) zf[s] = *reinterpret_cast<const h8*>(zsrc + 16 * s);
-                zf[14] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-                zf[15] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (!tok_ok) {
+                    for (int r = 0; r < 16; ++r) {
+                        pt[r] = crow32(r, hh) < S ? pt[r] : -3.0e38f;
+                        m = fmaxf(m, pt[r]);
+                    }
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    float sum = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 14; ++s) zf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = crow32(r, hh) < S ? __expf(pt[r] - m) : 0.f;
+                        pt[r] = p;
+                        sum += p;
+                    }
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float inv = 1.0f / sum;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pt[r] *= inv;
                 }
-                const h8 d0 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 8 * hh);
-                const h8 d1 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 16 + 8 * hh);
-                dct = zero16();
-                tile_mma<true>(dct, ring, n, zf);
+                // ---- dP^T[j][i] = sum_f V^T[f][j] d(ctx)^T[f][i];  dS^T = P^T o (dP^T - delta_i)
+                f32x16 dst = mfma32h(v0, dc0, zero16());
+                dst = mfma32h(v1, dc1, dst);
+                {
+                    float delta = 0.f;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    dct[r] += wgt * (float)d0[r];
-                    dct[8 + r] += wgt * (float)d1[r];
+                    for (int r = 0; r < 16; ++r) delta += pt[r] * dst[r];
+                    delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[r] = pt[r] * (dst[r] - delta);
                 }
-                if (a.drop.thresh != 0u) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
-                        const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
+                const h8 ds0 = acc_frag(dst, 0), ds1 = acc_frag(dst, 1);
+                _Float16* orow = a.dqkv16 + (drow < 0 ? 0 : drow) * (long)B16_DQ + head * 96 + 8 * hh;
+                // ---- dV^T[f][j] = sum_i d(ctx)[i][f] P[i][j]
+                {
+                    const f32x16 p = transpose32(pt, idf);                          // [i][j]
+                    const f32x16 dctx = transpose_frags(dc0, dc1, idf);             // [i][f]
+                    atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx));       // d(b_v) = sum_i d(ctx)_i (rows of P sum to 1)
+                    f32x16 dv = mfma32h(acc_frag(dctx, 0), acc_frag(p, 0), zero16());
+                    dv = mfma32h(acc_frag(dctx, 1), acc_frag(p, 1), dv);
+                    if (drow >= 0) {
+                        *reinterpret_cast<h8*>(orow + 64) = acc_frag(dv, 0);
+                        *reinterpret_cast<h8*>(orow + 64 + 16) = acc_frag(dv, 1);
                     }
                 }
-                if (only_add) { if (head + 1 < a.h) ring.store(n + 4); }
-                else ring.store(n + 2);
-                __syncthreads();
-                n += tstep;
-            }
-            if (only_add || !live) {
-                // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
-                const f32x16 dctx = transpose32(dct, idf);               // [tok][f]
-                if (valid) atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx));
-                if (!only_add) {                                         // keep the barrier schedule of the live waves
-                    ring.load(n + 2); ring.store(n + 2); __syncthreads(); ++n;
-                    ring.load(n + 2); ring.store(n + 2); __syncthreads(); ++n;
-                    ring.load(n + 2); ring.store(n + 2); __syncthreads(); ++n;
+                // ---- dQ'^T[f][i] = sum_j K[j][f] dS^T[j][i]
+                {
+                    const f32x16 k = transpose_frags(k0, k1, idf);                  // [j][f]
+                    f32x16 dq = mfma32h(acc_frag(k, 0), ds0, zero16());
+                    dq = mfma32h(acc_frag(k, 1), ds1, dq);
+                    const h8 dq0 = acc_frag(dq, 0), dq1 = acc_frag(dq, 1);
+                    if (drow >= 0) {
+                        *reinterpret_cast<h8*>(orow) = dq0;
+                        *reinterpret_cast<h8*>(orow + 16) = dq1;
+                    }
+                    atomicAdd(red + (3 * head) * 32 + l32, regsum(transpose_frags(dq0, dq1, idf)));
                 }
-                continue;
-            }
-            // ---- tiles W'_q, W_k, W_v: Q^T, K^T, V^T [f][tok].  The x fragments are re-read per head (640 B per token,
-            // L2 resident): held across the whole head they would push the attention algebra below into scratch
-            f32x16 qt, kt, vt;
-            h8 xf[F16_KS];
-            {
-                const _Float16* xr = a.x16 + (drow < 0 ? 0 : drow) * KP + 8 * hh;
-#pragma unroll
-                for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
-                if (drow < 0) {
-#pragma unroll
-                    for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                // ---- dK^T[f][j] = sum_i Q'[i][f] dS[i][j]
+                {
+                    const f32x16 q = transpose_frags(q0, q1, idf);                  // [i][f]
+                    const f32x16 dsn = transpose_frags(ds0, ds1, idf);              // [i][j]
+                    f32x16 dk = mfma32h(acc_frag(q, 0), acc_frag(dsn, 0), zero16());
+                    dk = mfma32h(acc_frag(q, 1), acc_frag(dsn, 1), dk);
+                    const h8 dk0 = acc_frag(dk, 0), dk1 = acc_frag(dk, 1);
+                    if (drow >= 0) {
+                        *reinterpret_cast<h8*>(orow + 32) = dk0;
+                        *reinterpret_cast<h8*>(orow + 32 + 16) = dk1;
+                    }
+                    atomicAdd(red + (3 * head + 1) * 32 + l32, regsum(transpose_frags(dk0, dk1, idf)));
                 }
-            }
-            ring.load(n + 2);
-            { const f32x16 b = rows_of(a.bqkv32 + (3 * head) * 32, hh); qt = zero16(); tile_mma<true>(qt, ring, n, xf); qt += b; }
-            ring.store(n + 2);
-            __syncthreads();
-            ++n;
-            ring.load(n + 2);
-            { const f32x16 b = rows_of(a.bqkv32 + (3 * head + 1) * 32, hh); kt = zero16(); tile_mma<true>(kt, ring, n, xf); kt += b; }
-            ring.store(n + 2);
-            __syncthreads();
-            ++n;
-            ring.load(n + 2);
-            { const f32x16 b = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh); vt = zero16(); tile_mma<true>(vt, ring, n, xf); vt += b; }
-            ring.store(n + 2);
-
-            // ---- P^T (rows = keys, columns = queries), as in the forward
-            f32x16 pt = mfma32h(acc_frag(kt, 0), acc_frag(qt, 0), zero16());
-            pt = mfma32h(acc_frag(kt, 1), acc_frag(qt, 1), pt);
-            {
-                float m = -3.0e38f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    pt[r] = crow32(r, hh) < S ? pt[r] : -3.0e38f;
-                    m = fmaxf(m, pt[r]);
-                }
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = crow32(r, hh) < S ? __expf(pt[r] - m) : 0.f;
-                    pt[r] = p;
-                    sum += p;
-                }
-                sum += __shfl_xor(sum, 32, 64);
-                const float inv = 1.0f / sum;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pt[r] *= inv;
-            }
-            // ---- dP^T[j][i] = sum_f V^T[f][j] d(ctx)^T[f][i];  dS^T = P^T o (dP^T - delta_i)
-            f32x16 dst = mfma32h(acc_frag(vt, 0), acc_frag(dct, 0), zero16());
-            dst = mfma32h(acc_frag(vt, 1), acc_frag(dct, 1), dst);
-            {
-                float delta = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) delta += pt[r] * dst[r];
-                delta += __shfl_xor(delta, 32, 64);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dst[r] = pt[r] * (dst[r] - delta);
-            }
-            _Float16* orow = a.dqkv16 + (drow < 0 ? 0 : drow) * (long)B16_DQ + head * 96 + 8 * hh;
-            // ---- dV^T[f][j] = sum_i d(ctx)[i][f] P[i][j]
-            {
-                const f32x16 p = transpose32(pt, idf);                    // [i][j]
-                const f32x16 dctx = transpose32(dct, idf);                // [i][f]
-                atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx)); // d(b_v) = sum_j dV_j = sum_i d(ctx)_i (rows of P sum to 1)
-                f32x16 dv = mfma32h(acc_frag(dctx, 0), acc_frag(p, 0), zero16());
-                dv = mfma32h(acc_frag(dctx, 1), acc_frag(p, 1), dv);
-                if (drow >= 0) {
-                    *reinterpret_cast<h8*>(orow + 64) = acc_frag(dv, 0);
-                    *reinterpret_cast<h8*>(orow + 64 + 16) = acc_frag(dv, 1);
-                }
-            }
-            // ---- dQ'^T[f][i] = sum_j K[j][f] dS^T[j][i]
-            {
-                const f32x16 k = transpose32(kt, idf);                    // [j][f]
-                f32x16 dq = mfma32h(acc_frag(k, 0), acc_frag(dst, 0), zero16());
-                dq = mfma32h(acc_frag(k, 1), acc_frag(dst, 1), dq);
-                if (drow >= 0) {
-                    *reinterpret_cast<h8*>(orow) = acc_frag(dq, 0);
-                    *reinterpret_cast<h8*>(orow + 16) = acc_frag(dq, 1);
-                }
-                atomicAdd(red + (3 * head) * 32 + l32, regsum(transpose32(dq, idf)));
-            }
-            // ---- dK^T[f][j] = sum_i Q'[i][f] dS[i][j]
-            {
-                const f32x16 q = transpose32(qt, idf);                    // [i][f]
-                const f32x16 dsn = transpose32(dst, idf);                 // [i][j]
-                f32x16 dk = mfma32h(acc_frag(q, 0), acc_frag(dsn, 0), zero16());
-                dk = mfma32h(acc_frag(q, 1), acc_frag(dsn, 1), dk);
-                if (drow >= 0) {
-                    *reinterpret_cast<h8*>(orow + 32) = acc_frag(dk, 0);
-                    *reinterpret_cast<h8*>(orow + 32 + 16) = acc_frag(dk, 1);
-                }
-                atomicAdd(red + (3 * head + 1) * 32 + l32, regsum(transpose32(dk, idf)));
             }
             __syncthreads();
             ++n;
@@ -378,12 +454,15 @@ __global__ __launch_bounds__(256) void prep16b_kernel(Prep16bArgs a) {
         if (i < n1) {
             const int c = (int)(i % KP);
             const long r = i / KP;
-            const int f = (int)(r & 31), tile = (int)(r >> 5), head = tile >> 2, which = tile & 3;
+            const int f = (int)(r & 31), tile = (int)(r >> 5);
             float v = 0.f;
-            if (which == 0) {                                   // Wadd_h^T: row f, column q (natural order)
+            if (tile < a.h) {                                   // Wadd_h^T: row f, column q (natural order)
+                const int head = tile;
                 if (f < a.dk && c < a.q) v = a.w_add[(long)c * a.d + head * a.dk + f];
-            } else if (f < a.dk && c < a.d) {
-                v = a.w_qkv[((long)(which - 1) * a.d + head * a.dk + f) * a.d + c] * (which == 1 ? qscale : 1.0f);
+            } else {
+                const int t3 = tile - a.h, head = t3 / 3, which = t3 - 3 * head;
+                if (f < a.dk && c < a.d)
+                    v = a.w_qkv[((long)which * a.d + head * a.dk + f) * a.d + c] * (which == 0 ? qscale : 1.0f);
             }
             a.btiles[i] = (_Float16)v;
         } else if (i < n1 + n2) {
@@ -691,8 +770,9 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     L.bqkv32 = take((size_t)30 * 32 * 4);
     L.dout16 = take((size_t)n_seq * F16_DP * 2);
     L.dz16 = take((size_t)M * F16_QP * 2);
+    L.dctx16 = take((size_t)M * F16_DP * 2);
     L.dqkv16 = take((size_t)(M + 32) * B16_DQ * 2);
-    L.red = take((size_t)L.n_wg * B16_RED * 4);
+    L.red = take((size_t)2 * L.n_wg * B16_RED * 4);      // pool kernel + attention kernel
     L.maps = take((size_t)(B16_DQ * 2 + F16_KP + F16_QP * 2 + F16_DP) * 4);
     // TN partial slabs (one workgroup per CU and round): the larger of the two products
     L.tn_splits_qkv = 42;      // x 6 output blocks of 320 x 160
@@ -737,6 +817,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     float* bqkv32 = (float*)(base + L.bqkv32);
     _Float16* dout16 = (_Float16*)(base + L.dout16);
     _Float16* dz16 = (_Float16*)(base + L.dz16);
+    _Float16* dctx16 = (_Float16*)(base + L.dctx16);
     _Float16* dqkv16 = (_Float16*)(base + L.dqkv16);
     float* red = (float*)(base + L.red);
     int* nmap_qkv = (int*)(base + L.maps);
@@ -765,20 +846,29 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
     a.btiles = btiles; a.bqkv32 = bqkv32; a.qv16 = qv16;
     a.ctx16 = (const _Float16*)f.ctx16; a.t16 = (const _Float16*)f.t16; a.w = f.w; a.dout16 = dout16;
-    a.dz16 = dz16; a.dqkv16 = dqkv16; a.red = red; a.drop = f.drop;
+    a.dz16 = dz16; a.dctx16 = dctx16; a.dqkv16 = dqkv16; a.red = red; a.drop = f.drop;
     const int n_wg = a.n_groups < L.n_wg ? a.n_groups : L.n_wg;
     {
         const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4;
-        const hipError_t e = hipFuncSetAttribute((const void*)fused_bwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)fused_bwd16_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fused_bwd16_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("fused_bwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
-        TimingScope ts("fused_bwd16", stream);
-        hipLaunchKernelGGL(fused_bwd16_kernel, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+        {
+            TimingScope ts("fused_bwd16_pool", stream);
+            hipLaunchKernelGGL(fused_bwd16_pool_kernel, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+        }
+        Bwd16Args b = a;
+        b.red = red + (long)n_wg * B16_RED;                       // second set of per-workgroup sums
+        {
+            TimingScope ts("fused_bwd16_attn", stream);
+            hipLaunchKernelGGL(fused_bwd16_attn_kernel, dim3(n_wg), dim3(F16_THREADS), lds, stream, b);
+        }
         int rc = check_launch("fused_bwd16");
         if (rc) return rc;
     }
     {
         TimingScope ts("red16", stream);
-        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 32)), dim3(256), 0, stream, red, n_wg, f.h, dk, f.d, f.q, inv_scale,
+        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 32)), dim3(256), 0, stream, red, 2 * n_wg, f.h, dk, f.d, f.q, inv_scale,
                            qscale, f.db_qkv, f.db_add, f.dq_vec);
         int rc = check_launch("red16");
         if (rc) return rc;

@@ -349,7 +349,7 @@ int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cn
 
 // fused16_bwd.hip: the backward of the above.  `workspace` holds the backward weight planes, dout16, dZ16, dQKV16, the
 // per-workgroup column sums and the split-M partial slabs (fused16_bwd_layout(M, n_seq).total bytes).
-struct Fused16BwdLayout { int n_wg, tn_splits_qkv, tn_splits_add; size_t btiles, xtiles, qv16, bqkv32, dout16, dz16, dqkv16, red, maps, partial, total; };
+struct Fused16BwdLayout { int n_wg, tn_splits_qkv, tn_splits_add; size_t btiles, xtiles, qv16, bqkv32, dout16, dz16, dctx16, dqkv16, red, maps, partial, total; };
 Fused16BwdLayout fused16_bwd_layout(long M, int n_seq);
 struct Fused16Bwd {
     int n_seq, S, d, h, q;
