@@ -216,6 +216,7 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
             rc = launch_gather16(M, d, L.KP, ids, live, n_live, w->table, drop_e, acts->x, s);
             if (rc) return rc;
             f.pos = pos;
+            f.n_rows = n_live;
             f.ids = ids;
             int* order = (int*)(base + fs.order);
             int* order_cnt = (int*)(base + fs.order_cnt);

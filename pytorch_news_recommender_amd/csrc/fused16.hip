@@ -29,7 +29,9 @@ namespace nrms {
 struct Fwd16Args {
     int n_seq, S, d, h, dk, q;
     const _Float16* x16;      // [rows][KP]
-    const int* pos;           // [n_seq*S] token -> x16 row, -1 = padding token (zero row); null: row = token
+    const int* pos;           // [n_seq*S] token -> x16 row, -1 = padding token (-> the pad row); null: row = token
+    const int* n_rows;        // with pos: number of compact rows (device); row *n_rows of x16 is the padding token's row
+                              // (zeros and the ones column: its Q|K|V is exactly the bias)
     const int64_t* ids;       // news encoder with NRMS_FLAG_PAD_ROW_ZERO: all-padding titles take the closed form; else null
     const int* order;         // optional [2][n_seq]: the titles with a real token, then (second row) the all-padding
     const int* order_cnt;     //          titles; order_cnt[0..1] = their numbers (device).  null = identity
@@ -95,7 +97,10 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
     h8 xf[F16_KS];
     {
         long row = -1;
-        if (tok_ok && !empty) row = a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32;
+        if (tok_ok && !empty) {
+            row = a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32;
+            if (row < 0) row = *a.n_rows;                       // padding token inside a live title
+        }
         const _Float16* xr = a.x16 + (row < 0 ? 0 : row) * KP + 8 * hh;
 #pragma unroll
         for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
@@ -116,35 +121,22 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
             f32x16 qt, kt, vv;
             // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] + b   (features in registers, tokens on lanes)
             ring.load(n + 2);
-            {
-                const f32x16 b = rows_of(a.bqkv32 + n * 32, hh);
-                qt = zero16();
-                if (live) tile_mma<true>(qt, ring, n, xf);
-                qt += b;
-            }
+            qt = zero16();                                        // (bias: column d of the tile x the ones column of x16)
+            if (live) tile_mma<true>(qt, ring, n, xf);
             ring.store(n + 2);
             __syncthreads();
             ++n;
             // ---- tile K
             ring.load(n + 2);
-            {
-                const f32x16 b = rows_of(a.bqkv32 + n * 32, hh);
-                kt = zero16();
-                if (live) tile_mma<true>(kt, ring, n, xf);
-                kt += b;
-            }
+            kt = zero16();
+            if (live) tile_mma<true>(kt, ring, n, xf);
             ring.store(n + 2);
             __syncthreads();
             ++n;
             // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k] + b   (bias per column = lane)
             ring.load(n + 2);
-            {
-                const float bv = a.bqkv32[n * 32 + l32];
-                vv = zero16();
-                if (live) tile_mma<false>(vv, ring, n, xf);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) vv[r] += bv;
-            }
+            vv = zero16();
+            if (live) tile_mma<false>(vv, ring, n, xf);
             ring.store(n + 2);
             // ---- attention of this head, entirely in registers
             if (live) {
@@ -225,6 +217,8 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
     for (int t = 0; t < F16_QT; ++t) {                            // (not unrolled: hipcc would software-pipeline the tanh
                                                                   //  epilogues across tiles and spill their accumulators)
         ring.load(n + 2);
+        // tanh(y) = 1 - 2 / (exp(2 y) + 1) on v_exp / v_rcp: ~1e-7 absolute, far inside what fp16 keeps of it;
+        // badd32 holds b * 2 log2(e), so exp(2 (x + b)) = exp2(x * c + b')
         const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
         f32x16 tt = zero16();
         if (valid) tile_mma<true>(tt, ring, n, cf);
@@ -233,7 +227,8 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
             h4 th;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = fast_tanh(tt[4 * g + e] + ba[4 * g + e]);
+                const float ex = __builtin_amdgcn_exp2f(fmaf(tt[4 * g + e], 2.885390082f, ba[4 * g + e]));
+                const float v = fmaf(-2.0f, __builtin_amdgcn_rcpf(ex + 1.0f), 1.0f);
                 score += qq[4 * g + e] * v;
                 th[e] = (_Float16)v;
             }
@@ -320,6 +315,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
             const int f = (int)(r & 31), tile = (int)(r >> 5), head = tile / 3, which = tile - 3 * head;
             float v = 0.f;
             if (f < a.dk && k < a.d) v = a.w_qkv[((long)which * a.d + head * a.dk + f) * a.d + k] * (which == 0 ? qscale : 1.0f);
+            if (f < a.dk && k == a.d) v = a.b_qkv[which * a.d + head * a.dk + f] * (which == 0 ? qscale : 1.0f);   // x16[:, d] = 1
             a.wqkv16[i] = (_Float16)v;
         } else if (i < n1 + n2) {
             const long j = i - n1;
@@ -339,7 +335,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
             a.bqkv32[j] = v;
         } else if (i < n1 + n2 + n3 + n4) {
             const long j = i - n1 - n2 - n3;
-            a.badd32[j] = j < a.q ? a.b_add[j] : 0.f;
+            a.badd32[j] = j < a.q ? a.b_add[j] * 2.885390082f : 0.f;          // pre-multiplied by 2 log2(e) (see the tanh)
         } else {
             const long j = i - n1 - n2 - n3 - n4;
             a.qv32[j] = j < a.q ? a.q_vec[j] : 0.f;
@@ -390,12 +386,14 @@ int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cn
 __global__ __launch_bounds__(256) void gather16_kernel(unsigned d4, unsigned kp4, long M, const int64_t* ids, const int* live,
                                                        const int* n_live, const float* table, Dropout drop, _Float16* x16) {
     const unsigned rows = live != nullptr ? (unsigned)(*n_live) : (unsigned)M;
-    const unsigned total = rows * kp4;
+    const unsigned total = (rows + (live != nullptr ? 1u : 0u)) * kp4;         // compact: + the padding token's row
     const unsigned stride = gridDim.x * blockDim.x;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const unsigned r = i / kp4, c4 = i - r * kp4;
-        const long t = live != nullptr ? (long)live[r] : (long)r;
         h4 o = {0, 0, 0, 0};
+        if (c4 == d4) o[0] = (_Float16)1.0f;                                    // the ones column (bias of Q|K|V)
+        if (r >= rows) { *reinterpret_cast<h4*>(x16 + (long)i * 4) = o; continue; }
+        const long t = live != nullptr ? (long)live[r] : (long)r;
         if (c4 < d4) {
             f32x4 v = *reinterpret_cast<const f32x4*>(table + ids[t] * (long)(4 * d4) + 4 * c4);
             if (drop.thresh != 0u) v *= dropout_scale4(drop.seed, 0u, (uint64_t)(t * d4 + c4), drop.thresh, drop.inv_keep);
@@ -412,6 +410,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(unsigned d4, unsigned kp4, 
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const unsigned r = i / kp4, c4 = i - r * kp4;
         h4 o = {0, 0, 0, 0};
+        if (c4 == d4) o[0] = (_Float16)1.0f;                                    // the ones column
         if (c4 < d4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)r * d4 + c4) * 4);
 #pragma unroll
@@ -426,7 +425,7 @@ bool fused16_supported(int S, int d, int h, int q, const char** why) {
     const int dk = d / h;
     const char* w = nullptr;
     if (S > 32) w = "seq_len <= 32";
-    else if (d > F16_KP) w = "d_model <= 320";
+    else if (d > F16_KP - 4) w = "d_model <= 316";          // one spare column carries the bias of Q|K|V
     else if (dk > 32) w = "d_k <= 32";
     else if (32 * h > F16_DP) w = "n_heads <= 10";
     else if (q > F16_QP) w = "q_dim <= 224";
@@ -468,8 +467,8 @@ int launch_prep16(int d, int h, int q, const float* w_qkv, const float* b_qkv, c
 int launch_gather16(long M, int d, int KP, const int64_t* ids, const int* live, const int* n_live, const float* table,
                     const Dropout& drop, void* x16, hipStream_t stream) {
     if (M <= 0) return NRMS_OK;
-    if (M * (KP / 4) >= (1L << 32)) { set_error("gather16: index overflow"); return NRMS_EINVAL; }
-    int blocks = cdiv(M * (KP / 4), 256);
+    if ((M + 1) * (KP / 4) >= (1L << 32)) { set_error("gather16: index overflow"); return NRMS_EINVAL; }
+    int blocks = cdiv((M + 1) * (KP / 4), 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     TimingScope ts("gather_dropout", stream);
     hipLaunchKernelGGL(gather16_kernel, dim3(blocks), dim3(256), 0, stream, (unsigned)(d / 4), (unsigned)(KP / 4), M, ids, live,
@@ -493,7 +492,7 @@ int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
     const char* base = (const char*)f.planes;
     Fwd16Args a{};
     a.n_seq = f.n_seq; a.S = f.S; a.d = f.d; a.h = f.h; a.dk = f.d / f.h; a.q = f.q;
-    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
+    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.n_rows = f.n_rows; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
     a.wtiles = (const _Float16*)(base + L.wqkv16); a.bqkv32 = (const float*)(base + L.bqkv32);
     a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
     a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;

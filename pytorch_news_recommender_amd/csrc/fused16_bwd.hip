@@ -27,6 +27,7 @@ struct Bwd16Args {
     int n_groups;               // ceil(n_seq / F16_WAVES) (+1 with an order list)
     const _Float16* x16;        // [rows][KP]
     const int* pos;             // token -> x16 / dqkv16 row, -1 = padding token; null: row = token
+    const int* n_rows;          // device: number of compact rows (with pos); x16 row *n_rows is the padding token's row
     const int64_t* ids;         // non-null: all-padding titles take the closed form
     const int* order;           // as in the forward
     const int* order_cnt;
@@ -277,10 +278,12 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_k
         const long drow = tok_ok && live ? (a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32) : -1;   // x16 / dqkv16 row
         h8 xf[F16_KS];
         {
-            const _Float16* xr = a.x16 + (drow < 0 ? 0 : drow) * KP + 8 * hh;
+            // a padding token inside a live title reads the pad row (zeros + the ones column => Q|K|V = bias)
+            const long xrow = (tok_ok && live && drow < 0) ? (long)*a.n_rows : drow;
+            const _Float16* xr = a.x16 + (xrow < 0 ? 0 : xrow) * KP + 8 * hh;
 #pragma unroll
             for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
-            if (drow < 0) {
+            if (xrow < 0) {
 #pragma unroll
                 for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
             }
@@ -296,10 +299,8 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_k
             h8 q0, q1, k0, k1, v0, v1;
             ring.load(n + 2);
             {
-                const f32x16 b = rows_of(a.bqkv32 + (3 * head) * 32, hh);
-                f32x16 t = zero16();
+                f32x16 t = zero16();                              // bias: column d of the tile x the ones column of x16
                 if (live) tile_mma<true>(t, ring, n, xf);
-                t += b;
                 q0 = acc_frag(t, 0); q1 = acc_frag(t, 1);
             }
             ring.store(n + 2);
@@ -307,10 +308,8 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_k
             ++n;
             ring.load(n + 2);
             {
-                const f32x16 b = rows_of(a.bqkv32 + (3 * head + 1) * 32, hh);
-                f32x16 t = zero16();
+                f32x16 t = zero16();                              // bias: column d of the tile x the ones column of x16
                 if (live) tile_mma<true>(t, ring, n, xf);
-                t += b;
                 k0 = acc_frag(t, 0); k1 = acc_frag(t, 1);
             }
             ring.store(n + 2);
@@ -318,10 +317,8 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_k
             ++n;
             ring.load(n + 2);
             {
-                const f32x16 b = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh);
-                f32x16 t = zero16();
+                f32x16 t = zero16();                              // bias: column d of the tile x the ones column of x16
                 if (live) tile_mma<true>(t, ring, n, xf);
-                t += b;
                 v0 = acc_frag(t, 0); v1 = acc_frag(t, 1);
             }
             ring.store(n + 2);
@@ -463,6 +460,7 @@ __global__ __launch_bounds__(256) void prep16b_kernel(Prep16bArgs a) {
                 const int t3 = tile - a.h, head = t3 / 3, which = t3 - 3 * head;
                 if (f < a.dk && c < a.d)
                     v = a.w_qkv[((long)which * a.d + head * a.dk + f) * a.d + c] * (which == 0 ? qscale : 1.0f);
+                if (f < a.dk && c == a.d) v = a.b_qkv[which * a.d + head * a.dk + f] * (which == 0 ? qscale : 1.0f);   // ones column
             }
             a.btiles[i] = (_Float16)v;
         } else if (i < n1 + n2) {
@@ -602,40 +600,48 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
     const int out_blocks = a.n_blk * a.k_blk;
-    const int blk = blockIdx.x % out_blocks, split = blockIdx.x / out_blocks;
+    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, and the out_blocks workgroups of one M-split read the
+    // same rows (each A chunk k_blk times, each B chunk n_blk times): give an XCD a contiguous range of (split, block)
+    // pairs so those re-reads hit its L2 (the grid is a multiple of 8)
+    const int per_xcd = gridDim.x >> 3;
+    const int idx = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const int blk = idx % out_blocks, split = idx / out_blocks;
     const int bn = blk % a.n_blk, bk = blk / a.n_blk;
     const int ncol0 = bn * T16_AW, kcol0 = bk * T16_BW;
     const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
     const int rps = (((M + a.splits - 1) / a.splits) + T16_MC - 1) / T16_MC * T16_MC;
     const int m_begin = split * rps, m_end = min(M, m_begin + rps);
 
-    // staging slots (16-byte chunks); loads are unconditional from clamped addresses, zeroed when written to LDS
-    h8 ra[T16_A_IT], rb[T16_B_IT];
-    auto load_stage = [&](int m0) {
+    // staging slots (16-byte chunks); loads are unconditional from clamped addresses, zeroed when written to LDS.
+    // A stage is only ~400 cycles of MFMA per wave, far less than one HBM round trip: the rows are prefetched TWO
+    // stages ahead in two statically named register sets (the loop is unrolled by two; a run-time set index would go
+    // through movrel), and the stage body is branch-free (clamped loads past the end, zeroed at the LDS write).
+    struct Regs { h8 a[T16_A_IT], b[T16_B_IT]; };
+    auto load_stage = [&](Regs& R, int m0) {
 #pragma unroll
         for (int i = 0; i < T16_A_IT; ++i) {
             const int sl = tid + T16_THREADS * i;
             const int r = min(sl / (T16_AW / 8), T16_MC - 1), c = (sl % (T16_AW / 8)) * 8;
             const long m = min(m0 + r, max(m_end - 1, 0));
-            ra[i] = *reinterpret_cast<const h8*>(a.A + m * a.lda + min(ncol0 + c, a.N - 8));
+            R.a[i] = *reinterpret_cast<const h8*>(a.A + m * a.lda + min(ncol0 + c, a.N - 8));
         }
 #pragma unroll
         for (int i = 0; i < T16_B_IT; ++i) {
             const int sl = tid + T16_THREADS * i;
             const int r = min(sl / (T16_BW / 8), T16_MC - 1), c = (sl % (T16_BW / 8)) * 8;
             const long m = min(m0 + r, max(m_end - 1, 0));
-            rb[i] = *reinterpret_cast<const h8*>(a.B + m * a.ldb + min(kcol0 + c, a.K - 8));
+            R.b[i] = *reinterpret_cast<const h8*>(a.B + m * a.ldb + min(kcol0 + c, a.K - 8));
         }
     };
     const h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto store_stage = [&](int m0, char* st) {
+    auto store_stage = [&](const Regs& R, int m0, char* st) {
 #pragma unroll
         for (int i = 0; i < T16_A_IT; ++i) {
             const int sl = tid + T16_THREADS * i;
             const int r = sl / (T16_AW / 8), c = (sl % (T16_AW / 8)) * 8;
             if (r < T16_MC) {
                 const bool ok = m0 + r < m_end && ncol0 + c < a.N;
-                *reinterpret_cast<h8*>(st + (r * T16_PA + c) * 2) = ok ? ra[i] : z8;
+                *reinterpret_cast<h8*>(st + (r * T16_PA + c) * 2) = ok ? R.a[i] : z8;
             }
         }
 #pragma unroll
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
             const int r = sl / (T16_BW / 8), c = (sl % (T16_BW / 8)) * 8;
             if (r < T16_MC) {
                 const bool ok = m0 + r < m_end && kcol0 + c < a.K;
-                *reinterpret_cast<h8*>(st + T16_A_BYTES + (r * T16_PB + c) * 2) = ok ? rb[i] : z8;
+                *reinterpret_cast<h8*>(st + T16_A_BYTES + (r * T16_PB + c) * 2) = ok ? R.b[i] : z8;
             }
         }
     };
@@ -664,16 +670,23 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
             for (int j = 0; j < T16_NTK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0);
         }
     };
-    const int n_stage = m_end > m_begin ? (m_end - m_begin + T16_MC - 1) / T16_MC : 0;
+    int n_stage = m_end > m_begin ? (m_end - m_begin + T16_MC - 1) / T16_MC : 0;
     if (n_stage > 0) {
-        load_stage(m_begin);
-        store_stage(m_begin, smem);
+        n_stage = (n_stage + 1) & ~1;                 // an odd count is rounded up (one all-zero stage)
+        Regs R0, R1;
+        load_stage(R1, m_begin);
+        store_stage(R1, m_begin, smem);
+        load_stage(R0, m_begin + T16_MC);
         __syncthreads();
-        for (int s = 0; s < n_stage; ++s) {
-            load_stage(m_begin + (s + 1) * T16_MC);
+        auto body = [&](const Regs& Rs, Regs& Rl, int s) {
+            load_stage(Rl, m_begin + (s + 2) * T16_MC);
+            store_stage(Rs, m_begin + (s + 1) * T16_MC, smem + ((s + 1) & 1) * T16_STAGE);
             compute(smem + (s & 1) * T16_STAGE);
-            store_stage(m_begin + (s + 1) * T16_MC, smem + ((s + 1) & 1) * T16_STAGE);
             __syncthreads();
+        };
+        for (int s = 0; s < n_stage; s += 2) {
+            body(R0, R1, s);
+            body(R1, R0, s + 1);
         }
     }
     // partial slab [split][N][K]
@@ -710,18 +723,20 @@ __global__ void tn16_reduce_kernel(const float* partial, int splits, int N, int 
 
 // bias / q_vec gradients from the per-workgroup column sums of the fused kernel (fixed order: 8 row groups per
 // column, each summed in ascending workgroup order, then combined in a fixed tree)
-__global__ __launch_bounds__(256) void red16_kernel(const float* red, int n_wg, int h, int dk, int d, int q, float inv_scale,
+__global__ __launch_bounds__(1024) void red16_kernel(const float* red, int n_wg, int h, int dk, int d, int q, float inv_scale,
                                                     float qscale, float* db_qkv, float* db_add, float* dq_vec) {
-    __shared__ float part[8][32];
+    __shared__ float part[32][33];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + c;
     float s = 0.f;
     if (i < B16_RED)
-        for (int g = rg; g < n_wg; g += 8) s += red[(long)g * B16_RED + i];
+        for (int g = rg; g < n_wg; g += 32) s += red[(long)g * B16_RED + i];
     part[rg][c] = s;
     __syncthreads();
     if (rg != 0 || i >= B16_RED) return;
-    s = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += part[r][c];               // fixed order
     s *= inv_scale;
     if (i < B16_RED_QKV) {
         const int tile = i >> 5, f = i & 31, head = tile / 3, which = tile - 3 * head;
@@ -775,8 +790,8 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     L.red = take((size_t)2 * L.n_wg * B16_RED * 4);      // pool kernel + attention kernel
     L.maps = take((size_t)(B16_DQ * 2 + F16_KP + F16_QP * 2 + F16_DP) * 4);
     // TN partial slabs (one workgroup per CU and round): the larger of the two products
-    L.tn_splits_qkv = 42;      // x 6 output blocks of 320 x 160
-    L.tn_splits_add = 128;     // x 2
+    L.tn_splits_qkv = 44;      // x 6 output blocks of 320 x 160 = 264 workgroups (a multiple of 8: XCD mapping)
+    L.tn_splits_add = 128;     // x 2 = 256
     const size_t p1 = (size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4, p2 = (size_t)L.tn_splits_add * F16_QP * F16_DP * 4;
     L.partial = take(p1 > p2 ? p1 : p2);
     L.total = off;
@@ -843,7 +858,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     Bwd16Args a{};
     a.n_seq = f.n_seq; a.S = f.S; a.d = f.d; a.h = f.h; a.dk = dk; a.q = f.q;
     a.n_groups = cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 1 : 0);
-    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
+    a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.n_rows = f.n_rows_dev; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
     a.btiles = btiles; a.bqkv32 = bqkv32; a.qv16 = qv16;
     a.ctx16 = (const _Float16*)f.ctx16; a.t16 = (const _Float16*)f.t16; a.w = f.w; a.dout16 = dout16;
     a.dz16 = dz16; a.dctx16 = dctx16; a.dqkv16 = dqkv16; a.red = red; a.drop = f.drop;
@@ -868,7 +883,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     }
     {
         TimingScope ts("red16", stream);
-        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 32)), dim3(256), 0, stream, red, 2 * n_wg, f.h, dk, f.d, f.q, inv_scale,
+        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 32)), dim3(1024), 0, stream, red, 2 * n_wg, f.h, dk, f.d, f.q, inv_scale,
                            qscale, f.db_qkv, f.db_add, f.dq_vec);
         int rc = check_launch("red16");
         if (rc) return rc;

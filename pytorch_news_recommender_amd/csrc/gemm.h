@@ -334,7 +334,8 @@ struct Fused16Fwd {
     int n_seq, S, d, h, q;
     const void* planes;       // fused16_layout(d, h, q).total bytes, filled by launch_prep16
     const void* x16;          // [rows][KP] fp16
-    const int* pos;           // token -> x16 row (-1: zero row) or null (row = token)
+    const int* pos;           // token -> x16 row (-1: the padding token's row, index *n_rows) or null (row = token)
+    const int* n_rows;        // device: number of compact rows (required with pos)
     const int64_t* ids;       // non-null: sequences whose ids are all 0 take the closed form (padding row is zero)
     const int* order;         // optional [2][n_seq] from launch_title_order (+ order_cnt[2]): live titles, then all-padding ones
     const int* order_cnt;

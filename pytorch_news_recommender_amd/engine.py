@@ -124,7 +124,7 @@ class NRMSEngine:
         self._bad_event = None
         self._news_cache = None
 
-    FP16_LIMITS = dict(seq_len=32, d_model=320, d_k=32, n_heads=10, q_dim=224)
+    FP16_LIMITS = dict(seq_len=32, d_model=316, d_k=32, n_heads=10, q_dim=224)
 
     def _fp16_ok(self, enc, seq_len, mask_mode, training):
         """The fused fp16 kernels cover the shapes of include/nrms_hip.h (NRMS_PRECISION_FP16); an encoder pass
@@ -185,7 +185,7 @@ class NRMSEngine:
             # fp16 activations with padded pitches (include/nrms_hip.h, nrms_encoder_acts)
             KP, DP, QP = _lib.NRMS_FP16_KP, _lib.NRMS_FP16_DP, _lib.NRMS_FP16_QP
             h = torch.float16
-            x = self._buf(tag + ".x16", M * KP, h)
+            x = self._buf(tag + ".x16", (M + 1) * KP, h)          # + the padding token's row
             ctx = self._buf(tag + ".ctx16", M * DP, h)
             t = self._buf(tag + ".t16", M * QP, h) if need_bwd else None
             w = self._buf(tag + ".w", M) if need_bwd else None
