@@ -66,7 +66,10 @@ def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news):
     if fp16_news:
         # news encoder in the fused fp16 kernels (fp16 activations: 2 B per element, padded pitches 320 / 224)
         w["fused_fwd16"] = ("mfma", qkv_n + att_n + add_n, 2.0 * (live_rows * 320 + Mn * 320 + Mn * 224))
-        w["fused_bwd16"] = ("mfma", add_n + 2.0 * att_n, 2.0 * (live_rows * 320 + Mn * 320 + 2 * Mn * 224 + live_rows * 960))
+        # backward, kernel 1: pooling backward + d(ctx) (reads ctx16, t16; writes dZ16, d(ctx)16); kernel 2: attention backward
+        # of the titles with a real token (reads x16, d(ctx)16; writes dQKV16); recomputed Q|K|V / P are not algorithmic work
+        w["fused_bwd16_pool"] = ("mfma", add_n, 2.0 * (2 * Mn * 320 + 2 * Mn * 224))
+        w["fused_bwd16_attn"] = ("mfma", 2.0 * att_n, 2.0 * (live_rows * 320 + Mn * (1.0 - ap) * 320 + live_rows * 960))
         w["dwqkv_bwd"] = ("mfma", qkv_n + qkv_u, 2.0 * live_rows * (960 + 320) + 16.0 * Mu * d)
         w["dx_bwd"] = ("mfma", dx_n + qkv_u, 2.0 * live_rows * 960 + 4.0 * live_rows * d + 16.0 * Mu * d)
         w["dwadd_bwd"] = ("mfma", add_n + add_u, 2.0 * Mn * (224 + 320) + 4.0 * Mu * (d + q))
