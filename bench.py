@@ -70,17 +70,14 @@ def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news):
         # of the titles with a real token (reads x16, d(ctx)16; writes dQKV16); recomputed Q|K|V / P are not algorithmic work
         w["fused_bwd16_pool"] = ("mfma", add_n, 2.0 * (2 * Mn * 320 + 2 * Mn * 224))
         w["fused_bwd16_attn"] = ("mfma", 2.0 * att_n, 2.0 * (live_rows * 320 + Mn * (1.0 - ap) * 320 + live_rows * 960))
-        w["dwqkv_bwd"] = ("mfma", qkv_n + qkv_u, 2.0 * live_rows * (960 + 320) + 16.0 * Mu * d)
-        w["dx_bwd"] = ("mfma", dx_n + qkv_u, 2.0 * live_rows * 960 + 4.0 * live_rows * d + 16.0 * Mu * d)
-        w["dwadd_bwd"] = ("mfma", add_n + add_u, 2.0 * Mn * (224 + 320) + 4.0 * Mu * (d + q))
+        w["dwqkv_bwd"] = ("mfma", qkv_n + qkv_u, 2.0 * (live_rows + Mu) * (960 + 320))
+        w["dx_bwd"] = ("mfma", dx_n + qkv_u, (live_rows + Mu) * (2.0 * 960 + 4.0 * d))
+        w["dwadd_bwd"] = ("mfma", add_n + add_u, 2.0 * (Mn + Mu) * (224 + 320))
         w["gather_dropout"] = ("hbm", 0.0, live_rows * (4.0 * d + 2.0 * 320))
-        # user encoder (histories of 50 > 32 rows) runs in the bf16x3 kernels
-        w["qkv_proj_fwd"] = ("mfma", qkv_u, 16.0 * Mu * d)
-        w["addattn_fwd"] = ("mfma", add_u, 4.0 * Mu * (d + q))
-        w["dctx_bwd"] = ("mfma", add_u, 4.0 * Mu * (d + q))
-        w["attn_fwd"] = ("hbm", att_u, 16.0 * Mu * d)
-        w["attn_bwd"] = ("hbm", 2.5 * att_u, 28.0 * Mu * d)
-        w["addattn_bwd_rows"] = ("hbm", 0.0, 4.0 * Mu * (d + q))
+        # user encoder (histories of 50 rows): the 64-row variants of the same kernels
+        w["fused64_fwd16"] = ("mfma", qkv_u + att_u + add_u, 2.0 * Mu * (320 + 320 + 224))
+        w["fused64_bwd16_pool"] = ("mfma", add_u, 2.0 * Mu * (2 * 320 + 2 * 224))
+        w["fused64_bwd16_attn"] = ("mfma", 2.0 * att_u, 2.0 * Mu * (320 + 320 + 960))
     else:
         M = float(Mn + Mu)
         Md, Mq = 4.0 * M * d, 4.0 * M * q
@@ -331,9 +328,6 @@ def main():
         work = kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news)
         # which arithmetic each timer's kernels run in (fp16 mode: the user encoder's kernels are bf16x3)
         kprec = {k: args.precision for k in work}
-        if fp16_news:
-            for k in ("qkv_proj_fwd", "addattn_fwd", "dctx_bwd"):
-                kprec[k] = "bf16x3"
         kernels = {}
         for name, (bound, fl, by) in work.items():
             ms, n = eng.timing_read(name)

@@ -44,7 +44,7 @@ extern "C" {
 #define NRMS_PRECISION_FP16   3 /* fused path: one wavefront per sequence, every contraction on v_mfma_f32_32x32x16_f16
                                    (fp16 operands: 11 significant bits, fp32 accumulate), Q/K/V, attention probabilities
                                    and tanh(.) register-resident, activations kept for the backward in fp16.
-                                   Restrictions: seq_len <= 32, d_model <= 316, d_k <= 32, n_heads <= 10, q_dim <= 224,
+                                   Restrictions: seq_len <= 64, d_model <= 316, d_k <= 32, n_heads <= 10, q_dim <= 224,
                                    no output projection, no masks (NRMS_EINVAL otherwise).  Activation buffers change
                                    meaning (see nrms_encoder_acts); context-dropout counters run over the padded
                                    [M, NRMS_FP16_DP] layout, 32 columns per head (nrms_dropout_keep_mask with d = 320). */

@@ -47,8 +47,12 @@ struct Fwd16Args {
     int dbg;                  // timing experiments only (NRMS_F16_DBG): 1 = no tile staging after the prologue
 };
 
-template <bool TRAIN>
-__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel(Fwd16Args a) {
+// SB = 32-row blocks per sequence: 1 (titles, histories of at most 32 slots; two workgroups per CU) or 2 (sequences of up
+// to 64 rows, e.g. the 50-slot histories of the user encoder: one wave still owns the whole sequence, with twice the
+// accumulators -- one workgroup per CU, up to 512 registers per lane; it is 3 % of the flops, what matters is that its
+// activations stay on chip like the titles')
+template <bool TRAIN, int SB>
+__global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fused_fwd16_kernel(Fwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
     constexpr int KP = F16_KP, DP = F16_DP, QP = F16_QP;
     const int n_head_tiles = 3 * a.h;
 
-    // ---- which sequence this wave owns.  With an order list, workgroups [0, ceil(n_ne / 8)) take the titles that
+    // ---- which sequence this wave owns.  With an order list, workgroups [0, ceil(n_ne / 4)) take the titles that
     // have a real token, the following ones the all-padding titles (closed form: no head tile is touched), so no
     // wave idles through the head tiles next to a working one.
     int slot_id = blockIdx.x * F16_WAVES + wave;
@@ -75,9 +79,11 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
     }
     if (!valid) seq = 0;
     const long tok0 = (long)seq * S;                             // first token of the sequence
-    const bool tok_ok = valid && l32 < S;
+    bool tok_ok[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) tok_ok[b] = valid && 32 * b + l32 < S;
     bool empty = false;                                          // all-padding title: attention is uniform over equal rows
-    if (a.ids != nullptr && valid) {
+    if (SB == 1 && a.ids != nullptr && valid) {
         const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
         empty = __ballot(is_pad) == ~0ull;
     }
@@ -93,126 +99,145 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
     ring.load(n_begin + 1);
     ring.store(n_begin + 1);
 
-    // ---- this lane's x fragments: token l32, features 16 s + 8 hh .. +7 (A operand of x W^T and B operand of W x^T)
-    h8 xf[F16_KS];
-    {
+    // ---- this lane's x fragments: token 32 b + l32, features 16 s + 8 hh .. +7 (A operand of x W^T, B operand of W x^T)
+    h8 xf[SB][F16_KS];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
         long row = -1;
-        if (tok_ok && !empty) {
-            row = a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32;
+        if (tok_ok[b] && !empty) {
+            row = a.pos != nullptr ? (long)a.pos[tok0 + 32 * b + l32] : tok0 + 32 * b + l32;
             if (row < 0) row = *a.n_rows;                       // padding token inside a live title
         }
         const _Float16* xr = a.x16 + (row < 0 ? 0 : row) * KP + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
+        for (int s = 0; s < F16_KS; ++s) xf[b][s] = *reinterpret_cast<const h8*>(xr + 16 * s);
         if (row < 0) {
 #pragma unroll
-            for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < F16_KS; ++s) xf[b][s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
     __syncthreads();
     ring.dbg = a.dbg;
 
-    const long ctx_row = (tok0 + l32) * (long)DP;                 // this lane's ctx16 row (token l32)
     int n = n_begin;
 #pragma unroll 1
     for (int head = 0; head < a.h; ++head) {
-        f32x16 ct;                                               // ctx^T[f][tok] of this head
+        f32x16 ct[SB];                                           // ctx^T[f][tok] of this head, per token block
         if (!skip_heads) {
-            f32x16 qt, kt, vv;
-            // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] + b   (features in registers, tokens on lanes)
+            f32x16 qt[SB], kt[SB], vv[SB];
+            // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] (+ b through the ones column)
             ring.load(n + 2);
-            qt = zero16();                                        // (bias: column d of the tile x the ones column of x16)
-            if (live) tile_mma<true>(qt, ring, n, xf);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) { qt[b] = zero16(); if (live) tile_mma<true>(qt[b], ring, n, xf[b]); }
             ring.store(n + 2);
             __syncthreads();
             ++n;
             // ---- tile K
             ring.load(n + 2);
-            kt = zero16();
-            if (live) tile_mma<true>(kt, ring, n, xf);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) { kt[b] = zero16(); if (live) tile_mma<true>(kt[b], ring, n, xf[b]); }
             ring.store(n + 2);
             __syncthreads();
             ++n;
-            // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k] + b   (bias per column = lane)
+            // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k]
             ring.load(n + 2);
-            vv = zero16();
-            if (live) tile_mma<false>(vv, ring, n, xf);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) { vv[b] = zero16(); if (live) tile_mma<false>(vv[b], ring, n, xf[b]); }
             ring.store(n + 2);
-            // ---- attention of this head, entirely in registers
+            // ---- attention of this head, entirely in registers: one query block at a time
             if (live) {
-                f32x16 st;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[r] = 0.f;
-                // S^T[j][i] = sum_f KT[f][j] QT[f][i]   (rows j = keys in registers, columns i = queries on lanes)
-                st = mfma32h(acc_frag(kt, 0), acc_frag(qt, 0), st);
-                st = mfma32h(acc_frag(kt, 1), acc_frag(qt, 1), st);
-                float m = -3.0e38f;
+                for (int ib = 0; ib < SB; ++ib) {
+                    f32x16 st[SB];                               // S^T[j][i]: rows j = keys (block jb) in registers, columns i = queries
+                    float m = -3.0e38f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    st[r] = crow32(r, hh) < S ? st[r] : -3.0e38f;        // rows beyond the sequence are not keys
-                    m = fmaxf(m, st[r]);
+                    for (int jb = 0; jb < SB; ++jb) {
+                        st[jb] = mfma32h(acc_frag(kt[jb], 0), acc_frag(qt[ib], 0), zero16());
+                        st[jb] = mfma32h(acc_frag(kt[jb], 1), acc_frag(qt[ib], 1), st[jb]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            st[jb][r] = 32 * jb + crow32(r, hh) < S ? st[jb][r] : -3.0e38f;   // rows beyond the sequence are not keys
+                            m = fmaxf(m, st[jb][r]);
+                        }
+                    }
+                    m = fmaxf(m, __shfl_xor(m, 32, 64));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int jb = 0; jb < SB; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float p = 32 * jb + crow32(r, hh) < S ? __expf(st[jb][r] - m) : 0.f;
+                            st[jb][r] = p;
+                            sum += p;
+                        }
+                    sum += __shfl_xor(sum, 32, 64);
+                    const float inv = 1.0f / sum;
+                    // ctx^T[f][i] = sum_j V[j][f] P^T[j][i]
+                    ct[ib] = zero16();
+#pragma unroll
+                    for (int jb = 0; jb < SB; ++jb) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[jb][r] *= inv;
+                        ct[ib] = mfma32h(acc_frag(vv[jb], 0), acc_frag(st[jb], 0), ct[ib]);
+                        ct[ib] = mfma32h(acc_frag(vv[jb], 1), acc_frag(st[jb], 1), ct[ib]);
+                    }
                 }
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = crow32(r, hh) < S ? __expf(st[r] - m) : 0.f;
-                    st[r] = p;
-                    sum += p;
-                }
-                sum += __shfl_xor(sum, 32, 64);
-                const float inv = 1.0f / sum;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[r] *= inv;
-                // ctx^T[f][i] = sum_j V[j][f] P^T[j][i]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ct[r] = 0.f;
-                ct = mfma32h(acc_frag(vv, 0), acc_frag(st, 0), ct);
-                ct = mfma32h(acc_frag(vv, 1), acc_frag(st, 1), ct);
             }
         }
-        if (!live) ct = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh);    // all-padding title: ctx = b_v for every token
-        if (a.drop.thresh != 0u) {
+        if (!live) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
-                const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ct[4 * g + e] *= sc[e];
-            }
+            for (int b = 0; b < SB; ++b) ct[b] = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh);   // all-padding title: ctx = b_v
         }
-        if (tok_ok) {
-            _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
-            *reinterpret_cast<h8*>(dst) = acc_frag(ct, 0);
-            *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct, 1);
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            if (a.drop.thresh != 0u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint64_t e0 = (uint64_t)(tok0 + 32 * b + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
+                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ct[b][4 * g + e] *= sc[e];
+                }
+            }
+            if (tok_ok[b]) {
+                _Float16* dst = a.ctx16 + (tok0 + 32 * b + l32) * (long)DP + head * 32 + 8 * hh;
+                *reinterpret_cast<h8*>(dst) = acc_frag(ct[b], 0);
+                *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct[b], 1);
+            }
         }
         if (!skip_heads) {
             __syncthreads();
             ++n;
         }
     }
-    if (tok_ok) {                                                  // heads the model does not have: zero columns
-        for (int head = a.h; head < F16_CS / 2; ++head) {
-            _Float16* dst = a.ctx16 + ctx_row + head * 32 + 8 * hh;
-            *reinterpret_cast<h8*>(dst) = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<h8*>(dst + 16) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        if (tok_ok[b]) {                                           // heads the model does not have: zero columns
+            for (int head = a.h; head < F16_CS / 2; ++head) {
+                _Float16* dst = a.ctx16 + (tok0 + 32 * b + l32) * (long)DP + head * 32 + 8 * hh;
+                *reinterpret_cast<h8*>(dst) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<h8*>(dst + 16) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     }
 
     // ---- additive attention: T^T[q][tok] = sum_f Wadd[q][f] ctx^T[f][tok]; the ctx operand is read back in the
     // very layout it was stored in (own stores: wait for them, then plain loads)
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's ctx16 stores have landed
-    h8 cf[F16_CS];
-    {
-        const _Float16* src = a.ctx16 + (tok_ok ? ctx_row : 0) + 8 * hh;
+    h8 cf[SB][F16_CS];
 #pragma unroll
-        for (int s = 0; s < F16_CS; ++s) cf[s] = *reinterpret_cast<const h8*>(src + 16 * s);
-        if (!tok_ok) {
+    for (int b = 0; b < SB; ++b) {
+        const _Float16* src = a.ctx16 + (tok0 + (tok_ok[b] ? 32 * b + l32 : 0)) * (long)DP + 8 * hh;
 #pragma unroll
-            for (int s = 0; s < F16_CS; ++s) cf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < F16_CS; ++s) cf[b][s] = *reinterpret_cast<const h8*>(src + 16 * s);
+        if (!tok_ok[b]) {
+#pragma unroll
+            for (int s = 0; s < F16_CS; ++s) cf[b][s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    float score = 0.f;                                            // sum_q q_vec[q] tanh(.)[q][tok], per token = per lane
+    float score[SB];                                              // sum_q q_vec[q] tanh(.)[q][tok], per token = per lane
+#pragma unroll
+    for (int b = 0; b < SB; ++b) score[b] = 0.f;
 #pragma unroll 1
     for (int t = 0; t < F16_QT; ++t) {                            // (not unrolled: hipcc would software-pipeline the tanh
                                                                   //  epilogues across tiles and spill their accumulators)
@@ -220,37 +245,51 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
         // tanh(y) = 1 - 2 / (exp(2 y) + 1) on v_exp / v_rcp: ~1e-7 absolute, far inside what fp16 keeps of it;
         // badd32 holds b * 2 log2(e), so exp(2 (x + b)) = exp2(x * c + b')
         const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
-        f32x16 tt = zero16();
-        if (valid) tile_mma<true>(tt, ring, n, cf);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            h4 th;
+        for (int b = 0; b < SB; ++b) {
+            f32x16 tt = zero16();
+            if (valid) tile_mma<true>(tt, ring, n, cf[b]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float ex = __builtin_amdgcn_exp2f(fmaf(tt[4 * g + e], 2.885390082f, ba[4 * g + e]));
-                const float v = fmaf(-2.0f, __builtin_amdgcn_rcpf(ex + 1.0f), 1.0f);
-                score += qq[4 * g + e] * v;
-                th[e] = (_Float16)v;
+            for (int g = 0; g < 4; ++g) {
+                h4 th;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ex = __builtin_amdgcn_exp2f(fmaf(tt[4 * g + e], 2.885390082f, ba[4 * g + e]));
+                    const float v = fmaf(-2.0f, __builtin_amdgcn_rcpf(ex + 1.0f), 1.0f);
+                    score[b] += qq[4 * g + e] * v;
+                    th[e] = (_Float16)v;
+                }
+                if (TRAIN && tok_ok[b])
+                    *reinterpret_cast<h4*>(a.t16 + (tok0 + 32 * b + l32) * (long)QP + 32 * t + 8 * g + 4 * hh) = th;
             }
-            if (TRAIN && tok_ok)
-                *reinterpret_cast<h4*>(a.t16 + (tok0 + l32) * (long)QP + 32 * t + 8 * g + 4 * hh) = th;
         }
         ring.store(n + 2);
         __syncthreads();
         ++n;
     }
-    score += __shfl_xor(score, 32, 64);
-    // softmax over the tokens of the sequence (lanes 0..S-1 of either half)
-    const float sm = l32 < S ? score : -3.0e38f;
-    float mx = sm;
+    // softmax over the tokens of the sequence (lane l32 of block b holds token 32 b + l32, in either half)
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        score[b] += __shfl_xor(score[b], 32, 64);
+        score[b] = 32 * b + l32 < S ? score[b] : -3.0e38f;
+        mx = fmaxf(mx, score[b]);
+    }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    const float ev = l32 < S ? __expf(sm - mx) : 0.f;
-    float es = ev;
+    float es = 0.f, wgt[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        wgt[b] = 32 * b + l32 < S ? __expf(score[b] - mx) : 0.f;
+        es += wgt[b];
+    }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
-    const float wgt = ev / es;
-    if (TRAIN && a.w != nullptr && tok_ok && hh == 0) a.w[tok0 + l32] = wgt;
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        wgt[b] /= es;
+        if (TRAIN && a.w != nullptr && tok_ok[b] && hh == 0) a.w[tok0 + 32 * b + l32] = wgt[b];
+    }
 
     // ---- pooling: out[f] = sum_tok w_tok ctx[tok][f].  Lane c owns the 16-byte chunk c of a ctx16 row (DP/8 chunks).
     if (valid) {
@@ -262,14 +301,14 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_fwd16_kernel
         // 16 rows per batch: all loads of a batch are in flight together (one latency per batch, not per row); rows
         // past the sequence re-read its last row with weight 0
 #pragma unroll
-        for (int t0 = 0; t0 < 32; t0 += 16) {
+        for (int t0 = 0; t0 < 32 * SB; t0 += 16) {
             if (t0 < S) {
                 h8 v[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const h8*>(base + (long)min(t0 + i, S - 1) * DP);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wgt), t0 + i));
+                    float wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wgt[t0 >> 5]), (t0 + i) & 31));
                     wt = t0 + i < S ? wt : 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc8[j] += wt * (float)v[i][j];
@@ -424,7 +463,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(unsigned d4, unsigned kp4, 
 bool fused16_supported(int S, int d, int h, int q, const char** why) {
     const int dk = d / h;
     const char* w = nullptr;
-    if (S > 32) w = "seq_len <= 32";
+    if (S > 64) w = "seq_len <= 64";
     else if (d > F16_KP - 4) w = "d_model <= 316";          // one spare column carries the bias of Q|K|V
     else if (dk > 32) w = "d_k <= 32";
     else if (32 * h > F16_DP) w = "n_heads <= 10";
@@ -498,14 +537,20 @@ int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
     a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;
     const size_t lds = (size_t)3 * F16_SLOT;
     { const char* e = getenv("NRMS_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
-    const bool train = f.t16 != nullptr;
-    const void* fn = train ? (const void*)fused_fwd16_kernel<true> : (const void*)fused_fwd16_kernel<false>;
+    const bool train = f.t16 != nullptr, two = f.S > 32;
+    const void* fn = two ? (train ? (const void*)fused_fwd16_kernel<true, 2> : (const void*)fused_fwd16_kernel<false, 2>)
+                         : (train ? (const void*)fused_fwd16_kernel<true, 1> : (const void*)fused_fwd16_kernel<false, 1>);
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("fused_fwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
-    TimingScope ts("fused_fwd16", stream);
+    TimingScope ts(two ? "fused64_fwd16" : "fused_fwd16", stream);
     const dim3 grid(cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 1 : 0));    // two lists: one more partial group
-    if (train) hipLaunchKernelGGL(fused_fwd16_kernel<true>, grid, dim3(F16_THREADS), lds, stream, a);
-    else hipLaunchKernelGGL(fused_fwd16_kernel<false>, grid, dim3(F16_THREADS), lds, stream, a);
+    if (two) {
+        if (train) hipLaunchKernelGGL((fused_fwd16_kernel<true, 2>), grid, dim3(F16_THREADS), lds, stream, a);
+        else hipLaunchKernelGGL((fused_fwd16_kernel<false, 2>), grid, dim3(F16_THREADS), lds, stream, a);
+    } else {
+        if (train) hipLaunchKernelGGL((fused_fwd16_kernel<true, 1>), grid, dim3(F16_THREADS), lds, stream, a);
+        else hipLaunchKernelGGL((fused_fwd16_kernel<false, 1>), grid, dim3(F16_THREADS), lds, stream, a);
+    }
     return check_launch("fused_fwd16");
 }
 

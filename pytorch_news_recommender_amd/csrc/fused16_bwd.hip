@@ -65,14 +65,17 @@ __device__ __forceinline__ f32x16 transpose_frags(const h8& x0, const h8& x1, co
     return mfma32h(x1, idf[1], z);
 }
 
-__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_kernel(Bwd16Args a) {
+// SB = 32-row blocks per sequence (1: titles / short histories, two workgroups per CU; 2: sequences of up to 64 rows, one
+// workgroup per CU with up to 512 registers per lane) -- see fused16.hip.
+template <int SB>
+__global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fused_bwd16_pool_kernel(Bwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 3 * F16_SLOT);         // [B16_RED] column sums of this workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
     const int S = a.S;
-    constexpr int KP = F16_KP, DP = F16_DP, QP = F16_QP;
+    constexpr int DP = F16_DP, QP = F16_QP;
 
     for (int i = tid; i < B16_RED; i += F16_THREADS) red[i] = 0.f;
 
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_k
         g_ne = (n_ne + F16_WAVES - 1) / F16_WAVES;
     }
     TileRing ring;
-    ring.smem = smem; ring.src = a.btiles; ring.n_tiles = 4 * a.h; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
+    ring.smem = smem; ring.src = a.btiles; ring.n_tiles = a.h; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
 
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
@@ -108,30 +111,33 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_k
             seq = valid ? a.order[a.n_seq + slot_id] : 0;
         }
         const long tok0 = (long)seq * S;
-        const bool tok_ok = valid && l32 < S;
         bool empty = false;
-        if (a.ids != nullptr && valid) {
+        if (SB == 1 && a.ids != nullptr && valid) {
             const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
             empty = __ballot(is_pad) == ~0ull;
         }
         const bool live = valid && !empty;
-        const bool only_add = __syncthreads_and(live ? 0 : 1) != 0;     // no live title: only the Wadd_h^T tiles are needed
-        // tile stream of a group: the h tiles Wadd_h^T (stream index 0..h-1), then per head W'_q, W_k, W_v (h + 3 head + i).
-        // btiles holds them in that order.
-        (void)only_add;
-        ring.n_tiles = a.h;
+        // tile stream of this kernel: the h tiles Wadd_h^T (the first h tiles of btiles)
         ring.load(0);                                                   // lands while the pooling backward runs
 
-        const long trow = tok0 + (tok_ok ? l32 : 0);                    // clamped token row for loads
-        const float wgt = tok_ok ? a.w[tok0 + l32] : 0.f;
+        bool tok_ok[SB];
+        long trow[SB];
+        float wgt[SB], dw[SB];
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            tok_ok[b] = valid && 32 * b + l32 < S;
+            trow[b] = tok0 + (tok_ok[b] ? 32 * b + l32 : 0);            // clamped token row for loads
+            wgt[b] = tok_ok[b] ? a.w[tok0 + 32 * b + l32] : 0.f;
+        }
 
         // ================= pooling backward =================
         // dw_tok = <dout, ctx_tok>: A = dout (the same row in every lane), B = ctx fragments; all rows of the result equal
-        float dw;
-        {
+        float aw = 0.f;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
             f32x16 acc = zero16();
             const _Float16* dsrc = a.dout16 + (long)seq * DP + 8 * hh;
-            const _Float16* csrc = a.ctx16 + trow * DP + 8 * hh;
+            const _Float16* csrc = a.ctx16 + trow[b] * DP + 8 * hh;
 #pragma unroll
             for (int g = 0; g < F16_CS / 4; ++g) {
                 h8 da[4], cb[4];
@@ -143,20 +149,21 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_k
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc = mfma32h(da[i], cb[i], acc);
             }
-            dw = acc[0];
+            dw[b] = acc[0];
+            aw += wgt[b] * dw[b];
         }
-        float aw = wgt * dw;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) aw += __shfl_xor(aw, o, 64);
-        const float ds = wgt * (dw - aw);                                // 0 for lanes beyond the sequence (wgt = 0)
 
         // dZ[tok][q] = ds q_vec[q] (1 - T^2),  U[tok][q] = ds T  (column sums of U = d(q_vec), of dZ = d(b_add)).
         // The dZ fragments stay in registers: they are the B operand of every head's d(ctx) product below.
-        h8 zf[16];
-        {
-            const _Float16* tsrc = a.t16 + trow * QP + 8 * hh;
+        h8 zf[SB][16];
 #pragma unroll
-            for (int s = 0; s < 14; ++s) zf[s] = *reinterpret_cast<const h8*>(tsrc + 16 * s);     // tanh(.) first, dZ in place
+        for (int b = 0; b < SB; ++b) {
+            const float ds = wgt[b] * (dw[b] - aw);                      // 0 for lanes beyond the sequence (wgt = 0)
+            const _Float16* tsrc = a.t16 + trow[b] * QP + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) zf[b][s] = *reinterpret_cast<const h8*>(tsrc + 16 * s);     // tanh(.) first, dZ in place
 #pragma unroll
             for (int t = 0; t < F16_QT; ++t) {
                 f32x16 accz = zero16(), accu = zero16();
@@ -167,12 +174,12 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_k
                     h8 dz, u;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float tv = (float)zf[s][j];
+                        const float tv = (float)zf[b][s][j];
                         dz[j] = (_Float16)(ds * (float)qf[j] * (1.0f - tv * tv));
                         u[j] = (_Float16)(ds * tv);
                     }
-                    zf[s] = dz;
-                    if (tok_ok) *reinterpret_cast<h8*>(a.dz16 + (tok0 + l32) * (long)QP + 16 * s + 8 * hh) = dz;
+                    zf[b][s] = dz;
+                    if (tok_ok[b]) *reinterpret_cast<h8*>(a.dz16 + (tok0 + 32 * b + l32) * (long)QP + 16 * s + 8 * hh) = dz;
                     // transposing products: D[tok][n] = X[tok][q = 32 t + n]  (rows = tokens in registers)
                     accz = mfma32h(dz, sel[s2], accz);
                     accu = mfma32h(u, sel[s2], accu);
@@ -182,46 +189,49 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_k
                     atomicAdd(red + B16_RED_QKV + QP + 32 * t + l32, regsum(accu));
                 }
             }
-            zf[14] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            zf[15] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            zf[b][14] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            zf[b][15] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
         ring.store(0);
         ring.load(1);
         ring.store(1);
         __syncthreads();
 
-        // ================= d(ctx)^T per head -> dctx16 (this wave's rows; read back head by head below) =================
+        // ================= d(ctx)^T per head -> dctx16 =================
         // d(ctx)^T[f][tok] = sum_q Wadd[q][f] dZ[tok][q] + w_tok dout[f], then the forward's dropout mask
-        _Float16* dcrow = a.dctx16 + (tok0 + l32) * (long)DP + 8 * hh;
         int n = 0;
 #pragma unroll 1
         for (int head = 0; head < a.h; ++head) {
             ring.load(n + 2);
             const h8 d0 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 8 * hh);
             const h8 d1 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 16 + 8 * hh);
-            f32x16 dct = zero16();
-            tile_mma<true>(dct, ring, n, zf);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                dct[r] += wgt * (float)d0[r];
-                dct[8 + r] += wgt * (float)d1[r];
-            }
-            if (a.drop.thresh != 0u) {
+            for (int b = 0; b < SB; ++b) {
+                f32x16 dct = zero16();
+                tile_mma<true>(dct, ring, n, zf[b]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint64_t e0 = (uint64_t)(tok0 + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
-                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
+                for (int r = 0; r < 8; ++r) {
+                    dct[r] += wgt[b] * (float)d0[r];
+                    dct[8 + r] += wgt[b] * (float)d1[r];
                 }
-            }
-            if (tok_ok) {
-                *reinterpret_cast<h8*>(dcrow + head * 32) = acc_frag(dct, 0);
-                *reinterpret_cast<h8*>(dcrow + head * 32 + 16) = acc_frag(dct, 1);
-            }
-            if (!live && valid) {
-                // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
-                atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(transpose32(dct, idf)));
+                if (a.drop.thresh != 0u) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint64_t e0 = (uint64_t)(tok0 + 32 * b + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
+                        const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
+                    }
+                }
+                if (tok_ok[b]) {
+                    _Float16* dcrow = a.dctx16 + (tok0 + 32 * b + l32) * (long)DP + 8 * hh;
+                    *reinterpret_cast<h8*>(dcrow + head * 32) = acc_frag(dct, 0);
+                    *reinterpret_cast<h8*>(dcrow + head * 32 + 16) = acc_frag(dct, 1);
+                }
+                if (!live && valid) {
+                    // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
+                    atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(transpose32(dct, idf)));
+                }
             }
             ring.store(n + 2);
             __syncthreads();
@@ -234,9 +244,9 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_pool_k
     for (int i = tid; i < B16_RED; i += F16_THREADS) out[i] = red[i];
 }
 
-
-// The attention part of the backward, on the titles with a real token only (the first g_ne groups of the order list).
-__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_kernel(Bwd16Args a) {
+// The attention part of the backward, on the sequences with a real token only (the first g_ne groups of the order list).
+template <int SB>
+__global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fused_bwd16_attn_kernel(Bwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 3 * F16_SLOT);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -257,6 +267,7 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_k
     }
     TileRing ring;
     ring.smem = smem; ring.src = a.btiles + (long)a.h * 32 * KP; ring.n_tiles = 3 * a.h; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
+    const h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     __syncthreads();
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < g_ne; grp += gridDim.x) {
@@ -264,147 +275,197 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void fused_bwd16_attn_k
         const bool valid = slot_id < n_ne;
         const int seq = valid ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0;
         const long tok0 = (long)seq * S;
-        const bool tok_ok = valid && l32 < S;
         bool empty = false;
-        if (a.ids != nullptr && valid) {
+        if (SB == 1 && a.ids != nullptr && valid) {
             const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
             empty = __ballot(is_pad) == ~0ull;
         }
         const bool live = valid && !empty;
-        const long trow = tok0 + (tok_ok ? l32 : 0);
         ring.load(0); ring.store(0);
         ring.load(1); ring.store(1);
         int n = 0;
-        const long drow = tok_ok && live ? (a.pos != nullptr ? (long)a.pos[tok0 + l32] : tok0 + l32) : -1;   // x16 / dqkv16 row
-        h8 xf[F16_KS];
-        {
+        bool tok_ok[SB];
+        long drow[SB];                                                  // x16 / dqkv16 row of this lane's token, -1: none
+        h8 xf[SB][F16_KS];
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            tok_ok[b] = valid && 32 * b + l32 < S;
+            drow[b] = tok_ok[b] && live ? (a.pos != nullptr ? (long)a.pos[tok0 + 32 * b + l32] : tok0 + 32 * b + l32) : -1;
             // a padding token inside a live title reads the pad row (zeros + the ones column => Q|K|V = bias)
-            const long xrow = (tok_ok && live && drow < 0) ? (long)*a.n_rows : drow;
+            const long xrow = (tok_ok[b] && live && drow[b] < 0) ? (long)*a.n_rows : drow[b];
             const _Float16* xr = a.x16 + (xrow < 0 ? 0 : xrow) * KP + 8 * hh;
 #pragma unroll
-            for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
+            for (int s = 0; s < F16_KS; ++s) xf[b][s] = *reinterpret_cast<const h8*>(xr + 16 * s);
             if (xrow < 0) {
 #pragma unroll
-                for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int s = 0; s < F16_KS; ++s) xf[b][s] = z8;
             }
         }
-        const _Float16* dcsrc = a.dctx16 + trow * DP + 8 * hh;
+        __syncthreads();
 #pragma unroll 1
         for (int head = 0; head < a.h; ++head) {
             // d(ctx)^T of this head as operand fragments (rows f = k); zero beyond the sequence
-            h8 dc0 = *reinterpret_cast<const h8*>(dcsrc + head * 32);
-            h8 dc1 = *reinterpret_cast<const h8*>(dcsrc + head * 32 + 16);
-            if (!tok_ok) { dc0 = h8{0, 0, 0, 0, 0, 0, 0, 0}; dc1 = dc0; }
-            // ---- tiles W'_q, W_k, W_v: Q^T, K^T, V^T [f][tok], kept as operand fragments only
-            h8 q0, q1, k0, k1, v0, v1;
+            h8 dc[SB][2];
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const _Float16* dcsrc = a.dctx16 + (tok0 + (tok_ok[b] ? 32 * b + l32 : 0)) * (long)DP + 8 * hh + head * 32;
+                dc[b][0] = *reinterpret_cast<const h8*>(dcsrc);
+                dc[b][1] = *reinterpret_cast<const h8*>(dcsrc + 16);
+                if (!tok_ok[b]) { dc[b][0] = z8; dc[b][1] = z8; }
+            }
+            // ---- tiles W'_q, W_k, W_v: Q^T, K^T, V^T [f][tok], kept as operand fragments only (bias: the ones column)
+            h8 qf[SB][2], kf[SB][2], vf[SB][2];
             ring.load(n + 2);
-            {
-                f32x16 t = zero16();                              // bias: column d of the tile x the ones column of x16
-                if (live) tile_mma<true>(t, ring, n, xf);
-                q0 = acc_frag(t, 0); q1 = acc_frag(t, 1);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                f32x16 t = zero16();
+                if (live) tile_mma<true>(t, ring, n, xf[b]);
+                qf[b][0] = acc_frag(t, 0); qf[b][1] = acc_frag(t, 1);
             }
             ring.store(n + 2);
             __syncthreads();
             ++n;
             ring.load(n + 2);
-            {
-                f32x16 t = zero16();                              // bias: column d of the tile x the ones column of x16
-                if (live) tile_mma<true>(t, ring, n, xf);
-                k0 = acc_frag(t, 0); k1 = acc_frag(t, 1);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                f32x16 t = zero16();
+                if (live) tile_mma<true>(t, ring, n, xf[b]);
+                kf[b][0] = acc_frag(t, 0); kf[b][1] = acc_frag(t, 1);
             }
             ring.store(n + 2);
             __syncthreads();
             ++n;
             ring.load(n + 2);
-            {
-                f32x16 t = zero16();                              // bias: column d of the tile x the ones column of x16
-                if (live) tile_mma<true>(t, ring, n, xf);
-                v0 = acc_frag(t, 0); v1 = acc_frag(t, 1);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                f32x16 t = zero16();
+                if (live) tile_mma<true>(t, ring, n, xf[b]);
+                vf[b][0] = acc_frag(t, 0); vf[b][1] = acc_frag(t, 1);
             }
             ring.store(n + 2);
             if (live) {
-                // ---- P^T (rows = keys, columns = queries), as in the forward
-                f32x16 pt = mfma32h(k0, q0, zero16());
-                pt = mfma32h(k1, q1, pt);
-                {
+                // ---- per query block ib: P^T[jb][ib] (rows = keys of block jb, columns = queries), dS^T[jb][ib]
+                h8 pf[SB][SB][2], sf[SB][SB][2];                         // [jb][ib] operand fragments
+#pragma unroll
+                for (int ib = 0; ib < SB; ++ib) {
+                    f32x16 pt[SB];
                     float m = -3.0e38f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        pt[r] = crow32(r, hh) < S ? pt[r] : -3.0e38f;
-                        m = fmaxf(m, pt[r]);
+                    for (int jb = 0; jb < SB; ++jb) {
+                        pt[jb] = mfma32h(kf[jb][0], qf[ib][0], zero16());
+                        pt[jb] = mfma32h(kf[jb][1], qf[ib][1], pt[jb]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            pt[jb][r] = 32 * jb + crow32(r, hh) < S ? pt[jb][r] : -3.0e38f;
+                            m = fmaxf(m, pt[jb][r]);
+                        }
                     }
                     m = fmaxf(m, __shfl_xor(m, 32, 64));
                     float sum = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float p = crow32(r, hh) < S ? __expf(pt[r] - m) : 0.f;
-                        pt[r] = p;
-                        sum += p;
-                    }
+                    for (int jb = 0; jb < SB; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float p = 32 * jb + crow32(r, hh) < S ? __expf(pt[jb][r] - m) : 0.f;
+                            pt[jb][r] = p;
+                            sum += p;
+                        }
                     sum += __shfl_xor(sum, 32, 64);
                     const float inv = 1.0f / sum;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) pt[r] *= inv;
-                }
-                // ---- dP^T[j][i] = sum_f V^T[f][j] d(ctx)^T[f][i];  dS^T = P^T o (dP^T - delta_i)
-                f32x16 dst = mfma32h(v0, dc0, zero16());
-                dst = mfma32h(v1, dc1, dst);
-                {
+                    // dP^T[j][i] = sum_f V^T[f][j] d(ctx)^T[f][i];  dS^T = P^T o (dP^T - delta_i)
+                    f32x16 dst[SB];
                     float delta = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) delta += pt[r] * dst[r];
+                    for (int jb = 0; jb < SB; ++jb) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pt[jb][r] *= inv;
+                        dst[jb] = mfma32h(vf[jb][0], dc[ib][0], zero16());
+                        dst[jb] = mfma32h(vf[jb][1], dc[ib][1], dst[jb]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) delta += pt[jb][r] * dst[jb][r];
+                    }
                     delta += __shfl_xor(delta, 32, 64);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[r] = pt[r] * (dst[r] - delta);
-                }
-                const h8 ds0 = acc_frag(dst, 0), ds1 = acc_frag(dst, 1);
-                _Float16* orow = a.dqkv16 + (drow < 0 ? 0 : drow) * (long)B16_DQ + head * 96 + 8 * hh;
-                // ---- dV^T[f][j] = sum_i d(ctx)[i][f] P[i][j]
-                {
-                    const f32x16 p = transpose32(pt, idf);                          // [i][j]
-                    const f32x16 dctx = transpose_frags(dc0, dc1, idf);             // [i][f]
-                    atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx));       // d(b_v) = sum_i d(ctx)_i (rows of P sum to 1)
-                    f32x16 dv = mfma32h(acc_frag(dctx, 0), acc_frag(p, 0), zero16());
-                    dv = mfma32h(acc_frag(dctx, 1), acc_frag(p, 1), dv);
-                    if (drow >= 0) {
-                        *reinterpret_cast<h8*>(orow + 64) = acc_frag(dv, 0);
-                        *reinterpret_cast<h8*>(orow + 64 + 16) = acc_frag(dv, 1);
+                    for (int jb = 0; jb < SB; ++jb) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dst[jb][r] = pt[jb][r] * (dst[jb][r] - delta);
+                        pf[jb][ib][0] = acc_frag(pt[jb], 0); pf[jb][ib][1] = acc_frag(pt[jb], 1);
+                        sf[jb][ib][0] = acc_frag(dst[jb], 0); sf[jb][ib][1] = acc_frag(dst[jb], 1);
                     }
                 }
-                // ---- dQ'^T[f][i] = sum_j K[j][f] dS^T[j][i]
-                {
-                    const f32x16 k = transpose_frags(k0, k1, idf);                  // [j][f]
-                    f32x16 dq = mfma32h(acc_frag(k, 0), ds0, zero16());
-                    dq = mfma32h(acc_frag(k, 1), ds1, dq);
+                // ---- d(ctx) [i][f] per query block; d(b_v) = sum_i d(ctx)_i (rows of P sum to 1)
+                h8 dx0[SB][2];
+#pragma unroll
+                for (int ib = 0; ib < SB; ++ib) {
+                    const f32x16 dctx = transpose_frags(dc[ib][0], dc[ib][1], idf);
+                    atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx));
+                    dx0[ib][0] = acc_frag(dctx, 0); dx0[ib][1] = acc_frag(dctx, 1);
+                }
+#pragma unroll
+                for (int jb = 0; jb < SB; ++jb) {
+                    _Float16* orow = a.dqkv16 + (drow[jb] < 0 ? 0 : drow[jb]) * (long)B16_DQ + head * 96 + 8 * hh;
+                    // ---- dV^T[f][j] = sum_i d(ctx)[i][f] P[i][j]   (j in block jb)
+                    {
+                        f32x16 dv = zero16();
+#pragma unroll
+                        for (int ib = 0; ib < SB; ++ib) {
+                            const f32x16 p = transpose_frags(pf[jb][ib][0], pf[jb][ib][1], idf);        // [i][j]
+                            dv = mfma32h(dx0[ib][0], acc_frag(p, 0), dv);
+                            dv = mfma32h(dx0[ib][1], acc_frag(p, 1), dv);
+                        }
+                        if (drow[jb] >= 0) {
+                            *reinterpret_cast<h8*>(orow + 64) = acc_frag(dv, 0);
+                            *reinterpret_cast<h8*>(orow + 64 + 16) = acc_frag(dv, 1);
+                        }
+                    }
+                    // ---- dK^T[f][j] = sum_i Q'[i][f] dS[i][j]   (j in block jb)
+                    {
+                        f32x16 dk = zero16();
+#pragma unroll
+                        for (int ib = 0; ib < SB; ++ib) {
+                            const f32x16 q = transpose_frags(qf[ib][0], qf[ib][1], idf);                // [i][f]
+                            const f32x16 dsn = transpose_frags(sf[jb][ib][0], sf[jb][ib][1], idf);      // [i][j]
+                            dk = mfma32h(acc_frag(q, 0), acc_frag(dsn, 0), dk);
+                            dk = mfma32h(acc_frag(q, 1), acc_frag(dsn, 1), dk);
+                        }
+                        const h8 dk0 = acc_frag(dk, 0), dk1 = acc_frag(dk, 1);
+                        if (drow[jb] >= 0) {
+                            *reinterpret_cast<h8*>(orow + 32) = dk0;
+                            *reinterpret_cast<h8*>(orow + 32 + 16) = dk1;
+                        }
+                        atomicAdd(red + (3 * head + 1) * 32 + l32, regsum(transpose_frags(dk0, dk1, idf)));
+                    }
+                }
+                // ---- dQ'^T[f][i] = sum_j K[j][f] dS^T[j][i]   (i in block ib)
+#pragma unroll
+                for (int ib = 0; ib < SB; ++ib) {
+                    f32x16 dq = zero16();
+#pragma unroll
+                    for (int jb = 0; jb < SB; ++jb) {
+                        const f32x16 k = transpose_frags(kf[jb][0], kf[jb][1], idf);                    // [j][f]
+                        dq = mfma32h(acc_frag(k, 0), sf[jb][ib][0], dq);
+                        dq = mfma32h(acc_frag(k, 1), sf[jb][ib][1], dq);
+                    }
                     const h8 dq0 = acc_frag(dq, 0), dq1 = acc_frag(dq, 1);
-                    if (drow >= 0) {
+                    if (drow[ib] >= 0) {
+                        _Float16* orow = a.dqkv16 + drow[ib] * (long)B16_DQ + head * 96 + 8 * hh;
                         *reinterpret_cast<h8*>(orow) = dq0;
                         *reinterpret_cast<h8*>(orow + 16) = dq1;
                     }
                     atomicAdd(red + (3 * head) * 32 + l32, regsum(transpose_frags(dq0, dq1, idf)));
                 }
-                // ---- dK^T[f][j] = sum_i Q'[i][f] dS[i][j]
-                {
-                    const f32x16 q = transpose_frags(q0, q1, idf);                  // [i][f]
-                    const f32x16 dsn = transpose_frags(ds0, ds1, idf);              // [i][j]
-                    f32x16 dk = mfma32h(acc_frag(q, 0), acc_frag(dsn, 0), zero16());
-                    dk = mfma32h(acc_frag(q, 1), acc_frag(dsn, 1), dk);
-                    const h8 dk0 = acc_frag(dk, 0), dk1 = acc_frag(dk, 1);
-                    if (drow >= 0) {
-                        *reinterpret_cast<h8*>(orow + 32) = dk0;
-                        *reinterpret_cast<h8*>(orow + 32 + 16) = dk1;
-                    }
-                    atomicAdd(red + (3 * head + 1) * 32 + l32, regsum(transpose_frags(dk0, dk1, idf)));
-                }
             }
             __syncthreads();
             ++n;
         }
-        if (drow >= 0) {                                          // heads the model does not have: zero columns (dX contracts over all 960)
-            for (int head = a.h; head < 10; ++head) {
-                _Float16* orow = a.dqkv16 + drow * (long)B16_DQ + head * 96 + 8 * hh;
 #pragma unroll
-                for (int c = 0; c < 96; c += 16) *reinterpret_cast<h8*>(orow + c) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < SB; ++b) {
+            if (drow[b] >= 0) {                                   // heads the model does not have: zero columns (dX contracts over all 960)
+                for (int head = a.h; head < 10; ++head) {
+                    _Float16* orow = a.dqkv16 + drow[b] * (long)B16_DQ + head * 96 + 8 * hh;
+#pragma unroll
+                    for (int c = 0; c < 96; c += 16) *reinterpret_cast<h8*>(orow + c) = z8;
+                }
             }
         }
         __syncthreads();                                          // the ring restarts: nobody may still read a slot
@@ -865,18 +926,23 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     const int n_wg = a.n_groups < L.n_wg ? a.n_groups : L.n_wg;
     {
         const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4;
-        hipError_t e = hipFuncSetAttribute((const void*)fused_bwd16_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fused_bwd16_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const bool two = f.S > 32;
+        const void* fp = two ? (const void*)fused_bwd16_pool_kernel<2> : (const void*)fused_bwd16_pool_kernel<1>;
+        const void* fa = two ? (const void*)fused_bwd16_attn_kernel<2> : (const void*)fused_bwd16_attn_kernel<1>;
+        hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("fused_bwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
         {
-            TimingScope ts("fused_bwd16_pool", stream);
-            hipLaunchKernelGGL(fused_bwd16_pool_kernel, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+            TimingScope ts(two ? "fused64_bwd16_pool" : "fused_bwd16_pool", stream);
+            if (two) hipLaunchKernelGGL(fused_bwd16_pool_kernel<2>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+            else hipLaunchKernelGGL(fused_bwd16_pool_kernel<1>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
         }
         Bwd16Args b = a;
         b.red = red + (long)n_wg * B16_RED;                       // second set of per-workgroup sums
         {
-            TimingScope ts("fused_bwd16_attn", stream);
-            hipLaunchKernelGGL(fused_bwd16_attn_kernel, dim3(n_wg), dim3(F16_THREADS), lds, stream, b);
+            TimingScope ts(two ? "fused64_bwd16_attn" : "fused_bwd16_attn", stream);
+            if (two) hipLaunchKernelGGL(fused_bwd16_attn_kernel<2>, dim3(n_wg), dim3(F16_THREADS), lds, stream, b);
+            else hipLaunchKernelGGL(fused_bwd16_attn_kernel<1>, dim3(n_wg), dim3(F16_THREADS), lds, stream, b);
         }
         int rc = check_launch("fused_bwd16");
         if (rc) return rc;

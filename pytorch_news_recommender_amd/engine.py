@@ -124,7 +124,7 @@ class NRMSEngine:
         self._bad_event = None
         self._news_cache = None
 
-    FP16_LIMITS = dict(seq_len=32, d_model=316, d_k=32, n_heads=10, q_dim=224)
+    FP16_LIMITS = dict(seq_len=64, d_model=316, d_k=32, n_heads=10, q_dim=224)
 
     def _fp16_ok(self, enc, seq_len, mask_mode, training):
         """The fused fp16 kernels cover the shapes of include/nrms_hip.h (NRMS_PRECISION_FP16); an encoder pass

@@ -128,7 +128,7 @@ def test_fp16_mode_rejects_shapes_outside_the_fused_kernels():
     import ctypes as C
     from pytorch_news_recommender_amd import _lib
     lib = _lib.load()
-    for kw in (dict(seq_len=33), dict(d_model=384, n_heads=12), dict(n_heads=5), dict(q_dim=256), dict(use_output_proj=1),
+    for kw in (dict(d_model=320), dict(d_model=384, n_heads=12), dict(n_heads=5), dict(q_dim=256), dict(use_output_proj=1),
                dict(mask_mode=1)):
         f = dict(n_seq=4, seq_len=30, d_model=300, n_heads=10, q_dim=200, vocab=0, p_drop_embed=0.0, p_drop_ctx=0.0,
                  precision=_lib.NRMS_PRECISION_FP16, use_output_proj=0, mask_mode=0, flags=0, seed=0)

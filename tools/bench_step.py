@@ -30,7 +30,7 @@ for prec in MODES:
         model.train_step(tb)
     torch.cuda.synchronize()
     rows = []
-    for name in ("fused_fwd16", "fused_bwd16_pool", "fused_bwd16_attn", "dwqkv_bwd", "dwadd_bwd", "dx_bwd", "tn_reduce", "red16", "prep16", "gather_dropout",
+    for name in ("fused64_fwd16", "fused64_bwd16_pool", "fused64_bwd16_attn", "fused_fwd16", "fused_bwd16_pool", "fused_bwd16_attn", "dwqkv_bwd", "dwadd_bwd", "dx_bwd", "tn_reduce", "red16", "prep16", "gather_dropout",
                  "scatter_dropout", "compact_rows", "title_order", "sanitize_ids", "cast16", "adam", "qkv_proj_fwd", "attn_fwd",
                  "attn_bwd", "addattn_fwd", "addattn_bwd_rows", "dctx_bwd", "fill_pad_rows", "click", "ce_loss", "split_planes",
                  "transpose", "permute_rows", "colsum", "padsum"):
