@@ -133,7 +133,8 @@ typedef struct nrms_encoder_acts {
                               token compaction lists */
     /* NRMS_PRECISION_FP16: x, ctx, t hold fp16 with the FIXED pitches KP = 320, DP = 320, QP = 224
      * (NRMS_FP16_KP / _DP / _QP):  x [M + 1, KP] (required for both encoders: gathered embeddings / the cast input),
-     * ctx [M, DP] (head-padded, internal order), t [M, QP]; w [M] fp32; qkv and attn are unused (may be NULL). */
+     * ctx [Mp, DP] and t [Mp, QP] with Mp = n_seq * (seq_len <= 32 ? 32 : 64) rows (every sequence padded to whole
+     * 32-row blocks, internal fragment order); w [M] fp32; qkv and attn are unused (may be NULL). */
 } nrms_encoder_acts;
 
 /* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V

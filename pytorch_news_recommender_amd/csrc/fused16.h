@@ -42,6 +42,15 @@ static_assert(F16_KP == F16_DP, "one tile geometry for the head tiles and the ad
 constexpr int F16_STG = (32 * F16_RC + F16_THREADS - 1) / F16_THREADS;      // staging chunks (16 B) per thread and tile
 constexpr bool F16_STG_EXACT = 32 * F16_RC == F16_STG * F16_THREADS;
 
+// ---- "fragment order" of the per-token activations the fused kernels exchange through HBM (ctx16, d(ctx)16, T16, dZ16):
+//      [sequence][32-row block][k-step of 16 columns][token 0..31][16 columns]   (fp16)
+// A lane (token l32, half hh) touches 16 B per k-step, and the 64 lanes of a wave-instruction touch ONE contiguous KiB
+// (token-major rows gave 32 separate 32-byte pieces per instruction).  Rows of tokens beyond the sequence exist and
+// hold zeros, so the weight-gradient GEMM can stage a block as 32 contiguous rows.
+__device__ __forceinline__ long frag_off(long seq_block, int c16, int s, int l32, int hh) {
+    return (seq_block * c16 + s) * 512 + l32 * 16 + 8 * hh;
+}
+
 // ---- the weight-tile ring shared by the forward and the backward kernel: tile n lives in LDS slot n % 3; while
 // tile n is consumed, tile n + 2 travels global -> registers -> LDS.  One barrier per tile.
 struct TileRing {

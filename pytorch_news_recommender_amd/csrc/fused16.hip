@@ -130,14 +130,14 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
             for (int b = 0; b < SB; ++b) { qt[b] = zero16(); if (live) tile_mma<true>(qt[b], ring, n, xf[b]); }
             ring.store(n + 2);
-            __syncthreads();
+            if (!(a.dbg & 2)) __syncthreads();
             ++n;
             // ---- tile K
             ring.load(n + 2);
 #pragma unroll
             for (int b = 0; b < SB; ++b) { kt[b] = zero16(); if (live) tile_mma<true>(kt[b], ring, n, xf[b]); }
             ring.store(n + 2);
-            __syncthreads();
+            if (!(a.dbg & 2)) __syncthreads();
             ++n;
             // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k]
             ring.load(n + 2);
@@ -199,24 +199,25 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                     for (int e = 0; e < 4; ++e) ct[b][4 * g + e] *= sc[e];
                 }
             }
-            if (tok_ok[b]) {
-                _Float16* dst = a.ctx16 + (tok0 + 32 * b + l32) * (long)DP + head * 32 + 8 * hh;
-                *reinterpret_cast<h8*>(dst) = acc_frag(ct[b], 0);
-                *reinterpret_cast<h8*>(dst + 16) = acc_frag(ct[b], 1);
+            if (valid) {                                        // rows beyond the sequence are stored too: zeros
+                const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                _Float16* dst = a.ctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
+                *reinterpret_cast<h8*>(dst) = tok_ok[b] ? acc_frag(ct[b], 0) : z;
+                *reinterpret_cast<h8*>(dst + 512) = tok_ok[b] ? acc_frag(ct[b], 1) : z;
             }
         }
         if (!skip_heads) {
-            __syncthreads();
+            if (!(a.dbg & 2)) __syncthreads();
             ++n;
         }
     }
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
-        if (tok_ok[b]) {                                           // heads the model does not have: zero columns
+        if (valid) {                                               // heads the model does not have: zero columns
             for (int head = a.h; head < F16_CS / 2; ++head) {
-                _Float16* dst = a.ctx16 + (tok0 + 32 * b + l32) * (long)DP + head * 32 + 8 * hh;
+                _Float16* dst = a.ctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
                 *reinterpret_cast<h8*>(dst) = h8{0, 0, 0, 0, 0, 0, 0, 0};
-                *reinterpret_cast<h8*>(dst + 16) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<h8*>(dst + 512) = h8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
     }
@@ -227,13 +228,9 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     h8 cf[SB][F16_CS];
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
-        const _Float16* src = a.ctx16 + (tok0 + (tok_ok[b] ? 32 * b + l32 : 0)) * (long)DP + 8 * hh;
+        const _Float16* src = a.ctx16 + frag_off((long)seq * SB + b, F16_CS, 0, l32, hh);      // (zeros beyond the sequence)
 #pragma unroll
-        for (int s = 0; s < F16_CS; ++s) cf[b][s] = *reinterpret_cast<const h8*>(src + 16 * s);
-        if (!tok_ok[b]) {
-#pragma unroll
-            for (int s = 0; s < F16_CS; ++s) cf[b][s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        for (int s = 0; s < F16_CS; ++s) cf[b][s] = *reinterpret_cast<const h8*>(src + 512 * s);
     }
     float score[SB];                                              // sum_q q_vec[q] tanh(.)[q][tok], per token = per lane
 #pragma unroll
@@ -259,12 +256,15 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                     score[b] += qq[4 * g + e] * v;
                     th[e] = (_Float16)v;
                 }
-                if (TRAIN && tok_ok[b])
-                    *reinterpret_cast<h4*>(a.t16 + (tok0 + 32 * b + l32) * (long)QP + 32 * t + 8 * g + 4 * hh) = th;
+                if (TRAIN && valid) {
+                    if (!tok_ok[b]) th = h4{0, 0, 0, 0};
+                    *reinterpret_cast<h4*>(a.t16 + ((((long)seq * SB + b) * (F16_QP / 16) + 2 * t + (g >> 1)) * 32 + l32) * 16 +
+                                           8 * (g & 1) + 4 * hh) = th;
+                }
             }
         }
         ring.store(n + 2);
-        __syncthreads();
+        if (!(a.dbg & 2)) __syncthreads();
         ++n;
     }
     // softmax over the tokens of the sequence (lane l32 of block b holds token 32 b + l32, in either half)
@@ -291,38 +291,36 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         if (TRAIN && a.w != nullptr && tok_ok[b] && hh == 0) a.w[tok0 + 32 * b + l32] = wgt[b];
     }
 
-    // ---- pooling: out[f] = sum_tok w_tok ctx[tok][f].  Lane c owns the 16-byte chunk c of a ctx16 row (DP/8 chunks).
+    // ---- pooling: out[f] = sum_tok w_tok ctx[tok][f], from the ctx fragments already in registers.  A product with a
+    // column selector moves the tokens from the lanes into the accumulator's rows (D[tok][n] = ctx[tok][32 p + n]),
+    // where the weighted sum over tokens is a sum over registers (+ one lane-half exchange) in fp32.
     if (valid) {
-        constexpr int n_chunks = DP >> 3;
-        float acc8[8];
+        h8 sel[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
-        const _Float16* base = a.ctx16 + tok0 * (long)DP + (lane < n_chunks ? lane : 0) * 8;
-        // 16 rows per batch: all loads of a batch are in flight together (one latency per batch, not per row); rows
-        // past the sequence re-read its last row with weight 0
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int t0 = 0; t0 < 32 * SB; t0 += 16) {
-            if (t0 < S) {
-                h8 v[16];
+            for (int j = 0; j < 8; ++j) sel[s2][j] = (_Float16)(l32 == 16 * s2 + 8 * hh + j ? 1.0f : 0.0f);
+        float wrow[SB][16];                                      // w of the token held in register r of this lane half
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const h8*>(base + (long)min(t0 + i, S - 1) * DP);
+        for (int b = 0; b < SB; ++b)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wgt[t0 >> 5]), (t0 + i) & 31));
-                    wt = t0 + i < S ? wt : 0.f;
+            for (int r = 0; r < 16; ++r) wrow[b][r] = __shfl(wgt[b], crow32(r, hh), 64);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc8[j] += wt * (float)v[i][j];
-                }
+        for (int p = 0; p < F16_CS / 2; ++p) {                   // 32 padded features = one head per step (unrolled: cf is indexed)
+            float acc = 0.f;
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                // cf element j of half hh is padded feature 16 s + 8 (j>>2) + 4 hh + (j&3) (P16 order): as the A operand its k
+                // index 8 hh + j is routed by the selector to column n = 16 s2 + 8 hh + j, i.e. D[tok][n] = ctx[tok][position n]
+                f32x16 dd = mfma32h(cf[b][2 * p], sel[0], zero16());
+                dd = mfma32h(cf[b][2 * p + 1], sel[1], dd);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc += wrow[b][r] * dd[r];
             }
-        }
-        if (lane < n_chunks) {
-            const int b16 = lane >> 1, ch = lane & 1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int fpad = 16 * b16 + 8 * (j >> 2) + 4 * ch + (j & 3);
-                const int head = fpad >> 5, f = fpad & 31;
-                if (f < a.dk && head < a.h) a.out[(long)seq * a.d + head * a.dk + f] = acc8[j];
-            }
+            acc += __shfl_xor(acc, 32, 64);
+            // column n = l32 holds P16 position n of head p: padded feature 16 (n>>4) + 8 ((n&7)>>2) + 4 ((n>>3)&1) + (n&3)
+            const int n = l32, f = 16 * (n >> 4) + 8 * ((n & 7) >> 2) + 4 * ((n >> 3) & 1) + (n & 3);
+            if (hh == 0 && f < a.dk && p < a.h) a.out[(long)seq * a.d + p * a.dk + f] = acc;
         }
     }
 }

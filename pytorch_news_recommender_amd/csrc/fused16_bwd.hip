@@ -43,6 +43,7 @@ struct Bwd16Args {
     _Float16* dqkv16;           // [rows][B16_DQ]
     float* red;                 // [gridDim.x][B16_RED] per-workgroup column sums (reduced afterwards, fixed order)
     Dropout drop;
+    int dbg;                    // timing experiments only (NRMS_F16_DBG): 4 = no dZ16 / d(ctx)16 stores, 8 = no d(ctx) products
 };
 
 // X^T for a 32x32 accumulator X: one product with the k-permuted identity (idf[s][j] = (n == row held as element j))
@@ -121,12 +122,10 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         ring.load(0);                                                   // lands while the pooling backward runs
 
         bool tok_ok[SB];
-        long trow[SB];
         float wgt[SB], dw[SB];
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
             tok_ok[b] = valid && 32 * b + l32 < S;
-            trow[b] = tok0 + (tok_ok[b] ? 32 * b + l32 : 0);            // clamped token row for loads
             wgt[b] = tok_ok[b] ? a.w[tok0 + 32 * b + l32] : 0.f;
         }
 
@@ -137,14 +136,14 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         for (int b = 0; b < SB; ++b) {
             f32x16 acc = zero16();
             const _Float16* dsrc = a.dout16 + (long)seq * DP + 8 * hh;
-            const _Float16* csrc = a.ctx16 + trow[b] * DP + 8 * hh;
+            const _Float16* csrc = a.ctx16 + frag_off((long)seq * SB + b, F16_CS, 0, l32, hh);
 #pragma unroll
             for (int g = 0; g < F16_CS / 4; ++g) {
                 h8 da[4], cb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     da[i] = *reinterpret_cast<const h8*>(dsrc + 16 * (4 * g + i));
-                    cb[i] = *reinterpret_cast<const h8*>(csrc + 16 * (4 * g + i));
+                    cb[i] = *reinterpret_cast<const h8*>(csrc + 512 * (4 * g + i));
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc = mfma32h(da[i], cb[i], acc);
@@ -161,9 +160,9 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
             const float ds = wgt[b] * (dw[b] - aw);                      // 0 for lanes beyond the sequence (wgt = 0)
-            const _Float16* tsrc = a.t16 + trow[b] * QP + 8 * hh;
+            const _Float16* tsrc = a.t16 + frag_off((long)seq * SB + b, QP / 16, 0, l32, hh);
 #pragma unroll
-            for (int s = 0; s < 14; ++s) zf[b][s] = *reinterpret_cast<const h8*>(tsrc + 16 * s);     // tanh(.) first, dZ in place
+            for (int s = 0; s < 14; ++s) zf[b][s] = *reinterpret_cast<const h8*>(tsrc + 512 * s);    // tanh(.) first, dZ in place
 #pragma unroll
             for (int t = 0; t < F16_QT; ++t) {
                 f32x16 accz = zero16(), accu = zero16();
@@ -179,7 +178,8 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                         u[j] = (_Float16)(ds * tv);
                     }
                     zf[b][s] = dz;
-                    if (tok_ok[b]) *reinterpret_cast<h8*>(a.dz16 + (tok0 + 32 * b + l32) * (long)QP + 16 * s + 8 * hh) = dz;
+                    // (zero beyond the sequence: ds = 0 there)
+                    if (valid && !(a.dbg & 4)) *reinterpret_cast<h8*>(a.dz16 + frag_off((long)seq * SB + b, QP / 16, s, l32, hh)) = dz;
                     // transposing products: D[tok][n] = X[tok][q = 32 t + n]  (rows = tokens in registers)
                     accz = mfma32h(dz, sel[s2], accz);
                     accu = mfma32h(u, sel[s2], accu);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 f32x16 dct = zero16();
-                tile_mma<true>(dct, ring, n, zf[b]);
+                if (!(a.dbg & 8)) tile_mma<true>(dct, ring, n, zf[b]);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     dct[r] += wgt[b] * (float)d0[r];
@@ -223,10 +223,10 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                         for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
                     }
                 }
-                if (tok_ok[b]) {
-                    _Float16* dcrow = a.dctx16 + (tok0 + 32 * b + l32) * (long)DP + 8 * hh;
-                    *reinterpret_cast<h8*>(dcrow + head * 32) = acc_frag(dct, 0);
-                    *reinterpret_cast<h8*>(dcrow + head * 32 + 16) = acc_frag(dct, 1);
+                if (valid && !(a.dbg & 4)) {                    // (zero beyond the sequence: dZ and w are 0 there)
+                    _Float16* dcrow = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
+                    *reinterpret_cast<h8*>(dcrow) = acc_frag(dct, 0);
+                    *reinterpret_cast<h8*>(dcrow + 512) = acc_frag(dct, 1);
                 }
                 if (!live && valid) {
                     // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
@@ -308,10 +308,9 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             h8 dc[SB][2];
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
-                const _Float16* dcsrc = a.dctx16 + (tok0 + (tok_ok[b] ? 32 * b + l32 : 0)) * (long)DP + 8 * hh + head * 32;
-                dc[b][0] = *reinterpret_cast<const h8*>(dcsrc);
-                dc[b][1] = *reinterpret_cast<const h8*>(dcsrc + 16);
-                if (!tok_ok[b]) { dc[b][0] = z8; dc[b][1] = z8; }
+                const _Float16* dcsrc = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
+                dc[b][0] = *reinterpret_cast<const h8*>(dcsrc);             // (zeros beyond the sequence)
+                dc[b][1] = *reinterpret_cast<const h8*>(dcsrc + 512);
             }
             // ---- tiles W'_q, W_k, W_v: Q^T, K^T, V^T [f][tok], kept as operand fragments only (bias: the ones column)
             h8 qf[SB][2], kf[SB][2], vf[SB][2];
@@ -655,6 +654,9 @@ __device__ __forceinline__ h8 tr16_frag(const char* plane, int pitch_b, int col0
     return __builtin_bit_cast(h8, r);
 }
 
+// FL: both operands are in the fragment order of fused16.h ([block of 32 rows][k-step][row][16]): a stage (32 rows) is ONE
+// contiguous block per operand; otherwise plain row-major [M][ld].
+template <bool FL>
 __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -678,28 +680,39 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
     // stages ahead in two statically named register sets (the loop is unrolled by two; a run-time set index would go
     // through movrel), and the stage body is branch-free (clamped loads past the end, zeroed at the LDS write).
     struct Regs { h8 a[T16_A_IT], b[T16_B_IT]; };
+    // slot -> (row r, column c) of the staged block.  Row-major source: a row's chunks are consecutive; fragment order:
+    // consecutive slots walk (k-step, row, half) so that consecutive lanes read consecutive 16-byte pieces
+    auto slot_rc = [&](int sl, int width, int& r, int& c) {
+        if (FL) { r = (sl >> 1) & 31; c = (sl >> 6) * 16 + (sl & 1) * 8; if (c >= width) r = T16_MC; }
+        else { r = sl / (width / 8); c = (sl % (width / 8)) * 8; }
+    };
     auto load_stage = [&](Regs& R, int m0) {
+        const long blk = min(m0, max(m_end - 1, 0)) >> 5;             // fragment order: the 32-row block of this stage
 #pragma unroll
         for (int i = 0; i < T16_A_IT; ++i) {
-            const int sl = tid + T16_THREADS * i;
-            const int r = min(sl / (T16_AW / 8), T16_MC - 1), c = (sl % (T16_AW / 8)) * 8;
-            const long m = min(m0 + r, max(m_end - 1, 0));
-            R.a[i] = *reinterpret_cast<const h8*>(a.A + m * a.lda + min(ncol0 + c, a.N - 8));
+            int r, c;
+            slot_rc(tid + T16_THREADS * i, T16_AW, r, c);
+            r = min(r, T16_MC - 1);
+            const int cc = min(ncol0 + c, a.N - 8);
+            if (FL) R.a[i] = *reinterpret_cast<const h8*>(a.A + (blk * (a.lda >> 4) + (cc >> 4)) * 512 + r * 16 + (cc & 8));
+            else R.a[i] = *reinterpret_cast<const h8*>(a.A + (long)min(m0 + r, max(m_end - 1, 0)) * a.lda + cc);
         }
 #pragma unroll
         for (int i = 0; i < T16_B_IT; ++i) {
-            const int sl = tid + T16_THREADS * i;
-            const int r = min(sl / (T16_BW / 8), T16_MC - 1), c = (sl % (T16_BW / 8)) * 8;
-            const long m = min(m0 + r, max(m_end - 1, 0));
-            R.b[i] = *reinterpret_cast<const h8*>(a.B + m * a.ldb + min(kcol0 + c, a.K - 8));
+            int r, c;
+            slot_rc(tid + T16_THREADS * i, T16_BW, r, c);
+            r = min(r, T16_MC - 1);
+            const int cc = min(kcol0 + c, a.K - 8);
+            if (FL) R.b[i] = *reinterpret_cast<const h8*>(a.B + (blk * (a.ldb >> 4) + (cc >> 4)) * 512 + r * 16 + (cc & 8));
+            else R.b[i] = *reinterpret_cast<const h8*>(a.B + (long)min(m0 + r, max(m_end - 1, 0)) * a.ldb + cc);
         }
     };
     const h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     auto store_stage = [&](const Regs& R, int m0, char* st) {
 #pragma unroll
         for (int i = 0; i < T16_A_IT; ++i) {
-            const int sl = tid + T16_THREADS * i;
-            const int r = sl / (T16_AW / 8), c = (sl % (T16_AW / 8)) * 8;
+            int r, c;
+            slot_rc(tid + T16_THREADS * i, T16_AW, r, c);
             if (r < T16_MC) {
                 const bool ok = m0 + r < m_end && ncol0 + c < a.N;
                 *reinterpret_cast<h8*>(st + (r * T16_PA + c) * 2) = ok ? R.a[i] : z8;
@@ -707,8 +720,8 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
         }
 #pragma unroll
         for (int i = 0; i < T16_B_IT; ++i) {
-            const int sl = tid + T16_THREADS * i;
-            const int r = sl / (T16_BW / 8), c = (sl % (T16_BW / 8)) * 8;
+            int r, c;
+            slot_rc(tid + T16_THREADS * i, T16_BW, r, c);
             if (r < T16_MC) {
                 const bool ok = m0 + r < m_end && kcol0 + c < a.K;
                 *reinterpret_cast<h8*>(st + T16_A_BYTES + (r * T16_PB + c) * 2) = ok ? R.b[i] : z8;
@@ -837,6 +850,7 @@ static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
 Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     Fused16BwdLayout L;
+    const long Mp = (long)n_seq * (M > (long)n_seq * 32 ? 64 : 32);      // fragment order: 32 (or 64) rows per sequence
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
     L.n_wg = 512;
@@ -845,8 +859,8 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     L.qv16 = take((size_t)F16_QP * 2);
     L.bqkv32 = take((size_t)30 * 32 * 4);
     L.dout16 = take((size_t)n_seq * F16_DP * 2);
-    L.dz16 = take((size_t)M * F16_QP * 2);
-    L.dctx16 = take((size_t)M * F16_DP * 2);
+    L.dz16 = take((size_t)Mp * F16_QP * 2);
+    L.dctx16 = take((size_t)Mp * F16_DP * 2);
     L.dqkv16 = take((size_t)(M + 32) * B16_DQ * 2);
     L.red = take((size_t)2 * L.n_wg * B16_RED * 4);      // pool kernel + attention kernel
     L.maps = take((size_t)(B16_DQ * 2 + F16_KP + F16_QP * 2 + F16_DP) * 4);
@@ -859,18 +873,20 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     return L;
 }
 
-static int launch_tn16(const _Float16* A, int lda, int N, const _Float16* B, int ldb, int K, int M, const int* m_dev,
+static int launch_tn16(bool frag_layout, const _Float16* A, int lda, int N, const _Float16* B, int ldb, int K, int M, const int* m_dev,
                        float* partial, int splits, const int* nmap, const int* kmap, const float* nscale, int ldw, float* dW,
                        hipStream_t stream, const char* name) {
     Tn16Args t{};
     t.M = M; t.m_dev = m_dev; t.A = A; t.lda = lda; t.N = N; t.B = B; t.ldb = ldb; t.K = K; t.partial = partial;
     t.splits = splits; t.n_blk = cdiv(N, T16_AW); t.k_blk = cdiv(K, T16_BW);
     const size_t lds = 2 * (size_t)T16_STAGE;
-    const hipError_t e = hipFuncSetAttribute((const void*)gemm16_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* fn = frag_layout ? (const void*)gemm16_tn_kernel<true> : (const void*)gemm16_tn_kernel<false>;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
     {
         TimingScope ts(name, stream);
-        hipLaunchKernelGGL(gemm16_tn_kernel, dim3(splits * t.n_blk * t.k_blk), dim3(T16_THREADS), lds, stream, t);
+        if (frag_layout) hipLaunchKernelGGL(gemm16_tn_kernel<true>, dim3(splits * t.n_blk * t.k_blk), dim3(T16_THREADS), lds, stream, t);
+        else hipLaunchKernelGGL(gemm16_tn_kernel<false>, dim3(splits * t.n_blk * t.k_blk), dim3(T16_THREADS), lds, stream, t);
     }
     int rc = check_launch(name);
     if (rc) return rc;
@@ -923,6 +939,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     a.btiles = btiles; a.bqkv32 = bqkv32; a.qv16 = qv16;
     a.ctx16 = (const _Float16*)f.ctx16; a.t16 = (const _Float16*)f.t16; a.w = f.w; a.dout16 = dout16;
     a.dz16 = dz16; a.dctx16 = dctx16; a.dqkv16 = dqkv16; a.red = red; a.drop = f.drop;
+    { const char* e = getenv("NRMS_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
     const int n_wg = a.n_groups < L.n_wg ? a.n_groups : L.n_wg;
     {
         const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4;
@@ -955,11 +972,13 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         if (rc) return rc;
     }
     // d(W_add)[q][f] = sum_tok dZ[tok][q] ctx[tok][f]
-    int rc = launch_tn16(dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, (int)M, nullptr, partial, L.tn_splits_add,
+    // (fragment order: 32 rows per block, rows beyond a sequence are zero)
+    const int Mp = f.n_seq * 32 * (f.S > 32 ? 2 : 1);
+    int rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial, L.tn_splits_add,
                          nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, stream, "dwadd_bwd");
     if (rc) return rc;
     // d(W_qkv)[n][k] = sum_rows dQKV[r][n] x[r][k]   (live rows only)
-    rc = launch_tn16(dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial, L.tn_splits_qkv,
+    rc = launch_tn16(false, dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial, L.tn_splits_qkv,
                      nmap_qkv, kmap_x, nscale_qkv, f.d, f.dw_qkv, stream, "dwqkv_bwd");
     if (rc) return rc;
     // dX = dQKV W'  -> fp32 rows

@@ -186,8 +186,9 @@ class NRMSEngine:
             KP, DP, QP = _lib.NRMS_FP16_KP, _lib.NRMS_FP16_DP, _lib.NRMS_FP16_QP
             h = torch.float16
             x = self._buf(tag + ".x16", (M + 1) * KP, h)          # + the padding token's row
-            ctx = self._buf(tag + ".ctx16", M * DP, h)
-            t = self._buf(tag + ".t16", M * QP, h) if need_bwd else None
+            Mp = desc.n_seq * (32 if desc.seq_len <= 32 else 64)      # whole 32-row blocks per sequence
+            ctx = self._buf(tag + ".ctx16", Mp * DP, h)
+            t = self._buf(tag + ".t16", Mp * QP, h) if need_bwd else None
             w = self._buf(tag + ".w", M) if need_bwd else None
             nbytes = int(self.lib.nrms_encoder_fwd_scratch_bytes(C.byref(desc)))
             scratch = self._buf("fwd_scratch16", (nbytes + 3) // 4)

@@ -31,8 +31,11 @@ def run(shape, seed=1, pad_zero=True, S_user=False):
     torch.cuda.synchronize()
     KP, DP, QP = 320, 320, 224
     M = N * L
-    ctx16 = eng._bufs["dbg.ctx16"][:M * DP].view(M, DP).float().cpu().numpy()
-    t16 = eng._bufs["dbg.t16"][:M * QP].view(M, QP).float().cpu().numpy()
+    # fragment order [title][k-step][token 0..31][16] -> token-major rows of the real tokens
+    ctx16 = eng._bufs["dbg.ctx16"][:N * 32 * DP].view(N, DP // 16, 32, 16).permute(0, 2, 1, 3).reshape(N, 32, DP)[:, :L]
+    ctx16 = ctx16.reshape(M, DP).float().cpu().numpy()
+    t16 = eng._bufs["dbg.t16"][:N * 32 * QP].view(N, QP // 16, 32, 16).permute(0, 2, 1, 3).reshape(N, 32, QP)[:, :L]
+    t16 = t16.reshape(M, QP).float().cpu().numpy()
     w = eng._bufs["dbg.w"][:M].cpu().numpy()
     # torch restatement
     p = {k: torch.from_numpy(v) for k, v in params.items()}
