@@ -848,6 +848,28 @@ __global__ void maps16_kernel(int d, int h, int dk, int q, float inv_scale, floa
 // ---------------------------------------------------------------------------------------------------------------
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
+// Two helper streams (created once per process) so that the two weight-gradient GEMMs -- HBM-bound, independent of
+// everything after them -- run beside the issue-bound attention kernel and the dX GEMM instead of behind them.  Forked
+// from and joined back into the caller's stream with events inside the same C-ABI call: to the caller the call is still
+// one in-order piece of work on its stream.
+struct SideStreams {
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t fork[2] = {nullptr, nullptr}, join[2] = {nullptr, nullptr};
+    bool ok = false, tried = false;
+    void init() {
+        if (tried) return;
+        tried = true;
+        if (getenv("NRMS_NO_SIDE_STREAMS") != nullptr) return;
+        for (int i = 0; i < 2; ++i) {
+            if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return;
+        }
+        ok = true;
+    }
+};
+static SideStreams g_side;
+
 Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     Fused16BwdLayout L;
     const long Mp = (long)n_seq * (M > (long)n_seq * 32 ? 64 : 32);      // fragment order: 32 (or 64) rows per sequence
@@ -868,7 +890,7 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     L.tn_splits_qkv = 44;      // x 6 output blocks of 320 x 160 = 264 workgroups (a multiple of 8: XCD mapping)
     L.tn_splits_add = 128;     // x 2 = 256
     const size_t p1 = (size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4, p2 = (size_t)L.tn_splits_add * F16_QP * F16_DP * 4;
-    L.partial = take(p1 > p2 ? p1 : p2);
+    L.partial = take(up256(p1) + p2);                    // both products have their own slabs: they run concurrently
     L.total = off;
     return L;
 }
@@ -918,7 +940,12 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     int* nmap_add = kmap_x + F16_KP;
     float* nscale_add = (float*)(nmap_add + F16_QP);
     int* kmap_ctx = (int*)(nscale_add + F16_QP);
-    float* partial = (float*)(base + L.partial);
+    float* partial_qkv = (float*)(base + L.partial);
+    float* partial_add = (float*)(base + L.partial + up256((size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4));
+    g_side.init();
+    const bool side = g_side.ok;
+    hipStream_t s_add = side ? g_side.s[0] : stream, s_qkv = side ? g_side.s[1] : stream;
+    const int Mp = f.n_seq * 32 * (f.S > 32 ? 2 : 1);         // fragment order: 32 rows per block, zero beyond a sequence
     {
         Prep16bArgs p{};
         p.d = f.d; p.h = f.h; p.dk = dk; p.q = f.q; p.w_qkv = f.w_qkv; p.b_qkv = f.b_qkv; p.w_add = f.w_add; p.q_vec = f.q_vec;
@@ -954,6 +981,15 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
             if (two) hipLaunchKernelGGL(fused_bwd16_pool_kernel<2>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
             else hipLaunchKernelGGL(fused_bwd16_pool_kernel<1>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
         }
+        if (side) {
+            // d(W_add)[q][f] = sum_tok dZ[tok][q] ctx[tok][f] needs only the pooling kernel's dZ16: beside the attention kernel
+            (void)hipEventRecord(g_side.fork[0], stream);
+            (void)hipStreamWaitEvent(s_add, g_side.fork[0], 0);
+            int rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
+                                 L.tn_splits_add, nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, s_add, "dwadd_bwd");
+            if (rc) return rc;
+            (void)hipEventRecord(g_side.join[0], s_add);
+        }
         Bwd16Args b = a;
         b.red = red + (long)n_wg * B16_RED;                       // second set of per-workgroup sums
         {
@@ -971,16 +1007,21 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         int rc = check_launch("red16");
         if (rc) return rc;
     }
-    // d(W_add)[q][f] = sum_tok dZ[tok][q] ctx[tok][f]
-    // (fragment order: 32 rows per block, rows beyond a sequence are zero)
-    const int Mp = f.n_seq * 32 * (f.S > 32 ? 2 : 1);
-    int rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial, L.tn_splits_add,
-                         nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, stream, "dwadd_bwd");
+    int rc = NRMS_OK;
+    if (!side) {
+        rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
+                         L.tn_splits_add, nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, stream, "dwadd_bwd");
+        if (rc) return rc;
+    }
+    // d(W_qkv)[n][k] = sum_rows dQKV[r][n] x[r][k]   (live rows only): beside the dX GEMM
+    if (side) {
+        (void)hipEventRecord(g_side.fork[1], stream);
+        (void)hipStreamWaitEvent(s_qkv, g_side.fork[1], 0);
+    }
+    rc = launch_tn16(false, dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial_qkv,
+                     L.tn_splits_qkv, nmap_qkv, kmap_x, nscale_qkv, f.d, f.dw_qkv, s_qkv, "dwqkv_bwd");
     if (rc) return rc;
-    // d(W_qkv)[n][k] = sum_rows dQKV[r][n] x[r][k]   (live rows only)
-    rc = launch_tn16(false, dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial, L.tn_splits_qkv,
-                     nmap_qkv, kmap_x, nscale_qkv, f.d, f.dw_qkv, stream, "dwqkv_bwd");
-    if (rc) return rc;
+    if (side) (void)hipEventRecord(g_side.join[1], s_qkv);
     // dX = dQKV W'  -> fp32 rows
     {
         Dx16Args g{};
@@ -992,6 +1033,10 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         TimingScope ts("dx_bwd", stream);
         hipLaunchKernelGGL(gemm16_dx_kernel, dim3(cdiv(M, 32 * F16_WAVES)), dim3(F16_THREADS), lds, stream, g);
         rc = check_launch("gemm16_dx");
+    }
+    if (side) {                                                     // join: the caller's stream continues after both GEMMs
+        (void)hipStreamWaitEvent(stream, g_side.join[0], 0);
+        (void)hipStreamWaitEvent(stream, g_side.join[1], 0);
     }
     return rc;
 }
