@@ -152,28 +152,30 @@ def timed(fn, n, sync=True):
 
 
 def eval_path_leg(model, dev):
-    """SURVEY f-1: evaluation impressions padded to max_candidate_size = 300 (data_handler.py:174-177), 4 batches of 128
-    impressions drawn from a 4000-news corpus: every slot encoded (as the reference does), distinct titles per batch
-    (device hash), and the persistent news-vector cache keyed by the batch dict's news ids."""
+    """SURVEY f-1: evaluation impressions padded to max_candidate_size = 300 (data_handler.py:174-177), 4 batches of 512
+    impressions (the reference's dev loader uses config.batch_size = 512, run_v0.py:46,81-82) drawn from a 4000-news
+    corpus: every slot encoded (as the reference does), distinct titles per batch (device hash table), and the
+    persistent news-vector cache keyed by the batch dict's news ids."""
     from torch.utils.data import DataLoader
     from pytorch_news_recommender_amd.data_handler import MyDataset, SyntheticMind
     cfg = model.config
     cfg.max_candidate_size, cfg.history_len = 300, 50
     corpus = SyntheticMind(cfg, n_news=4000, seed=3)
-    samples, _ = corpus.eval_samples(512, max_shown=70)
+    n_imp, per_batch = 2048, 512
+    samples, _ = corpus.eval_samples(n_imp, max_shown=70)
     ds = MyDataset(cfg, samples, type=1, id2title_dict=corpus.id2title_dict)
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
-               for b in DataLoader(ds, batch_size=128, shuffle=False, num_workers=0)]
+               for b in DataLoader(ds, batch_size=per_batch, shuffle=False, num_workers=0)]
     model.eval()
     eng = model.engine
-    ev = {}
+    ev = {"impressions": n_imp, "batch": per_batch, "slots_per_impression": 350}
     with torch.no_grad():
         def run_all():
             for b in batches:
                 model(b)
         model.dedup_inference = False
         run_all()
-        ev["all_slots_impressions_per_s"] = 512 * 3 / timed(run_all, 3)
+        ev["all_slots_impressions_per_s"] = n_imp * 3 / timed(run_all, 3)
         model.dedup_inference = True
         strip = [{k: v for k, v in b.items() if k not in ("browsed_ids", "candidate_ids")} for b in batches]
 
@@ -181,8 +183,8 @@ def eval_path_leg(model, dev):
             for b in strip:
                 model(b)
         run_hash()
-        ev["unique_titles_impressions_per_s"] = 512 * 3 / timed(run_hash, 3)
-        ev["unique_title_fraction"] = model.last_unique_titles / float(128 * 350)
+        ev["unique_titles_impressions_per_s"] = n_imp * 3 / timed(run_hash, 3)
+        ev["unique_title_fraction"] = model.last_unique_titles / float(per_batch * 350)
 
         def run_cached():
             eng.news_cache_begin()
@@ -192,7 +194,7 @@ def eval_path_leg(model, dev):
         run_cached()
         t = timed(run_cached, 3)
         stats = run_cached()
-        ev["news_cache_impressions_per_s"] = 512 * 3 / t
+        ev["news_cache_impressions_per_s"] = n_imp * 3 / t
         ev["news_cache_encoded_titles"] = stats["encoded"]
         ev["news_cache_lookups"] = stats["lookups"]
     model.train()
@@ -271,6 +273,9 @@ def main():
     loss = float(loss_sum) / B
     log("timed region: %d steps in %.3f s" % (args.steps, dt))
     eng.check_ids()
+    # The timed region overlaps the two weight-gradient GEMMs with other kernels on helper streams; a kernel's
+    # duration under that overlap is not its own, so the instrumented pass serialises the step (one stream).
+    os.environ["NRMS_NO_SIDE_STREAMS"] = "1"
     eng.timing_reset()
     eng.timing(True)
     torch.cuda.synchronize()
@@ -281,6 +286,7 @@ def main():
     parallel.barrier()
     dt_instr = time.perf_counter() - t1
     eng.timing(False)
+    os.environ.pop("NRMS_NO_SIDE_STREAMS", None)
     log("instrumented pass: %d steps in %.3f s" % (args.steps, dt_instr))
 
     # ---- data-parallel facts (every rank takes part; rank 0 reports)
@@ -385,7 +391,8 @@ def main():
                                         "bf16x3": "bf16 dense peak / 3 (3 bf16 MFMAs per fp32-equivalent step by construction)"}[kprec[dom]]),
                          "avg_launch_ms": dom_ms / max(dom_n, 1),
                          "timing_note": "kernel durations: HIP events on the launch stream, recorded in a second pass of the "
-                                        "same %d steps right after the (un-instrumented) timed region; that pass ran at "
+                                        "same %d steps right after the (un-instrumented) timed region, with the helper streams off "
+                                        "(NRMS_NO_SIDE_STREAMS) so that no two kernels share the GPU; that pass ran at "
                                         "%.2f ms/step" % (args.steps, dt_instr / args.steps * 1e3),
                          "algorithmic_per_step": by if bound == "hbm" else fl,
                          # the WHOLE step by BASELINE.md section 2: users/s x 3.558309e9 flop / peak (per GPU)

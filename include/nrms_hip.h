@@ -172,14 +172,22 @@ int nrms_sanitize_ids(const int64_t* src, int64_t* dst, int64_t n, int32_t vocab
 
 /* Evaluation encodes every DISTINCT title once (get_news_vector, nrms_v0.py:278-289, is the reference's hook for
  * caching news vectors; an impression padded to max_candidate_size = 300 slots, data_handler.py:174-177, is mostly
- * padding and repeats).  keys[t] = 64-bit hash of the seq_len word ids of title t: equal titles have equal keys;
- * the caller groups by key and verifies its representatives (a collision costs a re-run, not correctness). */
-int nrms_title_keys(const int64_t* ids, int64_t n_titles, int32_t seq_len, int64_t* keys, void* stream);
+ * padding and repeats).  Exact grouping of the n_titles rows of ids [n_titles, seq_len] (seq_len = 1 groups plain news
+ * ids): inverse[t] = index in [0, *n_unique) of the group of row t, rep_rows[u] = one row of group u (groups are
+ * numbered in arrival order, which may differ between runs; the groups themselves do not).  table: caller-provided
+ * workspace of table_size int32, a power of two >= 2 * n_titles.  *n_unique is a device int32. */
+int nrms_title_dedup(const int64_t* ids, int64_t n_titles, int32_t seq_len, int32_t* table, int64_t table_size,
+                     int32_t* inverse, int32_t* rep_rows, int32_t* n_unique, void* stream);
 
 /* Click scores: bmm(cand [B,C,d], user [B,d,1]) then masked_fill(mask==0, -1e9)
  * (DotProductClickPredictor, nrms_v0.py:205-216; mask nrms_v0.py:272-274).  mask may be NULL. */
 int nrms_click_score_fwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,
                          const uint8_t* mask, float* scores, void* stream);
+/* The same scores with the candidate vectors named by row index into a table of news vectors instead of being
+ * materialised: scores[b][c] = <news_vec[index[b*C + c]], user[b]> (the evaluation path: 300 candidate slots per
+ * impression over a few thousand distinct news).  index: int32 [B*C], every entry in [0, n_vec). */
+int nrms_click_score_indexed(int32_t B, int32_t C, int32_t d, const float* news_vec, int64_t n_vec, const int32_t* index,
+                             const float* user, const uint8_t* mask, float* scores, void* stream);
 /* dscores [B,C] -> dcand [B,C,d], duser [B,d] (masked slots receive no gradient). */
 int nrms_click_score_bwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,
                          const uint8_t* mask, const float* dscores, float* dcand, float* duser,

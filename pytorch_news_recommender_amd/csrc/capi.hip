@@ -583,10 +583,14 @@ extern "C" int nrms_sanitize_ids(const int64_t* src, int64_t* dst, int64_t n, in
     return launch_sanitize_ids((long)n, src, dst, vocab, n_bad, (hipStream_t)stream);
 }
 
-extern "C" int nrms_title_keys(const int64_t* ids, int64_t n_titles, int32_t seq_len, int64_t* keys, void* stream) {
-    NRMS_REQUIRE(n_titles >= 0 && seq_len >= 1, "title_keys: n_titles=%ld seq_len=%d", (long)n_titles, seq_len);
-    NRMS_REQUIRE(n_titles == 0 || (ids && keys), "title_keys: null argument");
-    return launch_title_keys((long)n_titles, seq_len, ids, keys, (hipStream_t)stream);
+extern "C" int nrms_title_dedup(const int64_t* ids, int64_t n_titles, int32_t seq_len, int32_t* table, int64_t table_size,
+                                int32_t* inverse, int32_t* rep_rows, int32_t* n_unique, void* stream) {
+    NRMS_REQUIRE(n_titles >= 0 && n_titles < (1L << 30) && seq_len >= 1, "title_dedup: n_titles=%ld seq_len=%d", (long)n_titles, seq_len);
+    NRMS_REQUIRE(n_unique != nullptr, "title_dedup: null n_unique");
+    NRMS_REQUIRE(n_titles == 0 || (ids && table && inverse && rep_rows), "title_dedup: null argument");
+    NRMS_REQUIRE(n_titles == 0 || (table_size >= 2 * n_titles && (table_size & (table_size - 1)) == 0),
+                 "title_dedup: table_size=%ld must be a power of two >= 2 * n_titles (%ld)", (long)table_size, (long)n_titles);
+    return launch_title_dedup((long)n_titles, seq_len, ids, table, (long)table_size, inverse, rep_rows, n_unique, (hipStream_t)stream);
 }
 
 extern "C" void nrms_timing_enable(int enable) {

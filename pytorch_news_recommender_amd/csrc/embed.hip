@@ -398,30 +398,81 @@ int launch_sanitize_ids(long n, const int64_t* src, int64_t* dst, int vocab, int
     return check_launch("sanitize_ids");
 }
 
-// keys[t] = 64-bit hash of title t's L word ids (one lane per title; titles are 30 words).  Equal titles get
-// equal keys; the caller verifies the converse on its representatives, so a collision costs time, not correctness.
-__global__ __launch_bounds__(256) void title_keys_kernel(long n, int L, const int64_t* ids, int64_t* keys) {
+// Distinct titles of a batch, exactly and without a sort: an open-addressing table of row indices.  One lane per
+// title hashes its L word ids and probes; an empty slot is claimed with a CAS (the claimant becomes the group's
+// representative and takes the next unique index), an occupied slot is compared word by word with the row that owns
+// it (ids is read-only, so the owner's words are always valid), and a mismatch -- two different titles in one slot --
+// moves on to the next slot.  Padding slots (the same all-zero title tens of thousands of times at C = 300) take the
+// read-only path: the slot is loaded before any CAS is tried.
+// The all-zero row is handled per wavefront: one lane probes for all of them (a hundred thousand lanes loading one
+// slot with a device-scope load is a hot spot at the memory side: 2 ms instead of 0.05).
+__global__ __launch_bounds__(256) void dedup_insert_kernel(long n, int L, const int64_t* ids, int* table, unsigned mask,
+                                                           int* inverse, int* rep_rows, int* n_unique) {
+    const int lane = threadIdx.x & 63;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
-        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)L;
         const int64_t* row = ids + t * L;
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)L;
+        int64_t any = 0;
         for (int i = 0; i < L; ++i) {
-            uint64_t k = (uint64_t)row[i] * 0xFF51AFD7ED558CCDull;
+            const int64_t w = row[i];
+            any |= w;
+            uint64_t k = (uint64_t)w * 0xFF51AFD7ED558CCDull;
             k ^= k >> 32;
             h = (h ^ k) * 0xC4CEB9FE1A85EC53ull;
             h ^= h >> 29;
         }
         h ^= h >> 33; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 33;
-        keys[t] = (int64_t)h;
+        const bool pad = any == 0;
+        const unsigned long long pads = __ballot(pad);
+        const int leader = pads != 0 ? __ffsll((long long)pads) - 1 : 0;
+        int result = 0;
+        if (!pad || lane == leader) {
+            unsigned slot = (unsigned)h & mask;
+            for (;;) {                                               // the table has >= 2n slots: an empty one is always reached
+                int cur = __hip_atomic_load(table + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur < 0) {
+                    cur = atomicCAS(table + slot, -1, (int)t);
+                    if (cur < 0) {                                   // claimed: representative of a new group
+                        const int u = atomicAdd(n_unique, 1);
+                        rep_rows[u] = (int)t;
+                        result = u;
+                        break;
+                    }
+                }
+                const int64_t* other = ids + (long)cur * L;
+                bool same = true;
+                for (int i = 0; i < L; ++i) same = same && other[i] == row[i];
+                if (same) { result = -cur - 1; break; }              // resolved to the owner's unique index below
+                slot = (slot + 1) & mask;
+            }
+        }
+        const int lead = __shfl(result, leader);                     // the owner's index, or the pointer to the owner
+        inverse[t] = (pad && lane != leader) ? lead : result;
     }
 }
 
-int launch_title_keys(long n, int L, const int64_t* ids, int64_t* keys, hipStream_t stream) {
+__global__ __launch_bounds__(256) void dedup_resolve_kernel(long n, int* inverse) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int v = inverse[t];
+        if (v < 0) inverse[t] = inverse[-v - 1];                     // owners hold their (non-negative) index and are not rewritten
+    }
+}
+
+int launch_title_dedup(long n, int L, const int64_t* ids, int* table, long table_size, int* inverse, int* rep_rows,
+                       int* n_unique, hipStream_t stream) {
+    if (hipMemsetAsync(n_unique, 0, sizeof(int), stream) != hipSuccess) { set_error("title_dedup: memset failed"); return NRMS_ELAUNCH; }
     if (n <= 0) return NRMS_OK;
+    if (hipMemsetAsync(table, 0xFF, (size_t)table_size * sizeof(int), stream) != hipSuccess) {
+        set_error("title_dedup: memset failed");
+        return NRMS_ELAUNCH;
+    }
     int blocks = cdiv(n, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    TimingScope ts("title_keys", stream);
-    hipLaunchKernelGGL(title_keys_kernel, dim3(blocks), dim3(256), 0, stream, n, L, ids, keys);
-    return check_launch("title_keys");
+    TimingScope ts("title_dedup", stream);
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(blocks), dim3(256), 0, stream, n, L, ids, table, (unsigned)(table_size - 1),
+                       inverse, rep_rows, n_unique);
+    hipLaunchKernelGGL(dedup_resolve_kernel, dim3(blocks), dim3(256), 0, stream, n, inverse);
+    return check_launch("title_dedup");
 }
 
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,

@@ -859,7 +859,6 @@ struct SideStreams {
     void init() {
         if (tried) return;
         tried = true;
-        if (getenv("NRMS_NO_SIDE_STREAMS") != nullptr) return;
         for (int i = 0; i < 2; ++i) {
             if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return;
             if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess) return;
@@ -943,7 +942,8 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     float* partial_qkv = (float*)(base + L.partial);
     float* partial_add = (float*)(base + L.partial + up256((size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4));
     g_side.init();
-    const bool side = g_side.ok;
+    // NRMS_NO_SIDE_STREAMS is read per call so that a profiler pass can serialise the step (exclusive kernel durations)
+    const bool side = g_side.ok && getenv("NRMS_NO_SIDE_STREAMS") == nullptr;
     hipStream_t s_add = side ? g_side.s[0] : stream, s_qkv = side ? g_side.s[1] : stream;
     const int Mp = f.n_seq * 32 * (f.S > 32 ? 2 : 1);         // fragment order: 32 rows per block, zero beyond a sequence
     {

@@ -374,7 +374,8 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream);
 // dst[i] = src[i] if 0 <= src[i] < vocab else 0; *n_bad += ids replaced (dst may alias src)
 int launch_sanitize_ids(long n, const int64_t* src, int64_t* dst, int vocab, int* n_bad, hipStream_t stream);
 // keys[t] = 64-bit hash of the L word ids of title t
-int launch_title_keys(long n, int L, const int64_t* ids, int64_t* keys, hipStream_t stream);
+int launch_title_dedup(long n, int L, const int64_t* ids, int* table, long table_size, int* inverse, int* rep_rows,
+                       int* n_unique, hipStream_t stream);
 int launch_gather_dropout(long M, int d, const int64_t* ids, const float* table, const Dropout& drop, float* x,
                           hipStream_t stream);
 // x[r, :] = table[ids[live[r]], :] * keep(live[r], :) / (1 - p) for the compact rows r < *n_live

@@ -265,6 +265,23 @@ __global__ void click_fwd_kernel(int B, int C, int d, const float* cand, const f
     if (lane == 0) scores[u] = (mask != nullptr && mask[u] == 0) ? -1e9f : p;
 }
 
+// candidate vectors by index into a news-vector table; an index outside [0, n_vec) reads row 0 and scores NaN
+__global__ void click_indexed_kernel(int B, int C, int d, const float* vec, long n_vec, const int* index, const float* user,
+                                     const uint8_t* mask, float* scores) {
+    const int lane = threadIdx.x & 63;
+    const long u = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (u >= (long)B * C) return;
+    const long b = u / C;
+    const long r = index[u];
+    const bool ok = r >= 0 && r < n_vec;
+    const float* cv = vec + (ok ? r : 0) * d;
+    const float* uv = user + b * d;
+    float p = 0.f;
+    for (int k = lane; k < d; k += 64) p += cv[k] * uv[k];
+    p = wave_sum(p);
+    if (lane == 0) scores[u] = (mask != nullptr && mask[u] == 0) ? -1e9f : (ok ? p : __builtin_nanf(""));
+}
+
 __global__ void click_bwd_kernel(int B, int C, int d, const float* cand, const float* user, const uint8_t* mask,
                                  const float* dscores, float* dcand, float* duser) {
     const int b = blockIdx.x;
@@ -407,6 +424,17 @@ extern "C" int nrms_click_score_fwd(int32_t B, int32_t C, int32_t d, const float
     TimingScope ts("click_fwd", s);
     hipLaunchKernelGGL(click_fwd_kernel, dim3(cdiv((long)B * C, 4)), dim3(256), 0, s, B, C, d, cand, user, mask, scores);
     return check_launch("click_fwd");
+}
+
+extern "C" int nrms_click_score_indexed(int32_t B, int32_t C, int32_t d, const float* news_vec, int64_t n_vec, const int32_t* index,
+                                        const float* user, const uint8_t* mask, float* scores, void* stream) {
+    NRMS_REQUIRE(B >= 0 && C > 0 && d > 0 && n_vec > 0 && news_vec && index && user && scores, "click_score_indexed: bad arguments");
+    if (B == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    TimingScope ts("click_fwd", s);
+    hipLaunchKernelGGL(click_indexed_kernel, dim3(cdiv((long)B * C, 4)), dim3(256), 0, s, B, C, d, news_vec, (long)n_vec, index,
+                       user, mask, scores);
+    return check_launch("click_indexed");
 }
 
 extern "C" int nrms_click_score_bwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* user,

@@ -435,27 +435,39 @@ class NRMSEngine:
         return auc
 
     # ---- inference with unique-title caching (SURVEY f-1) -------------------------------------
+    def group_rows(self, rows):
+        """rows [N, L] int64 (device) -> (inverse [N] int32, rep_rows [U] int32, U): exact grouping of equal rows
+        by a device hash table (nrms_title_dedup): rows[rep_rows[inverse[t]]] == rows[t].  One host read-back (U)."""
+        N, L = rows.shape
+        size = 1 << max(int(2 * N - 1).bit_length(), 4)
+        table = self._buf("dedup_table", size, torch.int32)
+        inverse = torch.empty(N, dtype=torch.int32, device=self.device)
+        rep = self._buf("dedup_rep", N, torch.int32)
+        n_unique = self._buf("dedup_count", 1, torch.int32)
+        rc = self.lib.nrms_title_dedup(_lib.ptr(rows), C.c_int64(N), int(L), _lib.ptr(table), C.c_int64(size),
+                                       _lib.ptr(inverse), _lib.ptr(rep), _lib.ptr(n_unique), _stream())
+        _lib.check(rc, "nrms_title_dedup")
+        U = int(n_unique.item())
+        return inverse, rep[:U], U
+
     def unique_titles(self, ids):
-        """ids [N, L] -> (representative titles [U, L], inverse [N]) with ids == uniq[inverse].  Titles are
-        grouped by a 64-bit device hash of their word ids (nrms_title_keys) -- a 1-D radix sort of N keys instead
-        of a lexicographic sort of N x L words -- and the grouping is verified against the representatives; on a
-        hash collision (never observed; ~N^2 / 2^65) the exact row-wise unique takes over."""
-        N, L = ids.shape
-        keys = torch.empty(N, dtype=torch.int64, device=self.device)
-        rc = self.lib.nrms_title_keys(_lib.ptr(ids), C.c_int64(N), int(L), _lib.ptr(keys), _stream())
-        _lib.check(rc, "nrms_title_keys")
-        ukeys, inverse = torch.unique(keys, return_inverse=True)
-        rep = torch.empty(ukeys.shape[0], dtype=torch.int64, device=self.device)
-        rep.scatter_(0, inverse, torch.arange(N, device=self.device))       # any member represents its group
-        uniq = ids.index_select(0, rep)
-        if not bool((uniq.index_select(0, inverse) == ids).all().item()):
-            uniq, inverse = torch.unique(ids, dim=0, return_inverse=True)
-        return uniq, inverse
+        """ids [N, L] -> (one title per group [U, L], inverse [N] int32) with ids == uniq[inverse]."""
+        inverse, rep, _ = self.group_rows(ids)
+        return ids.index_select(0, rep), inverse
+
+    def click_scores_indexed(self, news_vec, index, user_vec, B, Cn, cand_mask=None):
+        """scores [B, Cn] with candidate slot (b, c) = row index[b*Cn + c] of news_vec [n, d]."""
+        out = torch.empty(B, Cn, dtype=torch.float32, device=self.device)
+        rc = self.lib.nrms_click_score_indexed(B, Cn, news_vec.shape[1], _lib.ptr(news_vec), C.c_int64(news_vec.shape[0]),
+                                               _lib.ptr(index), _lib.ptr(user_vec), _lib.ptr(cand_mask), _lib.ptr(out),
+                                               _stream())
+        _lib.check(rc, "nrms_click_score_indexed")
+        return out
 
     def forward_dedup(self, flat, hist_ids, cand_ids, cand_mask):
         """Same scores as forward(training=False), but every distinct title of the batch is encoded
         once (the reference encodes all B*(H+C) slots, 350 per user at C=300, most of them padding
-        or repeats: train_eval.py:229-273 / data_handler.py:174-177)."""
+        or repeats: train_eval.py:229-273 / data_handler.py:174-177); candidate vectors are read by index."""
         B, H, L = hist_ids.shape
         Cn = cand_ids.shape[1]
         d = self.dims.word_embed_size
@@ -466,13 +478,11 @@ class NRMSEngine:
         self.sanitize_ids(cand_ids.reshape(B * Cn, L).contiguous(), ids[B * H:])
         uniq, inverse = self.unique_titles(ids)
         vec = self.encode_titles(flat, uniq, tag="news_eval", trusted_ids=True)
-        nv = vec.index_select(0, inverse)
-        hist = nv[:B * H].view(B, H, d)
-        cand = nv[B * H:].view(B, Cn, d)
+        hist = vec.index_select(0, inverse[:B * H]).view(B, H, d)
         user = self.encode_users(flat, hist, tag="user_eval")
         if cand_mask is not None:
             cand_mask = cand_mask.contiguous()
-        return self.click_scores(cand, user, cand_mask), int(uniq.shape[0])
+        return self.click_scores_indexed(vec, inverse[B * H:], user, B, Cn, cand_mask), int(uniq.shape[0])
 
     # persistent news-vector cache across evaluation batches, keyed by the news ids the batch dict carries
     # (browsed_ids / candidate_ids, data_handler.py:204-222; 0 = padding slot = all-padding title)
@@ -504,25 +514,23 @@ class NRMSEngine:
         Cn = cand_ids.shape[1]
         d = self.dims.word_embed_size
         N = B * (H + Cn)
-        news = torch.cat([hist_news.reshape(-1), cand_news.reshape(-1)]).to(torch.int64)
-        top = int(news.max().item()) + 1 if N else 1
-        if top > st["vec"].shape[0]:                                  # grow (amortised doubling)
-            cap = max(top, 2 * st["vec"].shape[0])
+        news = torch.cat([hist_news.reshape(-1), cand_news.reshape(-1)]).to(torch.int64).contiguous()
+        inverse, rep, _ = self.group_rows(news.view(N, 1))
+        u = news.index_select(0, rep)                                  # the distinct news ids of the batch
+        lo, top = (int(v) for v in torch.stack([u.min(), u.max()]).tolist()) if N else (0, 0)
+        if lo < 0:
+            raise _lib.NrmsError("negative news id in browsed_ids / candidate_ids")
+        if top + 1 > st["vec"].shape[0]:                              # grow (amortised doubling)
+            cap = max(top + 1, 2 * st["vec"].shape[0])
             vec = torch.empty(cap, d, dtype=torch.float32, device=self.device)
             have = torch.zeros(cap, dtype=torch.bool, device=self.device)
             vec[:st["vec"].shape[0]] = st["vec"]
             have[:st["have"].shape[0]] = st["have"]
             st["vec"], st["have"] = vec, have
-        if int(news.min().item()) < 0:
-            raise _lib.NrmsError("negative news id in browsed_ids / candidate_ids")
-        u, inv = torch.unique(news, return_inverse=True)
-        missing = u[~st["have"].index_select(0, u)]
-        if missing.numel():
-            rep = torch.empty(u.shape[0], dtype=torch.int64, device=self.device)
-            rep.scatter_(0, inv, torch.arange(N, device=self.device))
-            slot = torch.full((st["vec"].shape[0],), -1, dtype=torch.int64, device=self.device)
-            slot[u] = rep
-            rows = slot.index_select(0, missing)                       # a slot of the batch holding each missing news item
+        need = ~st["have"].index_select(0, u)
+        rows = rep[need].to(torch.int64)                               # a slot of the batch holding each news item not cached yet
+        if rows.numel():
+            missing = u[need]
             titles = torch.where((rows < B * H).unsqueeze(1),
                                  hist_ids.reshape(B * H, L).index_select(0, rows.clamp(max=B * H - 1)),
                                  cand_ids.reshape(B * Cn, L).index_select(0, (rows - B * H).clamp(min=0)))
@@ -530,13 +538,11 @@ class NRMSEngine:
             st["have"][missing] = True
             st["encoded"] += int(missing.numel())
         st["hits"] += N
-        nv = st["vec"].index_select(0, news)
-        hist = nv[:B * H].view(B, H, d)
-        cand = nv[B * H:].view(B, Cn, d)
+        hist = st["vec"].index_select(0, news[:B * H]).view(B, H, d)
         user = self.encode_users(flat, hist, tag="user_eval")
         if cand_mask is not None:
             cand_mask = cand_mask.contiguous()
-        return self.click_scores(cand, user, cand_mask)
+        return self.click_scores_indexed(st["vec"], news[B * H:].to(torch.int32), user, B, Cn, cand_mask)
 
     def dropout_keep_mask(self, seed, site, n_rows, p_drop, d=None):
         """Keep mask of a dropout site over [n_rows, d] (d defaults to the model width; the fp16 mode's context

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _build(shape, params):
+def _build(shape, params, precision="fp32"):
     from pytorch_news_recommender_amd.config import Config
     from pytorch_news_recommender_amd.model.nrms_hip import Model
     cfg = Config("nrms_hip")
@@ -29,12 +29,13 @@ def _build(shape, params):
     cfg.word_embed_size, cfg.num_attention_heads, cfg.query_vector_dim = (
         shape.word_embed_size, shape.num_attention_heads, shape.query_vector_dim)
     cfg.dropout = 0.0
+    cfg.precision = precision
     m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
     return m.to("cuda:0").train()
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, precision):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -43,7 +44,7 @@ def _worker(rank, world, port, out_dir):
     shape = synth.Shape(n_words=400, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                         batch_size=6, history_len=50, n_candidates=5, n_words_title=30)
     params = synth.make_params(shape, seed=9 + rank)          # deliberately different: broadcast must fix it
-    model = _build(shape, params)
+    model = _build(shape, params, precision)
     model.engine
     parallel.broadcast_parameters(model._flat, src=0)
     reduce = parallel.GradAllReduce()
@@ -60,26 +61,32 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(tmp_path):
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_two_ranks_match_single_process(tmp_path, precision):
     from pytorch_news_recommender_amd import synth
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), precision), nprocs=2, join=True)
     f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
     assert np.abs(f0 - f1).max() < 1e-7                   # replicas stay in lock-step
     shape = synth.Shape(n_words=400, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                         batch_size=6, history_len=50, n_candidates=5, n_words_title=30)
-    model = _build(shape, synth.make_params(shape, seed=9))
+    model = _build(shape, synth.make_params(shape, seed=9), precision)
     tot = []
     for t in range(2):
         gbatch = {k: torch.from_numpy(v) for k, v in synth.make_batch(shape, seed=20 + t, ragged=True).items()}
         tot.append(float(model.train_step(gbatch)))
     single = model._flat.detach().cpu().numpy()
     l0, l1 = np.load(tmp_path / "loss0.npy"), np.load(tmp_path / "loss1.npy")
-    np.testing.assert_allclose(l0 + l1, tot, rtol=1e-5)   # local loss sums add up to the global sum
+    np.testing.assert_allclose(l0 + l1, tot, rtol=1e-5 if precision == "fp32" else 1e-4)   # local loss sums add up to the global sum
     diff = np.abs(f0 - single)
-    # Adam amplifies fp32 summation-order noise where |g| ~ eps (see test_hip_parity.assert_params_close)
-    assert np.median(diff) < 1e-6 and np.quantile(diff, 0.999) < 1e-4 and diff.max() < 2.1e-3, (
-        float(np.median(diff)), float(diff.max()))
+    # Adam amplifies summation-order noise where |g| ~ eps (see test_hip_parity.assert_params_close); in fp16 mode the two
+    # runs also round their gradients differently (the loss scale follows the local batch): sign flips of noise-level
+    # gradient elements move a parameter by up to lr per step
+    if precision == "fp32":
+        assert np.median(diff) < 1e-6 and np.quantile(diff, 0.999) < 1e-4 and diff.max() < 2.1e-3, (
+            float(np.median(diff)), float(diff.max()))
+    else:
+        assert np.median(diff) < 2e-5 and diff.max() < 4.1e-3, (float(np.median(diff)), float(diff.max()))
 
 
 def test_deferred_wqkv_backward_equals_plain_backward():

@@ -60,6 +60,36 @@ def test_unique_title_inference_equals_plain_forward():
     assert (s_dedup[batch["candidate_mask"] == 0] == np.float32(-1e9)).all()
 
 
+def test_row_grouping_is_exact_and_indexed_scores_match():
+    """nrms_title_dedup against torch.unique(dim=0) (same partition of the rows, any numbering) on titles with many
+    repeats, near-duplicates (one word apart) and all-padding rows, and on plain ids (seq_len 1);
+    nrms_click_score_indexed against nrms_click_score_fwd on the materialised candidates."""
+    model = _model(synth.G1_ODD, synth.make_params(synth.G1_ODD, seed=1))
+    eng, dev = model.engine, torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    base = torch.randint(1, 40, (300, 30), generator=g)
+    near = base[:50].clone()
+    near[:, 29] += 1                                                   # differ in the last word only
+    rows = torch.cat([base, near, torch.zeros(500, 30, dtype=torch.int64), base[:200], near[:10]])
+    rows = rows[torch.randperm(rows.shape[0], generator=g)].contiguous().to(dev)
+    for r in (rows, rows[:, :1].contiguous(), rows[:1], rows[:0].reshape(0, 30)):
+        inverse, rep, U = eng.group_rows(r)
+        ref_u, ref_inv = torch.unique(r, dim=0, return_inverse=True)
+        assert U == ref_u.shape[0] == rep.shape[0]
+        if r.shape[0] == 0:
+            continue
+        assert int(inverse.min()) >= 0 and int(inverse.max()) == U - 1
+        assert torch.equal(r.index_select(0, rep).index_select(0, inverse), r)          # every row maps to an equal row
+        assert torch.unique(torch.stack([inverse.long(), ref_inv], 1), dim=0).shape[0] == U   # one-to-one with torch's groups
+    vec = torch.randn(37, 300, generator=g).to(dev)
+    user = torch.randn(4, 300, generator=g).to(dev)
+    index = torch.randint(0, 37, (4 * 9,), generator=g).to(torch.int32).to(dev)
+    mask = (torch.rand(4, 9, generator=g) > 0.3).to(torch.uint8).to(dev)
+    want = eng.click_scores(vec.index_select(0, index).view(4, 9, 300), user, mask)
+    got = eng.click_scores_indexed(vec, index, user, 4, 9, mask)
+    assert torch.equal(got, want)
+
+
 def test_train_evaluate_checkpoint_loop(tmp_path):
     from torch.utils.data import DataLoader
     from pytorch_news_recommender_amd.config import Config
