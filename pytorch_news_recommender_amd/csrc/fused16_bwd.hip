@@ -223,7 +223,8 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                         for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
                     }
                 }
-                if (valid && !(a.dbg & 4)) {                    // (zero beyond the sequence: dZ and w are 0 there)
+                if (live && !(a.dbg & 4)) {                     // (zero beyond the sequence: dZ and w are 0 there); the
+                    // attention kernel reads the rows of titles with a real token only
                     _Float16* dcrow = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
                     *reinterpret_cast<h8*>(dcrow) = acc_frag(dct, 0);
                     *reinterpret_cast<h8*>(dcrow + 512) = acc_frag(dct, 1);
@@ -888,6 +889,8 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     // TN partial slabs (one workgroup per CU and round): the larger of the two products
     L.tn_splits_qkv = 44;      // x 6 output blocks of 320 x 160 = 264 workgroups (a multiple of 8: XCD mapping)
     L.tn_splits_add = 128;     // x 2 = 256
+    if (const char* e = getenv("NRMS_TN_SPLITS_QKV")) L.tn_splits_qkv = atoi(e);      // tuning only
+    if (const char* e = getenv("NRMS_TN_SPLITS_ADD")) L.tn_splits_add = atoi(e);
     const size_t p1 = (size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4, p2 = (size_t)L.tn_splits_add * F16_QP * F16_DP * 4;
     L.partial = take(up256(p1) + p2);                    // both products have their own slabs: they run concurrently
     L.total = off;
