@@ -217,3 +217,120 @@ def make_params_v1(shape: Shape, seed: int = 0):
             t = rng.uniform(-1.0, 1.0, size=shp) / np.sqrt(shape.word_embed_size)
         out[name] = np.ascontiguousarray(t, dtype=np.float32)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# nrms_naml (SURVEY f-3; model/nrms_naml.py:103-257): title + abstract through ONE word-level encoder (W_O, dropout on
+# the attention probabilities), category / sub-category embeddings, LayerNorm on the history, a wide user encoder.
+@dataclass(frozen=True)
+class NamlShape:
+    """Names follow config.py:30-31,45-49,68-72,77,87."""
+    n_words: int = 45800
+    word_embed_size: int = 300
+    title_heads_num: int = 6
+    query_vector_dim: int = 200
+    category_nums: int = 19
+    subcategory_nums: int = 294
+    cate_embed_size: int = 100
+    user_heads_num: int = 8
+    query_vector_dim_large: int = 400
+    batch_size: int = 512
+    history_len: int = 50
+    n_candidates: int = 5
+    n_words_title: int = 20
+    n_words_abst: int = 40
+
+    @property
+    def news_feature_size(self):
+        return 2 * self.word_embed_size + 2 * self.cate_embed_size
+
+
+G7_ODD = NamlShape(n_words=83, word_embed_size=48, title_heads_num=6, query_vector_dim=20, category_nums=5,
+                   subcategory_nums=9, cate_embed_size=16, user_heads_num=8, query_vector_dim_large=36,
+                   batch_size=3, history_len=5, n_candidates=3, n_words_title=7, n_words_abst=11)
+G7_MIND = NamlShape(n_words=500, batch_size=2, history_len=50, n_candidates=5)
+
+
+def naml_param_shapes(s: NamlShape):
+    """The 27 tensors of nrms_naml.Model.state_dict(), in registration order (nrms_naml.py:106-117,181-186,200-207)."""
+    d, F, q, Q = s.word_embed_size, s.news_feature_size, s.query_vector_dim, s.query_vector_dim_large
+    out = {"news_encoder.category_embedding.weight": (s.category_nums, s.cate_embed_size),
+           "news_encoder.subcategory_embedding.weight": (s.subcategory_nums, s.cate_embed_size),
+           "news_encoder.word_embedding.weight": (s.n_words, d)}
+    for enc, dm, qq in (("news_encoder", d, q), ("user_encoder", F, Q)):
+        a = enc + ".multi_head_self_attention."
+        for i in range(3):
+            out[a + "linear_layers.%d.weight" % i] = (dm, dm)
+            out[a + "linear_layers.%d.bias" % i] = (dm,)
+        out[a + "output_linear.weight"] = (dm, dm)
+        out[a + "output_linear.bias"] = (dm,)
+        out[enc + ".additive_attention.query_vector"] = (qq,)        # a module's own parameters precede its children's
+        out[enc + ".additive_attention.linear.weight"] = (qq, dm)
+        out[enc + ".additive_attention.linear.bias"] = (qq,)
+    out["norm.weight"] = (F,)
+    out["norm.bias"] = (F,)
+    return out
+
+
+def make_params_naml(s: NamlShape, seed: int = 0):
+    """Initial distributions of the reference's modules (torch defaults: Linear kaiming-uniform(a=sqrt 5) = U(+-1/sqrt
+    fan_in), Embedding N(0,1) with a zero padding row; query vector U(-0.1, 0.1), nrms_naml.py:82); LayerNorm gets a
+    random affine instead of (1, 0) so that its gradients are exercised."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shp in naml_param_shapes(s).items():
+        if name.endswith("word_embedding.weight"):
+            t = rng.normal(0.0, 0.4, size=shp)
+            t[0] = 0.0
+        elif name.endswith("category_embedding.weight"):
+            t = rng.normal(0.0, 1.0, size=shp)
+            t[0] = 0.0
+        elif name.endswith("query_vector"):
+            t = rng.uniform(-0.1, 0.1, size=shp)
+        elif name == "norm.weight":
+            t = rng.uniform(0.5, 1.5, size=shp)
+        elif name == "norm.bias":
+            t = rng.uniform(-0.2, 0.2, size=shp)
+        elif name.endswith(".weight"):
+            bound = 1.0 / np.sqrt(shp[1])
+            t = rng.uniform(-bound, bound, size=shp)
+        else:
+            fan_in = s.news_feature_size if name.startswith("user_encoder") else s.word_embed_size
+            t = rng.uniform(-1.0, 1.0, size=shp) / np.sqrt(fan_in)
+        out[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return out
+
+
+def make_batch_naml(s: NamlShape, seed: int = 1, batch_size: int | None = None, mask_some_candidates: bool = True):
+    """The batch-dict keys nrms_naml.Model.forward reads (nrms_naml.py:217-228,245), shapes and dtypes of
+    data_handler.py:236-250: ragged titles / abstracts, left-aligned histories, padding slots with category 0."""
+    B = s.batch_size if batch_size is None else batch_size
+    H, C = s.history_len, s.n_candidates
+    rng = np.random.default_rng(seed)
+
+    def texts(n_slots, L):
+        ids = rng.integers(1, s.n_words, size=(B, n_slots, L), dtype=np.int64)
+        ln = rng.integers(1, L + 1, size=(B, n_slots))
+        return np.where(np.arange(L)[None, None, :] < ln[..., None], ids, 0)
+
+    bt, ba = texts(H, s.n_words_title), texts(H, s.n_words_abst)
+    ct, ca = texts(C, s.n_words_title), texts(C, s.n_words_abst)
+    bc = rng.integers(1, s.category_nums, size=(B, H), dtype=np.int64)
+    bs = rng.integers(1, s.subcategory_nums, size=(B, H), dtype=np.int64)
+    cc = rng.integers(1, s.category_nums, size=(B, C), dtype=np.int64)
+    cs = rng.integers(1, s.subcategory_nums, size=(B, C), dtype=np.int64)
+    hist_len = rng.integers(1, H + 1, size=(B,))
+    if B > 1:
+        hist_len[1] = 0
+    live = np.arange(H)[None, :] < hist_len[:, None]
+    bt, ba = np.where(live[..., None], bt, 0), np.where(live[..., None], ba, 0)
+    bc, bs = np.where(live, bc, 0), np.where(live, bs, 0)
+    ba[0, 0, :] = 0                                     # a news item without an abstract
+    cmask = np.ones((B, C), dtype=np.uint8)
+    if mask_some_candidates:
+        cmask[0, C - 1] = 0
+    c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    return {"browsed_titles": c64(bt), "browsed_absts": c64(ba), "browsed_categ_ids": c64(bc),
+            "browsed_subcateg_ids": c64(bs), "candidate_titles": c64(ct), "candidate_absts": c64(ca),
+            "candidate_categ_ids": c64(cc), "candidate_subcateg_ids": c64(cs), "candidate_mask": cmask,
+            "browsed_lens": hist_len.astype(np.int64), "browsed_mask": live.astype(np.uint8)}

@@ -25,6 +25,11 @@ reference's own classes:
                 hand-written samples of ``synth.dataset_fixture_inputs()``: all 13 keys, train (type 0)
                 and evaluation (type 1) padding.
 
+  g7_naml.npz   nrms_naml (model/nrms_naml.py) with dropout 0: an awkward small shape (all 27 gradients in full)
+                and the real widths (d=300, 6 heads, q=200, 100-wide category embeddings, 800-wide user encoder with 8
+                heads, q=400; B=2): scores, loss, news / user vectors, small gradients in full, the large matrices
+                as 32 sampled rows + row sums + column sums.
+
 The reference is imported, never copied; no reference source text is written anywhere.
 """
 import os
@@ -262,6 +267,63 @@ def gen_g6():
     print("g6", len(out), "arrays")
 
 
+def naml_sample_rows(n_rows, k=32, seed=77):
+    return np.sort(np.random.default_rng(seed).choice(n_rows, size=min(k, n_rows), replace=False))
+
+
+def gen_g7():
+    """nrms_naml.Model of the imported reference (SURVEY f-3)."""
+    import importlib
+    sys.modules.setdefault("torchsnooper", types.ModuleType("torchsnooper"))    # imported at nrms_naml.py:5, never used
+    mod = importlib.import_module("model.nrms_naml")
+    from config import Config
+    out = {}
+    for tag, shape in (("odd", synth.G7_ODD), ("mind", synth.G7_MIND)):
+        params = synth.make_params_naml(shape, seed=21)
+        batch = synth.make_batch_naml(shape, seed=22)
+        with tempfile.TemporaryDirectory() as td:
+            np.savez(os.path.join(td, "all_word_embedding_v3.npz"), embeddings=params["news_encoder.word_embedding.weight"])
+            cfg = Config("nrms_naml")
+            cfg.__nrms__()
+            cfg.data_path = td + "/"
+            cfg.device = torch.device("cpu")
+            cfg.dropout = 0.0
+            for k in ("word_embed_size", "title_heads_num", "query_vector_dim", "category_nums", "subcategory_nums",
+                      "cate_embed_size", "user_heads_num", "query_vector_dim_large"):
+                setattr(cfg, k, getattr(shape, k))
+            cfg.news_feature_size = shape.news_feature_size
+            model = mod.Model(cfg)
+        res = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert list(model.state_dict().keys()) == list(params.keys()), list(model.state_dict().keys())
+        model.train()
+        tb = torch_batch(batch)
+        scores = model(tb)
+        loss = torch.nn.CrossEntropyLoss()(scores, torch.zeros(len(scores)).long())
+        model.zero_grad()
+        loss.backward()
+        out[tag + "/scores"] = scores.detach().numpy()
+        out[tag + "/loss"] = np.float64(float(loss))
+        with torch.no_grad():
+            cand = model.news_encoder((tb["candidate_titles"], tb["candidate_absts"], tb["candidate_categ_ids"],
+                                       tb["candidate_subcateg_ids"]))
+            hist = model.news_encoder((tb["browsed_titles"], tb["browsed_absts"], tb["browsed_categ_ids"],
+                                       tb["browsed_subcateg_ids"]))
+            user = model.user_encoder(model.norm(hist))
+        out[tag + "/cand"], out[tag + "/hist"], out[tag + "/user"] = cand.numpy(), hist.numpy(), user.numpy()
+        for name, prm in model.named_parameters():
+            g = prm.grad.detach().numpy()
+            if g.size <= 100000:
+                out[tag + "/grad/" + name] = g.copy()
+            else:
+                rows = naml_sample_rows(g.shape[0])
+                out[tag + "/grad_rows/" + name] = g[rows].copy()
+                out[tag + "/grad_rowsum/" + name] = g.sum(1, dtype=np.float64)
+                out[tag + "/grad_colsum/" + name] = g.sum(0, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "g7_naml.npz"), **out)
+    print("g7", len(out), "arrays")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not present: fixtures can only be generated in the build container"
     sys.path.insert(0, REF)
@@ -271,6 +333,9 @@ if __name__ == "__main__":
     with tempfile.TemporaryDirectory() as td:
         os.chdir(td)            # the reference writes nothing, but keep its relative paths away from the repo
         try:
-            gen_g1(); gen_g2(); gen_g3(); gen_g4(); gen_g5(); gen_g6()
+            only = sys.argv[1:]
+            for name in ("g1", "g2", "g3", "g4", "g5", "g6", "g7"):
+                if not only or name in only:
+                    globals()["gen_" + name]()
         finally:
             os.chdir(cwd)

@@ -143,3 +143,50 @@ def test_dropout_keep_mask_semantics():
     zeros = {"embed": torch.zeros(n, L, d), "ctx": torch.ones(n, L, d)}
     s2, aux = orc.forward(p, batch, shape.num_attention_heads, p_drop=0.5, keep=zeros)
     assert torch.isfinite(s2).all()
+
+
+def naml_sample_rows(n_rows, k=32, seed=77):
+    """Same rows as tests/golden/gen_golden.py:naml_sample_rows."""
+    return np.sort(np.random.default_rng(seed).choice(n_rows, size=min(k, n_rows), replace=False))
+
+
+def check_naml_grads(g, tag, grads, names, rtol, atol, scale_floor=0.0):
+    """Gradients against fixture g7: small tensors in full, large matrices by sampled rows, row sums and column sums."""
+    for n in names:
+        got = grads[n]
+        if tag + "/grad/" + n in g:
+            want = g[tag + "/grad/" + n]
+            tol = atol + scale_floor * float(np.abs(want).max())
+            np.testing.assert_allclose(got, want, rtol=rtol, atol=tol, err_msg=n)
+        else:
+            want = g[tag + "/grad_rows/" + n]
+            tol = atol + scale_floor * float(np.abs(want).max())
+            np.testing.assert_allclose(got[naml_sample_rows(got.shape[0])], want, rtol=rtol, atol=tol, err_msg=n)
+            for axis, key in ((1, "grad_rowsum"), (0, "grad_colsum")):
+                w = g["%s/%s/%s" % (tag, key, n)]
+                np.testing.assert_allclose(got.sum(axis, dtype=np.float64), w, rtol=rtol,
+                                           atol=(atol + scale_floor * float(np.abs(w).max())) * 30, err_msg=n + " " + key)
+
+
+@pytest.mark.parametrize("tag", ["odd", "mind"])
+def test_g7_naml_forward_backward(golden_dir, tag):
+    """oracle/naml_oracle.py against the imported nrms_naml.Model (SURVEY f-3)."""
+    from oracle import naml_oracle as nml
+    g = load(golden_dir, "g7_naml.npz")
+    shape = synth.G7_ODD if tag == "odd" else synth.G7_MIND
+    params = synth.make_params_naml(shape, seed=21)
+    batch = synth.make_batch_naml(shape, seed=22)
+    assert batch["browsed_lens"][1] == 0 and not batch["browsed_absts"][0, 0].any() and batch["candidate_mask"][0, -1] == 0
+    p = nml.to_torch(params)
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    scores, parts = nml.forward(p, tb, shape.title_heads_num, shape.user_heads_num, parts=True)
+    np.testing.assert_allclose(scores.numpy(), g[tag + "/scores"], rtol=0, atol=2e-5)
+    for k in ("cand", "hist", "user"):
+        np.testing.assert_allclose(parts[k].numpy(), g[tag + "/" + k], rtol=0, atol=5e-6, err_msg=k)
+    scores, loss, grads = nml.loss_and_grads(params, batch, shape.title_heads_num, shape.user_heads_num)
+    assert abs(loss - float(g[tag + "/loss"])) < 5e-6
+    assert (scores[batch["candidate_mask"] == 0] == np.float32(-1e9)).all()
+    check_naml_grads(g, tag, grads, list(params), rtol=1e-4, atol=TOL, scale_floor=2e-6)   # fp32 rounding of a tensor's scale
+    for n in ("news_encoder.word_embedding.weight", "news_encoder.category_embedding.weight",
+              "news_encoder.subcategory_embedding.weight"):
+        assert not grads[n][0].any(), n                       # padding_idx = 0 (nrms_naml.py:107-111)
