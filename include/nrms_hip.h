@@ -71,10 +71,12 @@ extern "C" {
 typedef struct nrms_encoder_desc {
     int32_t  n_seq;        /* titles (B*(H+C)) or users (B) */
     int32_t  seq_len;      /* L or H, 1..64 */
-    int32_t  d_model;      /* config.word_embed_size; multiple of 4, <= 512; = n_heads * d_k */
-    int32_t  n_heads;      /* config.num_attention_heads (v1 news encoder: title_heads_num);
-                              d_k = d_model / n_heads even, <= 64 */
-    int32_t  q_dim;        /* config.query_vector_dim, multiple of 4, <= 256 */
+    int32_t  d_model;      /* config.word_embed_size (nrms_naml user encoder: news_feature_size); multiple of 4, <= 1024 */
+    int32_t  n_heads;      /* config.num_attention_heads (v1 / naml news encoder: title_heads_num; naml user encoder:
+                              user_heads_num); d_k = d_model / n_heads <= 128.  Even d_k <= 64 runs on the MFMA attention
+                              kernels, anything else on the shape-general fp32 kernel (csrc/wide.hip) */
+    int32_t  q_dim;        /* config.query_vector_dim (naml user encoder: query_vector_dim_large), multiple of 4, <= 512;
+                              above 256 (or d_model > 512) acts.t is required in inference too */
     int32_t  vocab;        /* rows of `table`, or 0 */
     float    p_drop_embed; /* dropout on the gathered embeddings (nrms_v0.py:137); 0 in eval / nrms_v1 */
     float    p_drop_ctx;   /* dropout on the attention output (nrms_v0.py:171-173; nrms_v1.py:161 after W_O) */
@@ -87,7 +89,9 @@ typedef struct nrms_encoder_desc {
     float    loss_scale;   /* NRMS_PRECISION_FP16 backward only: the fp16 gradient tensors are carried multiplied by this
                               power of two and the results divided by it (<= 0: 65536).  Pick ~128 x the global batch:
                               d(scores) is O(1/batch) and fp16 runs out of range below 6e-5 */
-    int32_t  reserved;     /* 0 */
+    float    p_drop_attn;  /* dropout on the attention PROBABILITIES (nrms_naml.py:36-39, dropout site 2; 0 in nrms_v0 /
+                              nrms_v1).  > 0 selects the shape-general attention kernel; not combinable with p_drop_ctx,
+                              NRMS_FLAG_PAD_ROW_ZERO or NRMS_PRECISION_FP16 */
 } nrms_encoder_desc;
 
 /* Parameters, in the reference's own tensor layout ([out,in] Linear weights).
@@ -213,8 +217,44 @@ int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, fl
 int nrms_impression_auc(int32_t n_imp, int32_t max_c, const float* scores, const uint8_t* labels,
                         const int32_t* lens, double* auc, void* stream);
 
+/* ---- nrms_naml pieces around the two encoder passes (model/nrms_naml.py) ----
+ * LayerNorm over the last dimension (nn.LayerNorm(news_feature_size) on the history vectors, nrms_naml.py:207,238):
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta, biased variance.  stats [n_rows, 2] = (mean, 1/std) is written when
+ * non-NULL (the backward needs it). */
+int nrms_layernorm_fwd(int64_t n_rows, int32_t d, const float* x, const float* gamma, const float* beta, float eps,
+                       float* y, float* stats, void* stream);
+size_t nrms_layernorm_bwd_workspace_bytes(int32_t d);
+/* dx [n_rows, d] is overwritten; d(gamma) [d] and d(beta) [d] are ACCUMULATED into dgamma_dbeta [2d] (gamma's gradient
+ * first: norm.weight and norm.bias are adjacent in the caller's flat gradient buffer).  Reproducible (fixed-order sums). */
+int nrms_layernorm_bwd(int64_t n_rows, int32_t d, const float* x, const float* gamma, const float* stats, const float* dy,
+                       float* dx, float* dgamma_dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* News feature rows (NewsEncoder.forward, nrms_naml.py:168-175):
+ * out[n] = dropout([title_vec[n] | abst_vec[n] | cat_table[categ[n]] | sub_table[subcateg[n]]]), dropout site 3 over
+ * [n, 2 d_text + 2 d_cat].  categ / subcateg: int64 [n], already validated (nrms_sanitize_ids with the table's row count). */
+typedef struct nrms_news_features {
+    int64_t n;               /* slots: B*(H+C) */
+    int32_t d_text;          /* config.word_embed_size */
+    int32_t d_cat;           /* config.cate_embed_size */
+    int32_t n_cat, n_sub;    /* config.category_nums, config.subcategory_nums (table rows; row 0 = padding_idx) */
+    float   p_drop;          /* config.dropout in training, 0 in eval */
+    uint64_t seed;
+    const float* title_vec;  /* [n, d_text] */
+    const float* abst_vec;   /* [n, d_text] */
+    const float* cat_table;  /* [n_cat, d_cat] */
+    const float* sub_table;  /* [n_sub, d_cat] */
+    const int64_t* categ;    /* [n] */
+    const int64_t* subcateg; /* [n] */
+} nrms_news_features;
+int nrms_news_features_fwd(const nrms_news_features* f, float* out, void* stream);
+/* dout [n, 2 d_text + 2 d_cat] -> d_title_vec, d_abst_vec [n, d_text] (overwritten); the table gradients are ACCUMULATED
+ * into d_cat_table / d_sub_table, row 0 (padding_idx = 0, nrms_naml.py:107-108) untouched; atomic-free. */
+int nrms_news_features_bwd(const nrms_news_features* f, const float* dout, float* d_title_vec, float* d_abst_vec,
+                           float* d_cat_table, float* d_sub_table, void* stream);
+
 /* The keep mask (1 = kept) the encoder kernels apply at a dropout site, for n_rows x d
- * elements: site 0 = embedding dropout (nrms_v0.py:137), site 1 = context dropout (:171-173).
+ * elements: site 0 = embedding dropout (nrms_v0.py:137), site 1 = context dropout (:171-173), site 2 = attention
+ * probabilities ([n_seq * n_heads * seq_len, seq_len], nrms_naml.py:36-39), site 3 = news feature rows (:175).
  * Lets a test replay a training step through the oracle with identical masks. */
 int nrms_dropout_keep_mask(uint64_t seed, int32_t site, int64_t n_rows, int32_t d, float p_drop,
                            uint8_t* keep, void* stream);

@@ -30,7 +30,7 @@ class EncoderDesc(C.Structure):
                 ("n_heads", C.c_int32), ("q_dim", C.c_int32), ("vocab", C.c_int32),
                 ("p_drop_embed", C.c_float), ("p_drop_ctx", C.c_float), ("precision", C.c_int32),
                 ("use_output_proj", C.c_int32), ("mask_mode", C.c_int32), ("flags", C.c_int32),
-                ("seed", C.c_uint64), ("loss_scale", C.c_float), ("reserved", C.c_int32)]
+                ("seed", C.c_uint64), ("loss_scale", C.c_float), ("p_drop_attn", C.c_float)]
 
 
 class EncoderWeights(C.Structure):
@@ -46,6 +46,12 @@ class EncoderGrads(C.Structure):
 class EncoderActs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("qkv", C.c_void_p), ("attn", C.c_void_p), ("ctx", C.c_void_p),
                 ("t", C.c_void_p), ("w", C.c_void_p), ("scratch", C.c_void_p)]
+
+
+class NewsFeatures(C.Structure):
+    _fields_ = [("n", C.c_int64), ("d_text", C.c_int32), ("d_cat", C.c_int32), ("n_cat", C.c_int32), ("n_sub", C.c_int32),
+                ("p_drop", C.c_float), ("seed", C.c_uint64), ("title_vec", C.c_void_p), ("abst_vec", C.c_void_p),
+                ("cat_table", C.c_void_p), ("sub_table", C.c_void_p), ("categ", C.c_void_p), ("subcateg", C.c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/nrms_hip.h declares.
@@ -76,6 +82,14 @@ SIGNATURES = {
                                       C.c_void_p]),
     "nrms_dropout_keep_mask": (C.c_int, [C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p,
                                          C.c_void_p]),
+    "nrms_layernorm_fwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "nrms_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "nrms_layernorm_bwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nrms_news_features_fwd": (C.c_int, [C.POINTER(NewsFeatures), C.c_void_p, C.c_void_p]),
+    "nrms_news_features_bwd": (C.c_int, [C.POINTER(NewsFeatures), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     "nrms_timing_enable": (None, [C.c_int]),
     "nrms_timing_reset": (None, []),
     "nrms_timing_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

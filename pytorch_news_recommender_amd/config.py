@@ -34,7 +34,10 @@ class Config(object):
         self.random_seed = 1998
         self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
+        self.category_nums = 18 + 1              # nrms_naml: rows of the category table, row 0 = padding (config.py:45)
         self.n_words = 45800
+        self.subcategory_nums = 293 + 1          # (config.py:47)
+        self.cate_embed_size = 100               # (config.py:49)
         self.word_embed_size = 300
         self.num_epochs = 5
         self.eval_step = 5000
@@ -51,6 +54,8 @@ class Config(object):
         self.skip_padding_tokens = True
 
     def __nrms__(self):
+        self.news_feature_size = 800             # nrms_naml: 2 * word_embed_size + 2 * cate_embed_size (config.py:68)
+        self.query_vector_dim_large = 400        # nrms_naml user encoder (config.py:72)
         self.query_vector_dim = 200
         self.title_heads_num = 6
         self.num_attention_heads = 10

@@ -21,6 +21,32 @@ int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, co
                             const float* T, float* ds, float* dq_partial, float* dq, const uint8_t* mask,
                             hipStream_t stream);
 
+// wide.hip: shape-general fp32 kernels (nrms_naml's widths, dropout on the attention probabilities)
+int launch_attention_wide(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& pdrop,
+                          const float* dctx, float* dqkv, const uint8_t* mask, hipStream_t stream);
+int launch_addattn_rows_fwd_wide(int n_seq, int S, int d, int q, float* T, const float* q_vec, const float* ctx,
+                                 const uint8_t* mask, float* wout, float* out, hipStream_t stream);
+int launch_addattn_rows_bwd_wide(int n_seq, int S, int d, int q, const float* ctx, const float* dout, const float* w,
+                                 const float* T, float* ds, float* dq_partial, float* dq, const uint8_t* mask,
+                                 hipStream_t stream);
+int launch_layernorm_fwd(long n_rows, int d, const float* x, const float* gamma, const float* beta, float eps, float* y,
+                         float* stats, hipStream_t stream);
+size_t layernorm_bwd_workspace_floats(int d);
+int launch_layernorm_bwd(long n_rows, int d, const float* x, const float* gamma, const float* stats, const float* dy,
+                         float* dx, float* dgamma_dbeta, float* workspace, hipStream_t stream);
+struct FeatArgs {
+    long n;
+    int dt, dc, n_cat, n_sub;
+    const float *title, *abst, *cat_table, *sub_table;
+    const int64_t *categ, *subcateg;
+    Dropout drop;
+    float* out;
+    const float* dout;
+    float *d_title, *d_abst, *d_cat_table, *d_sub_table;
+};
+int launch_features_fwd(const FeatArgs& a, hipStream_t stream);
+int launch_features_bwd(const FeatArgs& a, hipStream_t stream);
+
 // ---- error text -----------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
@@ -67,17 +93,30 @@ TimingScope::~TimingScope() {
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- encoder --------------------------------------------------------------------------
+// the MFMA attention kernels take even d_k <= 64 and drop the context; anything else goes to wide.hip
+static bool wide_attention(const nrms_encoder_desc* d) {
+    const int dk = d->n_heads > 0 ? d->d_model / d->n_heads : 0;
+    return dk > 64 || (dk & 1) != 0 || d->p_drop_attn > 0.f;
+}
+// the fused additive-attention forward holds q_dim <= 256 accumulator columns, the row backward d_model <= 512
+static bool wide_additive(const nrms_encoder_desc* d) { return d->q_dim > 256 || d->d_model > 512; }
+
 static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d != nullptr, "%s: null desc", who);
     NRMS_REQUIRE(d->n_seq >= 0, "%s: n_seq=%d", who, d->n_seq);
     NRMS_REQUIRE(d->seq_len >= 1 && d->seq_len <= 64, "%s: seq_len=%d outside 1..64", who, d->seq_len);
-    NRMS_REQUIRE(d->d_model > 0 && (d->d_model & 3) == 0 && d->d_model <= 512,
-                 "%s: d_model=%d must be a positive multiple of 4, <= 512", who, d->d_model);
+    NRMS_REQUIRE(d->d_model > 0 && (d->d_model & 3) == 0 && d->d_model <= 1024,
+                 "%s: d_model=%d must be a positive multiple of 4, <= 1024", who, d->d_model);
     NRMS_REQUIRE(d->n_heads > 0 && d->d_model % d->n_heads == 0, "%s: d_model %% n_heads != 0", who);
     const int dk = d->d_model / d->n_heads;
-    NRMS_REQUIRE(dk <= 64 && (dk & 1) == 0, "%s: d_k=%d must be even and <= 64", who, dk);
-    NRMS_REQUIRE(d->q_dim > 0 && (d->q_dim & 3) == 0 && d->q_dim <= 256, "%s: q_dim=%d must be a multiple of 4 <= 256",
+    NRMS_REQUIRE(dk <= 128, "%s: d_k=%d must be <= 128", who, dk);
+    NRMS_REQUIRE(d->q_dim > 0 && (d->q_dim & 3) == 0 && d->q_dim <= 512, "%s: q_dim=%d must be a multiple of 4 <= 512",
                  who, d->q_dim);
+    NRMS_REQUIRE(d->p_drop_attn >= 0.f && d->p_drop_attn < 1.f, "%s: p_drop_attn must be in [0,1)", who);
+    if (wide_attention(d))
+        NRMS_REQUIRE(!(d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO)) && d->p_drop_ctx == 0.f,
+                     "%s: d_k > 64, odd d_k or p_drop_attn > 0 (the shape-general attention) supports neither "
+                     "NRMS_FLAG_PAD_ROW_ZERO nor p_drop_ctx", who);
     NRMS_REQUIRE(d->vocab >= 0, "%s: vocab=%d", who, d->vocab);
     NRMS_REQUIRE(d->p_drop_embed >= 0.f && d->p_drop_embed < 1.f && d->p_drop_ctx >= 0.f && d->p_drop_ctx < 1.f,
                  "%s: dropout probabilities must be in [0,1)", who);
@@ -88,8 +127,8 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
         const char* why = nullptr;
         NRMS_REQUIRE(fused16_supported(d->seq_len, d->d_model, d->n_heads, d->q_dim, &why),
                      "%s: precision fp16 needs %s (use bf16x3 for this shape)", who, why);
-        NRMS_REQUIRE(d->use_output_proj == 0 && d->mask_mode == 0,
-                     "%s: precision fp16 supports neither the output projection nor masks (use bf16x3)", who);
+        NRMS_REQUIRE(d->use_output_proj == 0 && d->mask_mode == 0 && d->p_drop_attn == 0.f,
+                     "%s: precision fp16 supports neither the output projection, masks nor p_drop_attn (use bf16x3)", who);
     }
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
     NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV)) == 0, "%s: unknown flags 0x%x", who, d->flags);
@@ -140,7 +179,7 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     const size_t p2 = gemm_tn_workspace_floats((int)M, (int)q, (int)dm, nullptr);
     const size_t p3 = d->use_output_proj ? gemm_tn_workspace_floats((int)M, (int)dm, (int)dm, nullptr) : 0;
     w.tn_partial = take(p1 > p2 ? (p1 > p3 ? p1 : p3) : (p2 > p3 ? p2 : p3));
-    w.dq_partial = take((size_t)addattn_bwd_rows_waves(d->n_seq) * q);
+    w.dq_partial = take((size_t)(wide_additive(d) ? d->n_seq : addattn_bwd_rows_waves(d->n_seq)) * q);
     w.wplanes = take(wplane_bytes(d) / sizeof(float));
     const bool pz = d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO) != 0;
     w.live = take(d->vocab > 0 ? M : 0);          // int32 positions of the non-padding tokens (news encoder)
@@ -381,10 +420,14 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     if (rc) return rc;
     // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
     // concatenation, the output projection follows and carries the dropout in its epilogue.
-    rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
-                          wo ? no_drop : drop_c, nullptr, nullptr, amask,
-                          (gather && skip_pad_rows(desc)) ? ids : nullptr, (gather && skip_pad_rows(desc)) ? bq_hm : nullptr,
-                          nullptr, nullptr, nullptr, s);
+    if (wide_attention(desc))
+        rc = launch_attention_wide(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
+                                   make_dropout(desc->seed, desc->p_drop_attn), nullptr, nullptr, amask, s);
+    else
+        rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
+                              wo ? no_drop : drop_c, nullptr, nullptr, amask,
+                              (gather && skip_pad_rows(desc)) ? ids : nullptr, (gather && skip_pad_rows(desc)) ? bq_hm : nullptr,
+                              nullptr, nullptr, nullptr, s);
     if (rc) return rc;
     if (wo) {
         NTArgs o{};
@@ -392,6 +435,16 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
         o.A = acts->attn; o.lda = d; o.W = w->w_o; o.bias = w->b_o; o.C = acts->ctx; o.ldc = d; o.drop = drop_c;
         rc = nt_gemm(desc, A_PLAIN, E_STORE, o, wplanes, s, "out_proj_fwd");
         if (rc) return rc;
+    }
+    if (wide_additive(desc)) {
+        // Z = ctx Wa^T + ba by the plain NT GEMM into the T buffer, then tanh / scores / softmax / pooling per sequence
+        NRMS_REQUIRE(acts->t != nullptr, "encoder_fwd: acts.t is required for q_dim > 256 or d_model > 512 (also for inference)");
+        NTArgs z{};
+        z.M = M; z.N = q; z.K = d; z.rows_per_tile = NT_BM;
+        z.A = acts->ctx; z.lda = d; z.W = w->w_add; z.bias = w->b_add; z.C = acts->t; z.ldc = q;
+        rc = nt_gemm(desc, A_PLAIN, E_STORE, z, wplanes, s, "addattn_proj_fwd");
+        if (rc) return rc;
+        return launch_addattn_rows_fwd_wide(desc->n_seq, S, d, q, acts->t, w->q_vec, acts->ctx, pmask, acts->w, out, s);
     }
     const int npass = desc->precision == NRMS_PRECISION_FP32 ? 0 : (desc->precision == NRMS_PRECISION_BF16X3 ? 3 : 1);
     return launch_addattn_fwd(desc->n_seq, S, d, q, acts->ctx, w->w_add, w->b_add, w->q_vec, acts->t, acts->w, out,
@@ -486,8 +539,12 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     void* wplanes = (void*)(base + L.wplanes);
 
     // 1. pooling rows: ds, d(q_vec)
-    rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
-                                 pmask, s);
+    if (wide_additive(desc))
+        rc = launch_addattn_rows_bwd_wide(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
+                                          pmask, s);
+    else
+        rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
+                                     pmask, s);
     if (rc) return rc;
     // 2. d(ctx) = dZ Wa + w_s dout, then through the context-dropout mask in the GEMM's coalesced
     //    epilogue (one Philox call per float4) -- the attention backward then carries no RNG work.
@@ -545,9 +602,13 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         if (rc) return rc;
     }
     // 4. attention backward
-    rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask,
-                          nullptr, nullptr, compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
-                          compact ? grads->b_qkv : nullptr, s);
+    if (wide_attention(desc))
+        rc = launch_attention_wide(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr,
+                                   make_dropout(desc->seed, desc->p_drop_attn), dattn_in, dqkv, amask, s);
+    else
+        rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask,
+                              nullptr, nullptr, compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
+                              compact ? grads->b_qkv : nullptr, s);
     if (rc) return rc;
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings) -- or later,
     //    by nrms_encoder_bwd_wqkv (NRMS_FLAG_DEFER_WQKV)
@@ -575,6 +636,59 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
                                          (int*)(base + L.sscr), s);
     }
     return rc;
+}
+
+extern "C" int nrms_layernorm_fwd(int64_t n_rows, int32_t d, const float* x, const float* gamma, const float* beta, float eps,
+                                  float* y, float* stats, void* stream) {
+    NRMS_REQUIRE(n_rows >= 0 && d > 0 && eps > 0.f, "layernorm_fwd: n_rows=%ld d=%d eps=%g", (long)n_rows, d, (double)eps);
+    NRMS_REQUIRE(n_rows == 0 || (x && gamma && beta && y), "layernorm_fwd: null argument");
+    return launch_layernorm_fwd((long)n_rows, d, x, gamma, beta, eps, y, stats, (hipStream_t)stream);
+}
+
+extern "C" size_t nrms_layernorm_bwd_workspace_bytes(int32_t d) { return d > 0 ? layernorm_bwd_workspace_floats(d) * sizeof(float) : 0; }
+
+extern "C" int nrms_layernorm_bwd(int64_t n_rows, int32_t d, const float* x, const float* gamma, const float* stats,
+                                  const float* dy, float* dx, float* dgamma_dbeta, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    NRMS_REQUIRE(n_rows >= 0 && d > 0, "layernorm_bwd: n_rows=%ld d=%d", (long)n_rows, d);
+    NRMS_REQUIRE(n_rows == 0 || (x && gamma && stats && dy && dx && dgamma_dbeta && workspace), "layernorm_bwd: null argument");
+    if (workspace_bytes < nrms_layernorm_bwd_workspace_bytes(d)) {
+        set_error("layernorm_bwd: workspace %zu < required %zu bytes", workspace_bytes, nrms_layernorm_bwd_workspace_bytes(d));
+        return NRMS_EWORKSPACE;
+    }
+    return launch_layernorm_bwd((long)n_rows, d, x, gamma, stats, dy, dx, dgamma_dbeta, (float*)workspace, (hipStream_t)stream);
+}
+
+static int features_args(const nrms_news_features* f, FeatArgs* a, const char* who) {
+    NRMS_REQUIRE(f != nullptr, "%s: null descriptor", who);
+    NRMS_REQUIRE(f->n >= 0 && f->d_text > 0 && f->d_cat > 0 && f->n_cat > 0 && f->n_sub > 0, "%s: bad sizes", who);
+    NRMS_REQUIRE(f->p_drop >= 0.f && f->p_drop < 1.f, "%s: p_drop must be in [0,1)", who);
+    NRMS_REQUIRE((long)f->n * (2 * f->d_text + 2 * f->d_cat) < (1L << 40), "%s: too many elements", who);
+    NRMS_REQUIRE(f->n == 0 || (f->categ && f->subcateg), "%s: null ids", who);
+    a->n = (long)f->n; a->dt = f->d_text; a->dc = f->d_cat; a->n_cat = f->n_cat; a->n_sub = f->n_sub;
+    a->title = f->title_vec; a->abst = f->abst_vec; a->cat_table = f->cat_table; a->sub_table = f->sub_table;
+    a->categ = f->categ; a->subcateg = f->subcateg;
+    a->drop = make_dropout(f->seed, f->p_drop);
+    return NRMS_OK;
+}
+
+extern "C" int nrms_news_features_fwd(const nrms_news_features* f, float* out, void* stream) {
+    FeatArgs a{};
+    int rc = features_args(f, &a, "news_features_fwd");
+    if (rc) return rc;
+    NRMS_REQUIRE(f->n == 0 || (f->title_vec && f->abst_vec && f->cat_table && f->sub_table && out), "news_features_fwd: null argument");
+    a.out = out;
+    return launch_features_fwd(a, (hipStream_t)stream);
+}
+
+extern "C" int nrms_news_features_bwd(const nrms_news_features* f, const float* dout, float* d_title_vec, float* d_abst_vec,
+                                      float* d_cat_table, float* d_sub_table, void* stream) {
+    FeatArgs a{};
+    int rc = features_args(f, &a, "news_features_bwd");
+    if (rc) return rc;
+    NRMS_REQUIRE(f->n == 0 || (dout && d_title_vec && d_abst_vec && d_cat_table && d_sub_table), "news_features_bwd: null argument");
+    a.dout = dout; a.d_title = d_title_vec; a.d_abst = d_abst_vec; a.d_cat_table = d_cat_table; a.d_sub_table = d_sub_table;
+    return launch_features_bwd(a, (hipStream_t)stream);
 }
 
 extern "C" int nrms_sanitize_ids(const int64_t* src, int64_t* dst, int64_t n, int32_t vocab, int32_t* n_bad, void* stream) {

@@ -319,6 +319,8 @@ struct AddFwdArgs {
     const uint8_t* mask;   // optional [M]: masked_fill(mask == 0, -1e9) before the softmax (nrms_v1.py:100-101)
 };
 int launch_addattn_fwd_bf16(int npass, const AddFwdArgs& a, void* wplanes, hipStream_t stream);
+// out[c] += sum_r partial[r][c] in a fixed order (pool.hip)
+int launch_colsum_add(const float* partial, int rows, int cols, float* out, hipStream_t stream);
 
 // fused16.hip: fp16 mode.  One wavefront per sequence; weight planes prepared once per call.
 struct Fused16Layout { int KP, DP, QP; size_t wqkv16, wadd16, bqkv32, badd32, qv32, total; };   // byte offsets into `planes`

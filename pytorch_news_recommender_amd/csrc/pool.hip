@@ -243,8 +243,13 @@ int launch_addattn_bwd_rows(int n_seq, int S, int d, int q, const float* ctx, co
         int rc = check_launch("addattn_bwd_rows");
         if (rc) return rc;
     }
+    return launch_colsum_add(dq_partial, waves, q, dq, stream);
+}
+
+// out[c] += sum_r partial[r][c], rows summed in a fixed order
+int launch_colsum_add(const float* partial, int rows, int cols, float* out, hipStream_t stream) {
     TimingScope ts("colsum_add", stream);
-    hipLaunchKernelGGL(colsum_add_kernel, dim3(cdiv(q, 16)), dim3(1024), 0, stream, dq_partial, waves, q, dq);
+    hipLaunchKernelGGL(colsum_add_kernel, dim3(cdiv(cols, 16)), dim3(1024), 0, stream, partial, rows, cols, out);
     return check_launch("colsum_add");
 }
 

@@ -164,7 +164,7 @@ class NRMSEngine:
                                 precision=_lib.PRECISIONS[prec], use_output_proj=int(d.output_proj),
                                 mask_mode=int(mask_mode),
                                 flags=(_lib.NRMS_FLAG_PAD_ROW_ZERO if (self.pad_row_zero and enc == "news_encoder") else 0),
-                                seed=int(seed), loss_scale=float(self.loss_scale), reserved=0)
+                                seed=int(seed), loss_scale=float(self.loss_scale), p_drop_attn=0.0)
 
     def _ptrs(self, cls, flat, enc):
         b = self.layout.blocks[enc]

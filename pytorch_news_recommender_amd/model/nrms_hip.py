@@ -120,7 +120,7 @@ class Model(nn.Module):
             raise ValueError("embedding width %d != config.word_embed_size %d" % (d, config.word_embed_size))
         self._build_modules(config, table)
         self._dims = self._make_dims(config, int(V), int(d))
-        self._layout = FlatLayout(self._dims)
+        self._layout = self._make_layout(self._dims)
         self._names = self._layout.names
         named = dict(self.named_parameters())
         missing = [n for n in self._names if n not in named]
@@ -145,6 +145,12 @@ class Model(nn.Module):
     def _make_dims(self, config, V, d):
         return ModelDims(n_words=V, word_embed_size=d, num_attention_heads=int(config.num_attention_heads),
                          query_vector_dim=int(config.query_vector_dim))
+
+    def _make_layout(self, dims):
+        return FlatLayout(dims)
+
+    def _make_engine(self, device, precision):
+        return NRMSEngine(self._dims, device, precision=precision)
 
     # ---- flat parameter storage ----------------------------------------------------------
     def _flatten(self, device):
@@ -189,7 +195,7 @@ class Model(nn.Module):
                                  "(there is no CPU fallback)" % self._flat.device)
         prec = getattr(self.config, "precision", "fp32")
         if self._engine is None or self._engine.device != self._flat.device:
-            self._engine = NRMSEngine(self._dims, self._flat.device, precision=prec)
+            self._engine = self._make_engine(self._flat.device, prec)
         elif self._engine.precision != prec:
             self._engine.set_precision(prec)
         self._prepare_calls = getattr(self, "_prepare_calls", 0) + 1
