@@ -208,6 +208,20 @@ class SyntheticMind:
             noise = rng.integers(1, V, size=n)
             titles[i, :n] = np.where(rng.random(n) < 0.7, topical, noise)
         self.id2title_dict = {i: titles[i].tolist() for i in range(n_news)}
+        # abstracts (same topical vocabulary, config.n_words_abst words) and category / sub-category ids for nrms_naml:
+        # category = 1 + topic (0 is the padding slot), sub-category = a fixed refinement of it
+        # (their own generator: the title / behaviour streams stay what they were before the abstracts existed)
+        A = int(getattr(config, "n_words_abst", 40))
+        absts = np.zeros((n_news, A), dtype=np.int64)
+        rng2 = np.random.default_rng(seed + 1000003)
+        for i in range(n_news):
+            n = int(rng2.integers(min(8, A), A + 1))
+            lo = 1 + self.topic[i] * span
+            absts[i, :n] = np.where(rng2.random(n) < 0.6, rng2.integers(lo, lo + span, size=n), rng2.integers(1, V, size=n))
+        self.id2abst_dict = {i: absts[i].tolist() for i in range(n_news)}
+        n_cat, n_sub = int(getattr(config, "category_nums", 19)), int(getattr(config, "subcategory_nums", 294))
+        self.category = 1 + self.topic % max(n_cat - 1, 1)
+        self.subcategory = 1 + (self.topic * 7 + rng2.integers(0, 5, size=n_news)) % max(n_sub - 1, 1)
         self.n_topics = n_topics
         self.rng = rng
         self.by_topic = [np.flatnonzero(self.topic == t) + 1 for t in range(n_topics)]   # 1-based ids
@@ -225,8 +239,8 @@ class SyntheticMind:
         return out
 
     def train_samples(self, n_users):
-        """[history, None, None, [positive] + negatives, None, None] per user (positive first, as
-        the CE-with-label-0 loss of train_eval.py:116-117 expects)."""
+        """[history, its categories, its sub-categories, [positive] + negatives, their categories, their sub-categories] per
+        user (data_handler.py:40; positive first, as the CE-with-label-0 loss of train_eval.py:116-117 expects)."""
         cfg = self.config
         samples = []
         for _ in range(n_users):
@@ -234,8 +248,15 @@ class SyntheticMind:
             hist = self._pick(t, int(self.rng.integers(3, cfg.history_len + 1)))
             pos = self._pick(t, 1, p_in=1.0)
             neg = [int(x) for x in self.rng.integers(1, self.n_news + 1, size=cfg.sample_size)]
-            samples.append([hist, None, None, pos + neg, None, None])
+            imps = pos + neg
+            samples.append([hist, self._cat(hist), self._sub(hist), imps, self._cat(imps), self._sub(imps)])
         return samples
+
+    def _cat(self, news_ids):
+        return [int(self.category[i - 1]) for i in news_ids]
+
+    def _sub(self, news_ids):
+        return [int(self.subcategory[i - 1]) for i in news_ids]
 
     def eval_samples(self, n_imps, max_shown=40):
         """Impressions with 0/1 labels (>=1 of each), shown list shorter than max_candidate_size."""
@@ -249,6 +270,7 @@ class SyntheticMind:
             shown = self._pick(t, npos, p_in=1.0) + [int(x) for x in self.rng.integers(1, self.n_news + 1, size=n - npos)]
             y = [1] * npos + [0] * (n - npos)
             perm = self.rng.permutation(n)
-            samples.append([hist, None, None, [shown[i] for i in perm], None, None])
+            imps = [shown[i] for i in perm]
+            samples.append([hist, self._cat(hist), self._sub(hist), imps, self._cat(imps), self._sub(imps)])
             labels.append([y[i] for i in perm])
         return samples, labels

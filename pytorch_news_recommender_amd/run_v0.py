@@ -70,13 +70,13 @@ def main(argv=None):
         if rank == 0 and not os.path.exists(emb):
             np.savez(emb, embeddings=corpus.embedding_table(config.word_embed_size))
         parallel.barrier()
-        titles = corpus.id2title_dict
+        titles, absts = corpus.id2title_dict, corpus.id2abst_dict
         train_samples = corpus.train_samples(args.synthetic_users)
         dev_samples, dev_labels = corpus.eval_samples(1024)
     else:
         if args.dataset == 'demo':
             config.word_embedding_pretrained = 'demo_word_embedding.npz'       # run_demo.py:31
-        titles = None                                  # MyDataset loads news_title.pkl / news_words.csv itself
+        titles = absts = None                          # MyDataset loads news_title.pkl / news_words.csv itself
         demo = args.dataset == 'demo'
         train_samples = load_dataset(config, 'small_train.pkl' if demo else config.train_data, config.data_path, _type=0)
         dev_samples = load_dataset(config, 'small_dev.pkl' if demo else config.dev_data, config.data_path, _type=1)[:100000]
@@ -95,7 +95,7 @@ def main(argv=None):
         print(model_name, config.device, sum(p.numel() for p in recommender.parameters()), 'parameters')
 
     def loader(samples, typ, shuffle):
-        return DataLoader(MyDataset(config, samples, type=typ, id2title_dict=titles), batch_size=config.batch_size,
+        return DataLoader(MyDataset(config, samples, type=typ, id2title_dict=titles, id2abst_dict=absts), batch_size=config.batch_size,
                           num_workers=args.num_workers, drop_last=(world > 1 and typ == 0), shuffle=shuffle,
                           pin_memory=True)
 

@@ -213,3 +213,21 @@ def test_fused_train_step_is_forward_backward_adam(mode):
     for n in ("news_encoder.word_embedding.weight", "news_encoder.category_embedding.weight",
               "news_encoder.subcategory_embedding.weight"):
         assert torch.equal(model.state_dict()[n][0].cpu(), torch.from_numpy(params[n][0])), n
+
+
+def test_run_v0_entry_point_with_nrms_naml(tmp_path, monkeypatch):
+    """The reference's entry contract (run_v0.py --model nrms_naml -> model.Model(config, args) -> model.nrms_naml) on the
+    synthetic corpus: data_handler.MyDataset feeds titles, abstracts and category ids; a few training steps, a dev
+    evaluation, a checkpoint whose keys are the reference's behind the wrapper's ``model.`` prefix."""
+    from pytorch_news_recommender_amd import run_v0
+    monkeypatch.chdir(tmp_path)
+    hist = run_v0.main(["--model", "nrms_naml", "--dataset", "synthetic", "--epochs", "1", "--synthetic_users", "192",
+                        "--batch_size", "32", "--max_batches", "5", "--num_workers", "0", "--description", "T",
+                        "--data_path", str(tmp_path / "data_processed"), "--save_path", str(tmp_path / "save")])
+    assert len(hist["losses"]) == 5 and np.isfinite(hist["losses"]).all()
+    assert hist["aucs"] and 0.0 < hist["aucs"][-1][1] < 1.0
+    ckpts = [f for f in os.listdir(tmp_path / "save") if f.endswith(".ckpt")]
+    assert ckpts
+    sd = torch.load(os.path.join(tmp_path / "save", ckpts[0]), map_location="cpu", weights_only=True)
+    assert "model.norm.weight" in sd and "model.news_encoder.category_embedding.weight" in sd
+    assert sd["model.user_encoder.additive_attention.linear.weight"].shape == (400, 800)

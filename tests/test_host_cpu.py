@@ -362,3 +362,55 @@ def test_reference_side_binding_constructs_through_the_reference_wrapper(tmp_pat
     keys = [ln for ln in r.stdout.splitlines() if ln.startswith("KEYS ")][0].split()[1:]
     assert keys == sorted("model." + n for n in synth.param_names())
     assert "CLASS pytorch_news_recommender_amd.model.nrms_hip" in r.stdout
+
+
+def test_nrms_naml_wrapper_names_layout_and_loud_failure_on_cpu(tmp_path):
+    """SURVEY f-3: model.nrms_naml_hip.Model carries the 27 tensors of the reference's nrms_naml.Model.state_dict() (names,
+    order, shapes: fixture g7 was loaded into the reference with strict=True under these names), lays them out in one
+    flat buffer with the adjacencies the kernels rely on, is reachable through the dispatch wrapper, validates the
+    descriptor of its 800-wide user encoder without a GPU, and never computes on the CPU."""
+    import types
+    from pytorch_news_recommender_amd import model as model_pkg
+    from pytorch_news_recommender_amd.config import Config
+    from pytorch_news_recommender_amd.model.nrms_naml_hip import Model
+    shape = synth.G7_ODD
+    params = synth.make_params_naml(shape, seed=21)
+    cfg = Config("nrms_naml")
+    cfg.__nrms__()
+    assert (cfg.news_feature_size, cfg.query_vector_dim_large, cfg.user_heads_num, cfg.title_heads_num) == (800, 400, 8, 6)
+    assert (cfg.category_nums, cfg.subcategory_nums, cfg.cate_embed_size, cfg.n_words_abst) == (19, 294, 100, 40)
+    for k in ("word_embed_size", "title_heads_num", "query_vector_dim", "category_nums", "subcategory_nums",
+              "cate_embed_size", "user_heads_num", "query_vector_dim_large"):
+        setattr(cfg, k, getattr(shape, k))
+    cfg.news_feature_size = shape.news_feature_size
+    np.savez(tmp_path / "all_word_embedding_v3.npz", embeddings=params["news_encoder.word_embedding.weight"])
+    cfg.data_path = str(tmp_path) + "/"
+    m = Model(cfg)
+    sd = m.state_dict()
+    assert list(sd) == list(synth.naml_param_shapes(shape)) and len(sd) == 27
+    assert all(tuple(sd[k].shape) == v for k, v in synth.naml_param_shapes(shape).items())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    assert m._views_intact()
+    L = m._layout
+    for enc in ("news_encoder", "user_encoder"):
+        b, w = L.blocks[enc], m._dims.width(enc)
+        assert b["wk"] == b["wq"] + w * w and b["wv"] == b["wq"] + 2 * w * w and b["bk"] == b["bq"] + w and b["bv"] == b["bq"] + 2 * w
+    assert L.entries["norm.bias"][0] == L.entries["norm.weight"][0] + shape.news_feature_size
+    np.testing.assert_array_equal(L.view(m._flat, "norm.weight").numpy(), params["norm.weight"])
+    batch = {k: torch.from_numpy(v) for k, v in synth.make_batch_naml(shape, seed=22).items()}
+    with pytest.raises(_lib.NrmsError, match="no CPU fallback"):
+        m(batch)
+    cfg.news_feature_size += 4
+    with pytest.raises(ValueError, match="news_feature_size"):
+        Model(cfg)
+    cfg.news_feature_size -= 4
+    w = model_pkg.Model(cfg, types.SimpleNamespace(model="nrms_naml", n_GPUs=1))
+    assert list(w.state_dict()) == ["model." + k for k in synth.naml_param_shapes(shape)]
+    # the library accepts the real widths of the user encoder (d_model 800, d_k 100, q 400) and sizes its workspace
+    lib = _lib.load()
+    wide = _lib.EncoderDesc(n_seq=512, seq_len=50, d_model=800, n_heads=8, q_dim=400, vocab=0, precision=0,
+                            use_output_proj=1, p_drop_attn=0.2, seed=1)
+    assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(wide)) >= 4 * 512 * 50 * (800 * 5 + 1)
+    bad = _lib.EncoderDesc(n_seq=512, seq_len=50, d_model=800, n_heads=8, q_dim=400, vocab=0, precision=0,
+                           use_output_proj=1, p_drop_attn=0.2, p_drop_ctx=0.1, seed=1)
+    assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(bad)) == 0 and b"p_drop_ctx" in lib.nrms_last_error()
