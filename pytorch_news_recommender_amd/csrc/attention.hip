@@ -39,6 +39,8 @@ struct AttnArgs {
     uint32_t magic;         // ceil(2^20 / w2): idx / w2 == (idx * magic) >> 20 for idx < 2^20 / w2
     const uint8_t* mask;    // optional [n_seq, S]: v1's pairwise mask mask_i*mask_j -> masked_fill(-1e9)
                             // (model/nrms_v1.py:27-33); null = v0 (no mask at all)
+    Dropout pdrop;          // dropout on the attention PROBABILITIES (nrms_naml.py:36-39), site 2, element
+                            // ((seq * h + head) * S + query) * S + key; thresh 0 = none
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -242,6 +244,40 @@ __device__ __forceinline__ void softmax_cols(f32x16 (&st)[NS][NS], float scale, 
     }
 }
 
+// x^T[key j][query i] *= keep(i, j) / (1 - p): the probability-dropout mask of one (sequence, head) unit on a transposed
+// tile set.  A lane's registers 4g..4g+3 are four consecutive keys (crow32), i.e. four consecutive elements of the
+// flat [.., S, S] index when S is a multiple of 4: one Philox call per register group; otherwise one per element.
+template <int NS>
+__device__ __forceinline__ void prob_dropout(f32x16 (&xt)[NS][NS], const Dropout& pd, long unit, int S, int l32, int hh) {
+#pragma unroll
+    for (int it = 0; it < NS; ++it) {
+        const uint64_t row0 = (uint64_t)((unit * S + it * 32 + l32) * S);
+#pragma unroll
+        for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int j0 = jt * 32 + 8 * g + 4 * hh;
+                const uint64_t e0 = row0 + j0;
+                const f32x4 lo = dropout_scale4(pd.seed, 2u, e0 >> 2, pd.thresh, pd.inv_keep);
+                if ((S & 3) == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xt[jt][it][4 * g + e] *= lo[e];
+                } else {
+                    // the four keys straddle two Philox groups: elements sh..3 of this one, 0..sh-1 of the next
+                    // (selects, not an indexed array: that would live in scratch)
+                    const f32x4 hi = dropout_scale4(pd.seed, 2u, (e0 >> 2) + 1, pd.thresh, pd.inv_keep);
+                    const int sh = (int)(e0 & 3);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = e < 4 ? lo[e] : 0.f, a1 = e + 1 < 4 ? lo[e + 1] : hi[e + 1 - 4];
+                        const float a2 = e + 2 < 4 ? lo[e + 2] : hi[e + 2 - 4], a3 = e + 3 < 4 ? lo[e + 3] : hi[e + 3 - 4];
+                        xt[jt][it][4 * g + e] *= sh == 0 ? a0 : (sh == 1 ? a1 : (sh == 2 ? a2 : a3));
+                    }
+                }
+            }
+    }
+}
+
 // out^T[dd][i] = sum_j A[j][dd] X^T[j][i], X^T an accumulator tile set (keys in registers)
 template <int NS, int ND>
 __device__ __forceinline__ void at_x_tiles(const float* A, int RS, int l32, int hh, const f32x16 (&xt)[NS][NS],
@@ -378,6 +414,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
             f32x16 st[NS][NS];
             abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
             softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, Ms);
+            if (a.pdrop.thresh != 0u) prob_dropout<NS>(st, a.pdrop, u, a.S, l32, hh);
             f32x16 o[ND][NS];
             at_x_tiles<NS, ND>(Vs, RS, l32, hh, st, o);
             wave_sync();
@@ -535,6 +572,9 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         const float* msk = Ms;
         softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, msk);  // st = P^T
         abt_tiles<NS, ND>(Vs, Gs, RS, l32, hh, dp);         // dp = dP^T
+        // probability dropout: the product above is the gradient of the DROPPED probabilities; through the mask it is
+        // dP.  The mask is regenerated here and once more below (for dV) rather than kept in 16 NS^2 registers
+        if (a.pdrop.thresh != 0u) prob_dropout<NS>(dp, a.pdrop, u, a.S, l32, hh);
 #pragma unroll
         for (int it = 0; it < NS; ++it) {
             float D = 0.f;
@@ -556,6 +596,7 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         // dV^T = dO^T P  (queries summed: P through the transpose image, which may live in the dead V
         // region); dV stays in registers until that image has also served dK
         f32x16 dv[ND][NS];
+        if (a.pdrop.thresh != 0u) prob_dropout<NS>(st, a.pdrop, u, a.S, l32, hh);     // P is dead after dS: dV wants dropped P
         at_lds_transposed<NS, ND>(Gs, RS, Tb, st, l32, hh, dv);
         // dQ^T = K^T dS^T  (keys summed: dS^T straight from registers); K is dead afterwards -> stage dQ there
         {
@@ -715,9 +756,10 @@ static int launch_attn_inst(const AttnArgs& a, float* dbias, hipStream_t stream)
 // backward: pos / padsum / dbias (all three or none) = compact dQKV, see AttnArgs
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
                      const float* dctx, float* dqkv, const uint8_t* mask, const int64_t* ids, const float* bias_hm,
-                     const int* pos, float* padsum, float* dbias, hipStream_t stream) {
+                     const int* pos, float* padsum, float* dbias, hipStream_t stream, const Dropout* pdrop) {
     AttnArgs a;
     a.mask = mask;
+    a.pdrop = pdrop != nullptr ? *pdrop : make_dropout(0, 0.f);
     a.n_seq = n_seq; a.S = S; a.d = d; a.h = h; a.dk = d / h;
     a.scale = 1.0f / sqrtf((float)a.dk);
     a.qkv = qkv; a.ctx = ctx; a.drop = drop; a.dctx = dctx; a.dqkv = dqkv;

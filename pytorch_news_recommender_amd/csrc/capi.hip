@@ -11,7 +11,7 @@ namespace nrms {
 
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
                      const float* dctx, float* dqkv, const uint8_t* mask, const int64_t* ids, const float* bias_hm,
-                     const int* pos, float* padsum, float* dbias, hipStream_t stream);
+                     const int* pos, float* padsum, float* dbias, hipStream_t stream, const Dropout* pdrop = nullptr);
 size_t attention_padsum_floats();
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
                        const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, int npass,
@@ -93,10 +93,10 @@ TimingScope::~TimingScope() {
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- encoder --------------------------------------------------------------------------
-// the MFMA attention kernels take even d_k <= 64 and drop the context; anything else goes to wide.hip
+// the MFMA attention kernels take even d_k <= 64; anything else goes to wide.hip
 static bool wide_attention(const nrms_encoder_desc* d) {
     const int dk = d->n_heads > 0 ? d->d_model / d->n_heads : 0;
-    return dk > 64 || (dk & 1) != 0 || d->p_drop_attn > 0.f;
+    return dk > 64 || (dk & 1) != 0;
 }
 // the fused additive-attention forward holds q_dim <= 256 accumulator columns, the row backward d_model <= 512
 static bool wide_additive(const nrms_encoder_desc* d) { return d->q_dim > 256 || d->d_model > 512; }
@@ -115,8 +115,10 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d->p_drop_attn >= 0.f && d->p_drop_attn < 1.f, "%s: p_drop_attn must be in [0,1)", who);
     if (wide_attention(d))
         NRMS_REQUIRE(!(d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO)) && d->p_drop_ctx == 0.f,
-                     "%s: d_k > 64, odd d_k or p_drop_attn > 0 (the shape-general attention) supports neither "
-                     "NRMS_FLAG_PAD_ROW_ZERO nor p_drop_ctx", who);
+                     "%s: d_k > 64 or odd d_k (the shape-general attention) supports neither NRMS_FLAG_PAD_ROW_ZERO nor "
+                     "p_drop_ctx", who);
+    NRMS_REQUIRE(d->p_drop_attn == 0.f || !(d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO)),
+                 "%s: p_drop_attn is not combinable with NRMS_FLAG_PAD_ROW_ZERO (an all-padding title is no longer a closed form)", who);
     NRMS_REQUIRE(d->vocab >= 0, "%s: vocab=%d", who, d->vocab);
     NRMS_REQUIRE(d->p_drop_embed >= 0.f && d->p_drop_embed < 1.f && d->p_drop_ctx >= 0.f && d->p_drop_ctx < 1.f,
                  "%s: dropout probabilities must be in [0,1)", who);
@@ -420,14 +422,15 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     if (rc) return rc;
     // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
     // concatenation, the output projection follows and carries the dropout in its epilogue.
+    const Dropout pdrop_attn = make_dropout(desc->seed, desc->p_drop_attn);
     if (wide_attention(desc))
         rc = launch_attention_wide(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
-                                   make_dropout(desc->seed, desc->p_drop_attn), nullptr, nullptr, amask, s);
+                                   pdrop_attn, nullptr, nullptr, amask, s);
     else
         rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
                               wo ? no_drop : drop_c, nullptr, nullptr, amask,
                               (gather && skip_pad_rows(desc)) ? ids : nullptr, (gather && skip_pad_rows(desc)) ? bq_hm : nullptr,
-                              nullptr, nullptr, nullptr, s);
+                              nullptr, nullptr, nullptr, s, &pdrop_attn);
     if (rc) return rc;
     if (wo) {
         NTArgs o{};
@@ -602,13 +605,13 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         if (rc) return rc;
     }
     // 4. attention backward
+    const Dropout pdrop_attn = make_dropout(desc->seed, desc->p_drop_attn);
     if (wide_attention(desc))
-        rc = launch_attention_wide(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr,
-                                   make_dropout(desc->seed, desc->p_drop_attn), dattn_in, dqkv, amask, s);
+        rc = launch_attention_wide(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, pdrop_attn, dattn_in, dqkv, amask, s);
     else
         rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask,
                               nullptr, nullptr, compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
-                              compact ? grads->b_qkv : nullptr, s);
+                              compact ? grads->b_qkv : nullptr, s, &pdrop_attn);
     if (rc) return rc;
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings) -- or later,
     //    by nrms_encoder_bwd_wqkv (NRMS_FLAG_DEFER_WQKV)

@@ -20,11 +20,12 @@ static __device__ __forceinline__ void wave_fence() {
 }
 
 // =======================================================================================
-// Attention: one wavefront per (sequence, head).  Q, K, V (and dO) rows live in a wave-private LDS region;
-// a lane owns one key column of the score matrix, then one feature column of the products.
+// Attention: one workgroup (4 waves) per (sequence, head).  Q, K, V (and dO) rows and the S x S matrices live in LDS;
+// every product is a small matrix multiply done in 4 x 4 register blocks per thread (16 FMAs per 8 LDS reads), the
+// softmax rows are dealt to the waves.
 // =======================================================================================
 struct WideAttn {
-    int n_seq, S, d, h, dk, dkp, sp;      // dkp / sp: LDS row pitches (floats) of the [S][dk] operands / the [S][S] matrices
+    int n_seq, S, d, h, dk, dkp, sp;      // dkp / sp: LDS row pitches (floats, odd) of the [S][dk] operands / the [S][S] matrices
     float scale;
     const float* qkv;       // [M, 3d] head-major columns [head][Q | K | V][dk] (HeadPerm, common.h)
     float* ctx;             // fwd out [M, d]
@@ -32,48 +33,84 @@ struct WideAttn {
     float* dqkv;            // bwd out [M, 3d], head-major
     const uint8_t* mask;    // optional [n_seq, S]: pair (i, j) is masked unless mask_i and mask_j
     Dropout pdrop;          // site 2, element ((seq * h + head) * S + i) * S + j
-    int per_wave;           // floats of LDS per wave
 };
+
+// C(m, n) = sum_k A[m * am + k * ak] * B[n * bn + k * bk] for m < M, n < N, handed to `emit(m, n, value)`.
+// A thread owns rows m0..m0+3 and the columns {n0 + v * NB}: consecutive lanes walk consecutive n (odd pitches and
+// unit strides are both conflict-free), lanes of one row block share their A addresses (LDS broadcast).
+template <class Emit>
+static __device__ __forceinline__ void block_mm(const float* A, int am, int ak, const float* B, int bn, int bk, int M, int N,
+                                                int K, Emit emit) {
+    const int MB = (M + 3) >> 2, NB = (N + 3) >> 2;
+    for (int blk = threadIdx.x; blk < MB * NB; blk += blockDim.x) {
+        const int m0 = (blk / NB) * 4, n0 = blk % NB;
+        const float* ap[4];
+        const float* bp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ap[u] = A + min(m0 + u, M - 1) * am;
+            bp[u] = B + min(n0 + u * NB, N - 1) * bn;
+        }
+        float acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < K; ++k) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = ap[u][k * ak]; bv[u] = bp[u][k * bk]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (m0 + u < M && n0 + v * NB < N) emit(m0 + u, n0 + v * NB, acc[u][v]);
+    }
+}
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void attn_wide_kernel(WideAttn a) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wpb = blockDim.x >> 6;
     const int S = a.S, dk = a.dk, dkp = a.dkp, sp = a.sp;
-    float* Q = wsm + (long)wave * a.per_wave;
+    float* Q = wsm;
     float* K = Q + S * dkp;
     float* V = K + S * dkp;
-    float* Pd = V + S * dkp;               // dropped probabilities (fwd), later dS (bwd)
-    float* P = Pd + S * sp;                // bwd only
+    float* Pd = V + S * dkp;               // scores -> dropped probabilities (fwd); dP -> dS (bwd)
+    float* P = Pd + S * sp;                // bwd only: probabilities
     float* dO = P + S * sp;                // bwd only
     const long units = (long)a.n_seq * a.h;
-    for (long unit = (long)blockIdx.x * wpb + wave; unit < units; unit += (long)gridDim.x * wpb) {
+    for (long unit = blockIdx.x; unit < units; unit += gridDim.x) {
         const long seq = unit / a.h;
         const int head = (int)(unit - seq * a.h);
         const long row0 = seq * S;
-        for (int idx = lane; idx < S * 3 * dk; idx += 64) {
+        for (int idx = threadIdx.x; idx < S * 3 * dk; idx += blockDim.x) {
             const int i = idx / (3 * dk), c = idx - i * 3 * dk;
             const int which = c / dk, j = c - which * dk;
             Q[which * S * dkp + i * dkp + j] = a.qkv[(row0 + i) * 3 * a.d + head * 3 * dk + c];
         }
         if (BWD)
-            for (int idx = lane; idx < S * dk; idx += 64) {
+            for (int idx = threadIdx.x; idx < S * dk; idx += blockDim.x) {
                 const int i = idx / dk, j = idx - i * dk;
                 dO[i * dkp + j] = a.dctx[(row0 + i) * a.d + head * dk + j];
             }
-        wave_fence();
-        // ---- P[i][j], lane = key j
+        __syncthreads();
+        // scores[i][j] = Q_i . K_j
+        float* Sc = BWD ? P : Pd;
+        block_mm(Q, dkp, 1, K, dkp, 1, S, S, dk, [&](int i, int j, float v) { Sc[i * sp + j] = v; });
+        __syncthreads();
+        // softmax over the keys of each query row (one wave per row, lane = key), then the probability dropout
         const bool jok = lane < S;
-        const float* kr = K + (jok ? lane : 0) * dkp;
         const bool mj = a.mask == nullptr || (jok && a.mask[row0 + lane] != 0);
-        for (int i = 0; i < S; ++i) {
-            const float* qr = Q + i * dkp;
-            float dot = 0.f;
-            for (int c = 0; c < dk; ++c) dot += qr[c] * kr[c];
-            float s = dot * a.scale;
-            if (a.mask != nullptr && !(mj && a.mask[row0 + i] != 0)) s = -1e9f;
-            if (!jok) s = -3.0e38f;
+        for (int i = wave; i < S; i += 4) {
+            float s = jok ? Sc[i * sp + lane] * a.scale : -3.0e38f;
+            if (jok && a.mask != nullptr && !(mj && a.mask[row0 + i] != 0)) s = -1e9f;
             const float mx = wave_max(s);
             const float e = jok ? expf(s - mx) : 0.f;
             const float p = e / wave_sum(e);
@@ -85,68 +122,36 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(WideAttn a) {
                 if (BWD) P[i * sp + lane] = p;
             }
         }
-        wave_fence();
+        __syncthreads();
         if (!BWD) {
-            // ctx[i][c] = sum_j Pd[i][j] V[j][c], lanes over c
-            for (int c0 = 0; c0 < dk; c0 += 64) {
-                const int c = c0 + lane;
-                const bool cok = c < dk;
-                const float* vc = V + (cok ? c : 0);
-                for (int i = 0; i < S; ++i) {
-                    float o = 0.f;
-                    for (int j = 0; j < S; ++j) o += Pd[i * sp + j] * vc[j * dkp];
-                    if (cok) a.ctx[(row0 + i) * a.d + head * dk + c] = o;
-                }
-            }
+            // ctx[i][c] = sum_j Pd[i][j] V[j][c]
+            float* out = a.ctx + row0 * a.d + head * dk;
+            block_mm(Pd, sp, 1, V, 1, dkp, S, dk, S, [&](int i, int c, float v) { out[(long)i * a.d + c] = v; });
         } else {
             float* out = a.dqkv + row0 * 3 * a.d + head * 3 * dk;
             // dV[j][c] = sum_i Pd[i][j] dO[i][c]
-            for (int c0 = 0; c0 < dk; c0 += 64) {
-                const int c = c0 + lane;
-                const bool cok = c < dk;
-                const float* oc = dO + (cok ? c : 0);
-                for (int j = 0; j < S; ++j) {
-                    float o = 0.f;
-                    for (int i = 0; i < S; ++i) o += Pd[i * sp + j] * oc[i * dkp];
-                    if (cok) out[(long)j * 3 * a.d + 2 * dk + c] = o;
-                }
-            }
-            wave_fence();
-            // dS[i][j] = P (dP - sum_j dP P) * scale, dP = (dO V^T) * keep; lane = key j.  Overwrites Pd.
-            const float* vr = V + (jok ? lane : 0) * dkp;
-            for (int i = 0; i < S; ++i) {
-                const float* orow = dO + i * dkp;
-                float dp = 0.f;
-                for (int c = 0; c < dk; ++c) dp += orow[c] * vr[c];
+            block_mm(Pd, 1, sp, dO, 1, dkp, S, dk, S, [&](int j, int c, float v) { out[(long)j * 3 * a.d + 2 * dk + c] = v; });
+            __syncthreads();
+            // dPd[i][j] = dO_i . V_j  (overwrites Pd)
+            block_mm(dO, dkp, 1, V, dkp, 1, S, S, dk, [&](int i, int j, float v) { Pd[i * sp + j] = v; });
+            __syncthreads();
+            // dS = P (dP - sum_j dP P) * scale, dP = dPd * keep
+            for (int i = wave; i < S; i += 4) {
+                float dp = jok ? Pd[i * sp + lane] : 0.f;
                 if (a.pdrop.thresh != 0u)
                     dp *= dropout_scale1(a.pdrop.seed, 2u, (uint64_t)((unit * S + i) * S + lane), a.pdrop.thresh, a.pdrop.inv_keep);
                 const float p = jok ? P[i * sp + lane] : 0.f;
-                if (!jok) dp = 0.f;
                 const float delta = wave_sum(dp * p);
                 float ds = p * (dp - delta) * a.scale;
                 if (a.mask != nullptr && !(mj && a.mask[row0 + i] != 0)) ds = 0.f;     // masked_fill passes no gradient
                 if (jok) Pd[i * sp + lane] = ds;
             }
-            wave_fence();
+            __syncthreads();
             // dQ[i][c] = sum_j dS[i][j] K[j][c];  dK[j][c] = sum_i dS[i][j] Q[i][c]
-            for (int c0 = 0; c0 < dk; c0 += 64) {
-                const int c = c0 + lane;
-                const bool cok = c < dk;
-                const float* kc = K + (cok ? c : 0);
-                const float* qc = Q + (cok ? c : 0);
-                for (int i = 0; i < S; ++i) {
-                    float o = 0.f;
-                    for (int j = 0; j < S; ++j) o += Pd[i * sp + j] * kc[j * dkp];
-                    if (cok) out[(long)i * 3 * a.d + c] = o;
-                }
-                for (int j = 0; j < S; ++j) {
-                    float o = 0.f;
-                    for (int i = 0; i < S; ++i) o += Pd[i * sp + j] * qc[i * dkp];
-                    if (cok) out[(long)j * 3 * a.d + dk + c] = o;
-                }
-            }
+            block_mm(Pd, sp, 1, K, 1, dkp, S, dk, S, [&](int i, int c, float v) { out[(long)i * 3 * a.d + c] = v; });
+            block_mm(Pd, 1, sp, Q, 1, dkp, S, dk, S, [&](int j, int c, float v) { out[(long)j * 3 * a.d + dk + c] = v; });
         }
-        wave_fence();
+        __syncthreads();
     }
 }
 
@@ -159,24 +164,19 @@ int launch_attention_wide(bool bwd, int n_seq, int S, int d, int h, const float*
         set_error("attention (wide): unsupported S=%d d_k=%d (need 1<=S<=64, d_k<=128)", S, a.dk);
         return NRMS_EINVAL;
     }
-    a.dkp = a.dk | 1;                      // odd pitch: lanes reading one column of consecutive rows hit distinct banks
+    a.dkp = a.dk | 1;                      // odd pitches: a lane per row of one column hits distinct banks
     a.sp = S | 1;
     a.scale = 1.0f / sqrtf((float)a.dk);
     a.qkv = qkv; a.ctx = ctx; a.dctx = dctx; a.dqkv = dqkv; a.mask = mask; a.pdrop = pdrop;
-    a.per_wave = ((bwd ? 4 : 3) * S * a.dkp + (bwd ? 2 : 1) * S * a.sp + 3) & ~3;
-    const size_t per_wave_b = (size_t)a.per_wave * sizeof(float);
-    int wpb = (int)((size_t)(144 << 10) / per_wave_b);
-    if (wpb > 4) wpb = 4;
-    if (wpb < 1) { set_error("attention (wide): S=%d d_k=%d needs %zu bytes of LDS per wave", S, a.dk, per_wave_b); return NRMS_EINVAL; }
-    const size_t lds = per_wave_b * wpb;
+    const size_t lds = (size_t)((bwd ? 4 : 3) * S * a.dkp + (bwd ? 2 : 1) * S * a.sp) * sizeof(float);
     const void* fn = bwd ? (const void*)attn_wide_kernel<true> : (const void*)attn_wide_kernel<false>;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("attention (wide): hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
-    long blocks = cdiv((long)n_seq * h, wpb);
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    TimingScope ts(bwd ? "attn_bwd" : "attn_fwd", stream);
-    if (bwd) hipLaunchKernelGGL(attn_wide_kernel<true>, dim3((int)blocks), dim3(64 * wpb), lds, stream, a);
-    else hipLaunchKernelGGL(attn_wide_kernel<false>, dim3((int)blocks), dim3(64 * wpb), lds, stream, a);
+    long blocks = (long)n_seq * h;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    TimingScope ts(bwd ? "wide_attn_bwd" : "wide_attn_fwd", stream);
+    if (bwd) hipLaunchKernelGGL(attn_wide_kernel<true>, dim3((int)blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(attn_wide_kernel<false>, dim3((int)blocks), dim3(256), lds, stream, a);
     return check_launch("attention_wide");
 }
 
