@@ -201,6 +201,28 @@ def eval_path_leg(model, dev):
     return ev
 
 
+def naml_leg(dev, B):
+    """SURVEY f-3: one nrms_naml train step (model/nrms_naml.py) at the reference's own shapes -- title 20 and abstract
+    40 words through the shared word-level encoder (6 heads, W_O), 100-wide category embeddings, LayerNorm, the 800-wide
+    user encoder (8 heads, q = 400), dropout 0.2 -- in the bf16x3 mode (no fused fp16 kernels for this topology yet)."""
+    from pytorch_news_recommender_amd.model.nrms_naml_hip import Model as NamlModel
+    shape = synth.NamlShape(batch_size=B)
+    cfg = Config("nrms_naml")
+    cfg.__nrms__()
+    cfg.dropout, cfg.learning_rate, cfg.precision = 0.2, 1e-3, "bf16x3"
+    params = synth.make_params_naml(shape, seed=0)
+    m = NamlModel(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev).train()
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch_naml(shape, seed=1).items()}
+    for _ in range(2):
+        m.train_step(batch)
+    n = 4
+    t = timed(lambda: m.train_step(batch), n)
+    return {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n, "precision": "bf16x3",
+            "workload": "B=%d, H=50, C=5, title 20 + abstract 40 words, d=300, news_feature_size=800" % B}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,6 +468,10 @@ def main():
         except Exception as e:
             modes["error"] = repr(e)
         out["modes"] = modes
+        try:
+            out["variants"] = {"nrms_naml": naml_leg(dev, B)}
+        except Exception as e:       # secondary leg only
+            out["variants"] = {"error": repr(e)}
         try:
             out["eval_path"] = eval_path_leg(model, dev)
         except Exception as e:       # secondary leg only: never lose the headline line
