@@ -47,7 +47,8 @@ extern "C" {
                                    Restrictions: seq_len <= 64, d_model <= 316, d_k <= 32, n_heads <= 10, q_dim <= 224,
                                    no output projection, no masks (NRMS_EINVAL otherwise).  Activation buffers change
                                    meaning (see nrms_encoder_acts); context-dropout counters run over the padded
-                                   [M, NRMS_FP16_DP] layout, 32 columns per head (nrms_dropout_keep_mask with d = 320). */
+                                   [M, NRMS_FP16_DP] layout, 32 columns per head, in the 16-bit-field scheme
+                                   (nrms_dropout_keep_mask with d = 320 and site 1 | NRMS_DROPOUT_FIELDS16). */
 
 /* nrms_encoder_desc.flags */
 /* The caller guarantees that row 0 of `table` (the padding row, nn.Embedding padding_idx=0,
@@ -255,6 +256,11 @@ int nrms_news_features_bwd(const nrms_news_features* f, const float* dout, float
  * elements: site 0 = embedding dropout (nrms_v0.py:137), site 1 = context dropout (:171-173), site 2 = attention
  * probabilities ([n_seq * n_heads * seq_len, seq_len], nrms_naml.py:36-39), site 3 = news feature rows (:175).
  * Lets a test replay a training step through the oracle with identical masks. */
+#define NRMS_DROPOUT_FIELDS16 0x100   /* or-ed into `site`: the 16-bit-field scheme of the fp16 mode's context dropout --
+                                        one Philox call per 8 elements of the flat [n_rows, d] layout, P(drop) = p rounded
+                                        down to a multiple of 2^-16.  The fp16 kernels apply it over the padded [tokens, 320]
+                                        layout with the two middle bits of a column's index inside its 32-column head block
+                                        swapped: mask of column 16a + 8b + 4c + e = field at 16a + 8c + 4b + e */
 int nrms_dropout_keep_mask(uint64_t seed, int32_t site, int64_t n_rows, int32_t d, float p_drop,
                            uint8_t* keep, void* stream);
 

@@ -17,6 +17,7 @@ NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1
 NRMS_PRECISION_BF16 = 2
 NRMS_PRECISION_FP16 = 3
+NRMS_DROPOUT_FIELDS16 = 0x100
 NRMS_FP16_KP, NRMS_FP16_DP, NRMS_FP16_QP = 320, 320, 224     # fixed activation pitches of the fp16 mode (include/nrms_hip.h)
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 

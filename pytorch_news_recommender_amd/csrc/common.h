@@ -81,6 +81,23 @@ __device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, uint32_t site, ui
     s[3] = r[3] >= thresh ? inv_keep : 0.f;
     return s;
 }
+// 16-bit fields: ONE Philox call decides 8 elements (field k of the call = bits 16 (k & 1) .. of word k >> 1; keep <=> field
+// >= p * 2^16).  The 32-bit integer multiplies of Philox are quarter rate: in the fused fp16 kernels the context dropout
+// was a tenth of the forward.  P(drop) is p rounded down to a multiple of 2^-16.
+__host__ __device__ __forceinline__ uint32_t drop_threshold16(float p) {
+    const double t = (double)p * 65536.0;
+    return t <= 0.0 ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
+}
+__device__ __forceinline__ void dropout_scale8(uint64_t seed, uint32_t site, uint64_t group8, uint32_t thresh16, float inv_keep,
+                                               float (&s)[8]) {
+    uint32_t r[4];
+    philox4x32_7(seed, group8, site, r);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        s[2 * w] = (r[w] & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
+        s[2 * w + 1] = (r[w] >> 16) >= thresh16 ? inv_keep : 0.f;
+    }
+}
 // single element (row-major [rows,d], d % 4 == 0)
 __device__ __forceinline__ float dropout_scale1(uint64_t seed, uint32_t site, uint64_t elem,
                                                 uint32_t thresh, float inv_keep) {
@@ -121,12 +138,14 @@ struct Dropout {
     uint64_t seed;
     uint32_t thresh;     // 0 => disabled
     float inv_keep;
+    uint32_t thresh16;   // the same probability for the 16-bit-field scheme (dropout_scale8)
 };
 
 inline Dropout make_dropout(uint64_t seed, float p) {
     Dropout d;
     d.seed = seed;
     d.thresh = drop_threshold(p);
+    d.thresh16 = drop_threshold16(p);
     d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return d;
 }

@@ -191,12 +191,15 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
             if (a.drop.thresh != 0u) {
+                // two Philox calls for the lane's 16 values: registers 8c..8c+7 take the 8 fields of group
+                // (token row, 16-column half c of the head, lane half) -- see nrms_dropout_keep_mask, site 1 | 0x100
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint64_t e0 = (uint64_t)(tok0 + 32 * b + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
-                    const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+                for (int c = 0; c < 2; ++c) {
+                    const uint64_t e0 = (uint64_t)(tok0 + 32 * b + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 16 * c + 8 * hh);
+                    float sc[8];
+                    dropout_scale8(a.drop.seed, 1u, e0 >> 3, a.drop.thresh16, a.drop.inv_keep, sc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ct[b][4 * g + e] *= sc[e];
+                    for (int e = 0; e < 8; ++e) ct[b][8 * c + e] *= sc[e];
                 }
             }
             if (valid) {                                        // rows beyond the sequence are stored too: zeros

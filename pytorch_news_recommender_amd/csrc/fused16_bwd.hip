@@ -216,11 +216,12 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                 }
                 if (a.drop.thresh != 0u) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint64_t e0 = (uint64_t)(tok0 + 32 * b + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 8 * g + 4 * hh);
-                        const f32x4 sc = dropout_scale4(a.drop.seed, 1u, e0 >> 2, a.drop.thresh, a.drop.inv_keep);
+                    for (int c = 0; c < 2; ++c) {               // the forward's mask: same two calls per lane
+                        const uint64_t e0 = (uint64_t)(tok0 + 32 * b + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 16 * c + 8 * hh);
+                        float sc[8];
+                        dropout_scale8(a.drop.seed, 1u, e0 >> 3, a.drop.thresh16, a.drop.inv_keep, sc);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dct[4 * g + e] *= sc[e];
+                        for (int e = 0; e < 8; ++e) dct[8 * c + e] *= sc[e];
                     }
                 }
                 if (live && !(a.dbg & 4)) {                     // (zero beyond the sequence: dZ and w are 0 there); the

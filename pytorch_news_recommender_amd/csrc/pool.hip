@@ -371,6 +371,19 @@ __global__ void keep_mask_kernel(uint64_t seed, uint32_t site, long groups, uint
     reinterpret_cast<uchar4*>(keep)[i] = k;
 }
 
+// 16-bit-field scheme (dropout_scale8): element i of the flat layout takes field i & 7 of call i >> 3
+__global__ void keep_mask16_kernel(uint64_t seed, uint32_t site, long groups8, uint32_t thresh16, uint8_t* keep) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups8) return;
+    uint32_t r[4];
+    philox4x32_7(seed, (uint64_t)i, site, r);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        keep[8 * i + 2 * w] = (r[w] & 0xFFFFu) >= thresh16;
+        keep[8 * i + 2 * w + 1] = (r[w] >> 16) >= thresh16;
+    }
+}
+
 // Per-impression ROC-AUC on the un-padded prefix (train_eval.py:219-227 `auc_score(y_true,
 // rank_score[i][:len(y_true)])`, evaluation.py:26-27 = sklearn roc_auc_score): the Mann-Whitney
 // statistic  (#{pos > neg} + 0.5 #{pos == neg}) / (n_pos n_neg)  counted exactly in integers and
@@ -493,6 +506,12 @@ extern "C" int nrms_dropout_keep_mask(uint64_t seed, int32_t site, int64_t n_row
     const long groups = (long)n_rows * d / 4;
     if (groups == 0) return NRMS_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (site & NRMS_DROPOUT_FIELDS16) {
+        NRMS_REQUIRE((d & 7) == 0, "dropout_keep_mask: the 16-bit-field scheme needs d %% 8 == 0");
+        hipLaunchKernelGGL(keep_mask16_kernel, dim3(cdiv(groups / 2, 256)), dim3(256), 0, s, seed, (uint32_t)(site & 0xFF), groups / 2,
+                           drop_threshold16(p_drop), keep);
+        return check_launch("keep_mask16");
+    }
     hipLaunchKernelGGL(keep_mask_kernel, dim3(cdiv(groups, 256)), dim3(256), 0, s, seed, (uint32_t)site, groups,
                        drop_threshold(p_drop), keep);
     return check_launch("keep_mask");

@@ -544,15 +544,23 @@ class NRMSEngine:
             cand_mask = cand_mask.contiguous()
         return self.click_scores_indexed(st["vec"], news[B * H:].to(torch.int32), user, B, Cn, cand_mask)
 
-    def dropout_keep_mask(self, seed, site, n_rows, p_drop, d=None):
-        """Keep mask of a dropout site over [n_rows, d] (d defaults to the model width; the fp16 mode's context
-        dropout runs over the padded width 32 * n_heads)."""
+    def dropout_keep_mask(self, seed, site, n_rows, p_drop, d=None, fp16_ctx=False):
+        """Keep mask of a dropout site over [n_rows, d] (d defaults to the model width).  fp16_ctx: the context dropout
+        of the fp16 mode -- padded width 320 (32 columns per head), 16-bit-field scheme, the two middle index bits of a
+        column inside its head block swapped (include/nrms_hip.h, NRMS_DROPOUT_FIELDS16); returned in natural column order."""
         d = self.dims.word_embed_size if d is None else int(d)
+        if fp16_ctx:
+            d, site = _lib.NRMS_FP16_DP, site | _lib.NRMS_DROPOUT_FIELDS16
         keep = torch.empty(n_rows * d, dtype=torch.uint8, device=self.device)
         rc = self.lib.nrms_dropout_keep_mask(C.c_uint64(seed), site, C.c_int64(n_rows), d, C.c_float(p_drop),
                                              _lib.ptr(keep), _stream())
         _lib.check(rc, "nrms_dropout_keep_mask")
-        return keep.view(n_rows, d)
+        keep = keep.view(n_rows, d)
+        if fp16_ctx:
+            col = torch.arange(d, device=self.device)
+            a, b, c, e = col >> 4, (col >> 3) & 1, (col >> 2) & 1, col & 3
+            keep = keep.index_select(1, 16 * a + 8 * c + 4 * b + e)
+        return keep
 
     # ---- timing (bench.py roofline leg) --------------------------------------------------
     def timing(self, enable: bool):

@@ -112,7 +112,7 @@ def test_fp16_train_mode_forward_replays_its_dropout_masks():
     n_titles = shape.batch_size * (shape.history_len + shape.n_candidates)
     L, d, h = shape.n_words_title, shape.word_embed_size, shape.num_attention_heads
     ke = eng.dropout_keep_mask(seed, 0, n_titles * L, 0.2).cpu().view(n_titles, L, d)
-    kc_pad = eng.dropout_keep_mask(seed, 1, n_titles * L, 0.2, d=320).cpu().numpy()
+    kc_pad = eng.dropout_keep_mask(seed, 1, n_titles * L, 0.2, fp16_ctx=True).cpu().numpy()
     kc = torch.from_numpy(_padded_to_model_cols(kc_pad, h, d // h)).view(n_titles, L, d)
     assert 0.77 < float(kc.float().mean()) < 0.83
     pt = orc.to_torch(params)
@@ -215,7 +215,7 @@ def test_fp16_forward_backward_against_oracle(case):
         n_titles = shape.batch_size * (shape.history_len + shape.n_candidates)
         L, d, h = shape.n_words_title, shape.word_embed_size, shape.num_attention_heads
         ke = model.engine.dropout_keep_mask(sv["seed"], 0, n_titles * L, p_drop).cpu().view(n_titles, L, d)
-        kc = model.engine.dropout_keep_mask(sv["seed"], 1, n_titles * L, p_drop, d=320).cpu().numpy()
+        kc = model.engine.dropout_keep_mask(sv["seed"], 1, n_titles * L, p_drop, fp16_ctx=True).cpu().numpy()
         keep = {"embed": ke, "ctx": torch.from_numpy(_padded_to_model_cols(kc, h, d // h)).view(n_titles, L, d)}
     o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads, p_drop=p_drop, keep=keep)
     valid = batch["candidate_mask"] == 1
