@@ -87,11 +87,67 @@ struct TileRing {
     }
 };
 
+// ---- the same ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass, and a tile has
+// two whole steps to arrive instead of one).  A DMA instruction writes 64 lanes x 16 B = one contiguous KiB of LDS, so the
+// tile is stored in HBM in the order its fragments are read: [k-step s][lane half hh][row l32][8 halves] -- the fragment
+// read of a wave is then one contiguous KiB too (conflict-free without padding).  Tile n + 2 is issued at the top of step
+// n; at the end of step n every wave waits until only those five newest loads are outstanding (in-order counter: tile
+// n + 1 has landed) and meets the others at a raw s_barrier (__syncthreads() would drain the DMA with vmcnt(0)).
+constexpr int F16_SLOT_DMA = 32 * F16_KP * 2;
+static_assert(F16_SLOT_DMA == 5 * F16_WAVES * 1024, "five 1-KiB DMA pieces per wave and tile");
+struct TileRingDMA {
+    char* smem;
+    const _Float16* src;          // tiles are contiguous [n_tiles][KS][2][32][8]
+    int n_tiles, wave, lane, l32, hh;
+    __device__ __forceinline__ void load(int n) {
+        if (n >= n_tiles) return;
+        const char* g = reinterpret_cast<const char*>(src) + (long)n * F16_SLOT_DMA + wave * 1024 + lane * 16;
+        char* l = smem + (n % 3) * F16_SLOT_DMA + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * (F16_WAVES * 1024)),
+                                             (__attribute__((address_space(3))) void*)(l + i * (F16_WAVES * 1024)), 16, 0, 0);
+    }
+    // piece i (0..4) of tile n alone: issued between MFMA groups, where the instruction's issue cost hides under the
+    // matrix pipe (five back-to-back DMA issues in front of a tile's MFMAs cost as much as the staging they replaced)
+    __device__ __forceinline__ void load_piece(int n, int i) {
+        if (n >= n_tiles) return;
+        const char* g = reinterpret_cast<const char*>(src) + (long)n * F16_SLOT_DMA + wave * 1024 + lane * 16 + i * (F16_WAVES * 1024);
+        char* l = smem + (n % 3) * F16_SLOT_DMA + wave * 1024 + i * (F16_WAVES * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+    __device__ __forceinline__ void store(int) {}
+    // end of the step that consumed tile n: tile n + 1 is complete in LDS for every wave after this.  `younger` = vector
+    // memory instructions this wave issued in this step AFTER the five pieces of tile n + 2 (stores of the step's results):
+    // the counter is in order, so tile n + 1 is complete once at most 5 + younger operations are outstanding.  It must never
+    // be an over-estimate (0 is always safe).
+    template <int YOUNGER = 0>
+    __device__ __forceinline__ void step_barrier(int n) {
+        static_assert(YOUNGER == 0 || YOUNGER == 2 || YOUNGER == 4 || YOUNGER == 8, "add the immediate below");
+        if (n + 2 < n_tiles) {
+            if (YOUNGER == 0) __asm__ volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            if (YOUNGER == 2) __asm__ volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            if (YOUNGER == 4) __asm__ volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            if (YOUNGER == 8) __asm__ volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        } else {
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __device__ __forceinline__ h8 frag(int n, int s) const {
+        return *reinterpret_cast<const h8*>(smem + (n % 3) * F16_SLOT_DMA + ((2 * s + hh) * 32 + l32) * 16);
+    }
+};
+// position (in halves) of element (row r, column k) of a tile in that order
+__host__ __device__ __forceinline__ int dma_tile_pos(int r, int k) { return (((k >> 4) * 2 + ((k >> 3) & 1)) * 32 + r) * 8 + (k & 7); }
+
 // acc += (W tile n) x (register operand), 20 k-steps as 5 groups of 4: the weight fragments of group g + 1 are read
 // from LDS while the MFMAs of group g issue (two named register sets; the scheduling barriers keep hipcc from hoisting
 // all twenty reads to the top, which spills).  W_IS_A: acc = W x^T (features x tokens); else acc = x W^T.
-template <bool W_IS_A, int NS>
-__device__ __forceinline__ void tile_mma(f32x16& acc, const TileRing& ring, int n, const h8 (&op)[NS]) {
+struct NoPrefetch { __device__ __forceinline__ void operator()(int) const {} };
+// `between(g)` runs after the MFMAs of group g have been issued (the place for one DMA piece of a later tile)
+template <bool W_IS_A, class Ring, int NS, class Between = NoPrefetch>
+__device__ __forceinline__ void tile_mma(f32x16& acc, const Ring& ring, int n, const h8 (&op)[NS], Between between = Between()) {
     static_assert(NS % 4 == 0, "k-steps in groups of 4");
     h8 wa[4], wb[4];
 #pragma unroll
@@ -110,6 +166,7 @@ __device__ __forceinline__ void tile_mma(f32x16& acc, const TileRing& ring, int 
             const h8& w = (g & 1) ? wb[i] : wa[i];
             acc = W_IS_A ? mfma32h(w, op[4 * g + i], acc) : mfma32h(op[4 * g + i], w, acc);
         }
+        between(g);
         __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -14,6 +14,7 @@
 //
 // Layouts (all fp16 tensors are zero padded):
 //   x16    [rows][KP]      KP = 320 (fixed pitch, d <= 320); row = compact live-token index (pos[token]) or the token itself
+//   (each tile in the LDS-DMA order of fused16.h: [k-step][lane half][row][8], dma_tile_pos)
 //   wqkv16 [3h tiles][32][KP]   tile 3*head + {0,1,2} = the head's W_Q (pre-scaled by 1/sqrt(d_k)), W_K, W_V rows
 //   ctx16  [n_seq*S][DP]   DP = 320 >= 32 h: head-padded features, and INSIDE every 16-feature block in "P16" order: memory
 //                          position 8*hh + j  <->  feature 16 b + 8 (j>>2) + 4 hh + (j&3).  That is exactly the order in
@@ -91,13 +92,10 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     const bool skip_heads = __syncthreads_and(live ? 0 : 1) != 0;     // whole workgroup without a live title
     const int n_begin = skip_heads ? n_head_tiles : 0;
 
-    TileRing ring;
-    ring.dbg = 0;
-    ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_head_tiles + F16_QT; ring.tid = tid; ring.l32 = l32; ring.hh = hh;
+    TileRingDMA ring;
+    ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_head_tiles + F16_QT; ring.wave = wave; ring.lane = lane; ring.l32 = l32; ring.hh = hh;
     ring.load(n_begin);
-    ring.store(n_begin);
     ring.load(n_begin + 1);
-    ring.store(n_begin + 1);
 
     // ---- this lane's x fragments: token 32 b + l32, features 16 s + 8 hh .. +7 (A operand of x W^T, B operand of W x^T)
     h8 xf[SB][F16_KS];
@@ -116,8 +114,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             for (int s = 0; s < F16_KS; ++s) xf[b][s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    __syncthreads();
-    ring.dbg = a.dbg;
+    __asm__ volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the first two tiles have landed
 
     int n = n_begin;
 #pragma unroll 1
@@ -126,24 +123,31 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         if (!skip_heads) {
             f32x16 qt[SB], kt[SB], vv[SB];
             // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] (+ b through the ones column)
-            ring.load(n + 2);
+            auto pre = [&](int g) { ring.load_piece(n + 2, g); };     // tile n + 2 travels while tile n is consumed
+            if (!live) ring.load(n + 2);
 #pragma unroll
-            for (int b = 0; b < SB; ++b) { qt[b] = zero16(); if (live) tile_mma<true>(qt[b], ring, n, xf[b]); }
-            ring.store(n + 2);
-            if (!(a.dbg & 2)) __syncthreads();
+            for (int b = 0; b < SB; ++b) {
+                qt[b] = zero16();
+                if (live) { if (b == 0) tile_mma<true>(qt[b], ring, n, xf[b], pre); else tile_mma<true>(qt[b], ring, n, xf[b]); }
+            }
+            ring.step_barrier(n);
             ++n;
             // ---- tile K
-            ring.load(n + 2);
+            if (!live) ring.load(n + 2);
 #pragma unroll
-            for (int b = 0; b < SB; ++b) { kt[b] = zero16(); if (live) tile_mma<true>(kt[b], ring, n, xf[b]); }
-            ring.store(n + 2);
-            if (!(a.dbg & 2)) __syncthreads();
+            for (int b = 0; b < SB; ++b) {
+                kt[b] = zero16();
+                if (live) { if (b == 0) tile_mma<true>(kt[b], ring, n, xf[b], pre); else tile_mma<true>(kt[b], ring, n, xf[b]); }
+            }
+            ring.step_barrier(n);
             ++n;
             // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k]
-            ring.load(n + 2);
+            if (!live) ring.load(n + 2);
 #pragma unroll
-            for (int b = 0; b < SB; ++b) { vv[b] = zero16(); if (live) tile_mma<false>(vv[b], ring, n, xf[b]); }
-            ring.store(n + 2);
+            for (int b = 0; b < SB; ++b) {
+                vv[b] = zero16();
+                if (live) { if (b == 0) tile_mma<false>(vv[b], ring, n, xf[b], pre); else tile_mma<false>(vv[b], ring, n, xf[b]); }
+            }
             // ---- attention of this head, entirely in registers: one query block at a time
             if (live) {
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             }
         }
         if (!skip_heads) {
-            if (!(a.dbg & 2)) __syncthreads();
+            ring.step_barrier(n);          // (counting this head's 2 SB context stores as "younger" measured no gain: kept at the safe 0)
             ++n;
         }
     }
@@ -241,14 +245,17 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll 1
     for (int t = 0; t < F16_QT; ++t) {                            // (not unrolled: hipcc would software-pipeline the tanh
                                                                   //  epilogues across tiles and spill their accumulators)
-        ring.load(n + 2);
         // tanh(y) = 1 - 2 / (exp(2 y) + 1) on v_exp / v_rcp: ~1e-7 absolute, far inside what fp16 keeps of it;
         // badd32 holds b * 2 log2(e), so exp(2 (x + b)) = exp2(x * c + b')
+        // (ordinary loads go BEFORE the tile's DMA: the memory counter is in order, waiting for a younger load would drain it)
         const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
+        __builtin_amdgcn_sched_barrier(0);
+        auto pre2 = [&](int g) { ring.load_piece(n + 2, g); };
+        if (!valid) ring.load(n + 2);
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
             f32x16 tt = zero16();
-            if (valid) tile_mma<true>(tt, ring, n, cf[b]);
+            if (valid) { if (b == 0) tile_mma<true>(tt, ring, n, cf[b], pre2); else tile_mma<true>(tt, ring, n, cf[b]); }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 h4 th;
@@ -266,8 +273,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                 }
             }
         }
-        ring.store(n + 2);
-        if (!(a.dbg & 2)) __syncthreads();
+        ring.step_barrier(n);
         ++n;
     }
     // softmax over the tokens of the sequence (lane l32 of block b holds token 32 b + l32, in either half)
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
             float v = 0.f;
             if (f < a.dk && k < a.d) v = a.w_qkv[((long)which * a.d + head * a.dk + f) * a.d + k] * (which == 0 ? qscale : 1.0f);
             if (f < a.dk && k == a.d) v = a.b_qkv[which * a.d + head * a.dk + f] * (which == 0 ? qscale : 1.0f);   // x16[:, d] = 1
-            a.wqkv16[i] = (_Float16)v;
+            a.wqkv16[(long)tile * 32 * a.KP + dma_tile_pos(f, k)] = (_Float16)v;
         } else if (i < n1 + n2) {
             const long j = i - n1;
             const int p = (int)(j % a.DP), qq = (int)(j / a.DP);
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
             const int head = fpad >> 5, f = fpad & 31;
             float v = 0.f;
             if (qq < a.q && f < a.dk) v = a.w_add[(long)qq * a.d + head * a.dk + f];
-            a.wadd16[j] = (_Float16)v;
+            a.wadd16[(long)(qq >> 5) * 32 * a.DP + dma_tile_pos(qq & 31, p)] = (_Float16)v;
         } else if (i < n1 + n2 + n3) {
             const long j = i - n1 - n2;
             const int f = (int)(j & 31), tile = (int)(j >> 5), head = tile / 3, which = tile - 3 * head;
@@ -536,8 +542,8 @@ int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
     a.wtiles = (const _Float16*)(base + L.wqkv16); a.bqkv32 = (const float*)(base + L.bqkv32);
     a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
     a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;
-    const size_t lds = (size_t)3 * F16_SLOT;
-    { const char* e = getenv("NRMS_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
+    const size_t lds = (size_t)3 * F16_SLOT_DMA;
+    a.dbg = 0;
     const bool train = f.t16 != nullptr, two = f.S > 32;
     const void* fn = two ? (train ? (const void*)fused_fwd16_kernel<true, 2> : (const void*)fused_fwd16_kernel<false, 2>)
                          : (train ? (const void*)fused_fwd16_kernel<true, 1> : (const void*)fused_fwd16_kernel<false, 1>);
