@@ -95,14 +95,19 @@ struct TileRing {
 // n + 1 has landed) and meets the others at a raw s_barrier (__syncthreads() would drain the DMA with vmcnt(0)).
 constexpr int F16_SLOT_DMA = 32 * F16_KP * 2;
 static_assert(F16_SLOT_DMA == 5 * F16_WAVES * 1024, "five 1-KiB DMA pieces per wave and tile");
+// SLOTS = 3: tile n + 2 is issued during step n (two steps to land).  SLOTS = 2: tile n + 1 is issued in the first MFMA
+// groups of step n and awaited at its end -- 40 KB of LDS per workgroup instead of 60, which is what lets a third
+// workgroup share the CU.
+template <int SLOTS>
 struct TileRingDMA {
+    static constexpr int AHEAD = SLOTS - 1;
     char* smem;
     const _Float16* src;          // tiles are contiguous [n_tiles][KS][2][32][8]
     int n_tiles, wave, lane, l32, hh;
     __device__ __forceinline__ void load(int n) {
         if (n >= n_tiles) return;
         const char* g = reinterpret_cast<const char*>(src) + (long)n * F16_SLOT_DMA + wave * 1024 + lane * 16;
-        char* l = smem + (n % 3) * F16_SLOT_DMA + wave * 1024;
+        char* l = smem + (n % SLOTS) * F16_SLOT_DMA + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * (F16_WAVES * 1024)),
@@ -113,8 +118,15 @@ struct TileRingDMA {
     __device__ __forceinline__ void load_piece(int n, int i) {
         if (n >= n_tiles) return;
         const char* g = reinterpret_cast<const char*>(src) + (long)n * F16_SLOT_DMA + wave * 1024 + lane * 16 + i * (F16_WAVES * 1024);
-        char* l = smem + (n % 3) * F16_SLOT_DMA + wave * 1024 + i * (F16_WAVES * 1024);
+        char* l = smem + (n % SLOTS) * F16_SLOT_DMA + wave * 1024 + i * (F16_WAVES * 1024);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
+    // the share of tile `n`'s five pieces that goes behind MFMA group g
+    __device__ __forceinline__ void load_group(int n, int g) {
+        if (SLOTS == 3) { load_piece(n, g); return; }
+        if (g == 0) { load_piece(n, 0); load_piece(n, 1); }
+        if (g == 1) { load_piece(n, 2); load_piece(n, 3); }
+        if (g == 2) load_piece(n, 4);
     }
     __device__ __forceinline__ void store(int) {}
     // end of the step that consumed tile n: tile n + 1 is complete in LDS for every wave after this.  `younger` = vector
@@ -124,7 +136,7 @@ struct TileRingDMA {
     template <int YOUNGER = 0>
     __device__ __forceinline__ void step_barrier(int n) {
         static_assert(YOUNGER == 0 || YOUNGER == 2 || YOUNGER == 4 || YOUNGER == 8, "add the immediate below");
-        if (n + 2 < n_tiles) {
+        if (SLOTS == 3 && n + 2 < n_tiles) {
             if (YOUNGER == 0) __asm__ volatile("s_waitcnt vmcnt(5)" ::: "memory");
             if (YOUNGER == 2) __asm__ volatile("s_waitcnt vmcnt(7)" ::: "memory");
             if (YOUNGER == 4) __asm__ volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -135,7 +147,7 @@ struct TileRingDMA {
         __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     __device__ __forceinline__ h8 frag(int n, int s) const {
-        return *reinterpret_cast<const h8*>(smem + (n % 3) * F16_SLOT_DMA + ((2 * s + hh) * 32 + l32) * 16);
+        return *reinterpret_cast<const h8*>(smem + (n % SLOTS) * F16_SLOT_DMA + ((2 * s + hh) * 32 + l32) * 16);
     }
 };
 // position (in halves) of element (row r, column k) of a tile in that order

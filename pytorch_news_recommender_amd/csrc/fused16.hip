@@ -52,8 +52,12 @@ struct Fwd16Args {
 // to 64 rows, e.g. the 50-slot histories of the user encoder: one wave still owns the whole sequence, with twice the
 // accumulators -- one workgroup per CU, up to 512 registers per lane; it is 3 % of the flops, what matters is that its
 // activations stay on chip like the titles')
+#ifndef F16_FWD_SLOTS
+#define F16_FWD_SLOTS 3          // tuning: 3 slots / 2 workgroups per CU; 2 slots / 3 workgroups per CU (168 VGPRs, 16 spilled) measured the same
+#endif
+constexpr int F16_FWD_WGS = F16_FWD_SLOTS == 2 ? 3 : 2;
 template <bool TRAIN, int SB>
-__global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fused_fwd16_kernel(Fwd16Args a) {
+__global__ __launch_bounds__(F16_THREADS, SB == 1 ? F16_FWD_WGS : 1) void fused_fwd16_kernel(Fwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,10 +96,12 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     const bool skip_heads = __syncthreads_and(live ? 0 : 1) != 0;     // whole workgroup without a live title
     const int n_begin = skip_heads ? n_head_tiles : 0;
 
-    TileRingDMA ring;
+    using Ring = TileRingDMA<SB == 1 ? F16_FWD_SLOTS : 3>;
+    constexpr int AH = Ring::AHEAD;
+    Ring ring;
     ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_head_tiles + F16_QT; ring.wave = wave; ring.lane = lane; ring.l32 = l32; ring.hh = hh;
-    ring.load(n_begin);
-    ring.load(n_begin + 1);
+#pragma unroll
+    for (int i = 0; i < AH; ++i) ring.load(n_begin + i);
 
     // ---- this lane's x fragments: token 32 b + l32, features 16 s + 8 hh .. +7 (A operand of x W^T, B operand of W x^T)
     h8 xf[SB][F16_KS];
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         if (!skip_heads) {
             f32x16 qt[SB], kt[SB], vv[SB];
             // ---- tile Q: QT[f][tok] = sum_k Wq[f][k] x[tok][k] (+ b through the ones column)
-            auto pre = [&](int g) { ring.load_piece(n + 2, g); };     // tile n + 2 travels while tile n is consumed
-            if (!live) ring.load(n + 2);
+            auto pre = [&](int g) { ring.load_group(n + AH, g); };    // a later tile travels while tile n is consumed
+            if (!live) ring.load(n + AH);
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 qt[b] = zero16();
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             ring.step_barrier(n);
             ++n;
             // ---- tile K
-            if (!live) ring.load(n + 2);
+            if (!live) ring.load(n + AH);
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 kt[b] = zero16();
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             ring.step_barrier(n);
             ++n;
             // ---- tile V: V[tok][f] = sum_k x[tok][k] Wv[f][k]
-            if (!live) ring.load(n + 2);
+            if (!live) ring.load(n + AH);
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 vv[b] = zero16();
@@ -250,8 +256,8 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         // (ordinary loads go BEFORE the tile's DMA: the memory counter is in order, waiting for a younger load would drain it)
         const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
         __builtin_amdgcn_sched_barrier(0);
-        auto pre2 = [&](int g) { ring.load_piece(n + 2, g); };
-        if (!valid) ring.load(n + 2);
+        auto pre2 = [&](int g) { ring.load_group(n + AH, g); };
+        if (!valid) ring.load(n + AH);
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
             f32x16 tt = zero16();
@@ -542,9 +548,9 @@ int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
     a.wtiles = (const _Float16*)(base + L.wqkv16); a.bqkv32 = (const float*)(base + L.bqkv32);
     a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
     a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;
-    const size_t lds = (size_t)3 * F16_SLOT_DMA;
-    a.dbg = 0;
     const bool train = f.t16 != nullptr, two = f.S > 32;
+    const size_t lds = (size_t)(two ? 3 : F16_FWD_SLOTS) * F16_SLOT_DMA;
+    a.dbg = 0;
     const void* fn = two ? (train ? (const void*)fused_fwd16_kernel<true, 2> : (const void*)fused_fwd16_kernel<false, 2>)
                          : (train ? (const void*)fused_fwd16_kernel<true, 1> : (const void*)fused_fwd16_kernel<false, 1>);
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
