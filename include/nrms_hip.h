@@ -61,7 +61,10 @@ extern "C" {
 /* nrms_encoder_bwd leaves d(w_qkv) / d(b_qkv) out (its step 5); the caller runs nrms_encoder_bwd_wqkv with the
  * same descriptor, activations and workspace afterwards.  Everything else, in particular the embedding-table
  * gradient, is complete when nrms_encoder_bwd returns: a data-parallel caller starts the all-reduce of the
- * table gradient (95 % of the gradient bytes) there and lets it run underneath the deferred GEMM. */
+ * table gradient (95 % of the gradient bytes) there and lets it run underneath the deferred GEMM.
+ * NRMS_PRECISION_FP16: the weight-gradient GEMMs (d(w_qkv), d(b_qkv), d(w_add), d(b_add)) are already running on the
+ * library's helper streams when nrms_encoder_bwd returns; with this flag the call does not wait for them (dx and the table
+ * gradient are complete in stream order, those four are NOT) and nrms_encoder_bwd_wqkv orders them into the stream. */
 #define NRMS_FLAG_DEFER_WQKV 2
 
 /* One self-attention + additive-pooling encoder pass over n_seq sequences of seq_len rows.

@@ -340,6 +340,10 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     } else {
         f.dx = dx;
     }
+    // NRMS_FLAG_DEFER_WQKV: the two weight-gradient GEMMs stay on their helper streams; dX and the table gradient below
+    // are complete in stream order, nrms_encoder_bwd_wqkv joins the rest (a data-parallel caller starts the table
+    // all-reduce in between)
+    f.defer_join = (desc->flags & NRMS_FLAG_DEFER_WQKV) != 0;
     rc = launch_fused_bwd16(f, s);
     if (rc) return rc;
     if (gather) {
@@ -484,7 +488,7 @@ extern "C" int nrms_encoder_bwd_wqkv(const nrms_encoder_desc* desc, const int64_
                                      size_t workspace_bytes, void* stream) {
     int rc = validate_desc(desc, "encoder_bwd_wqkv");
     if (rc) return rc;
-    if (desc->precision == NRMS_PRECISION_FP16) return NRMS_OK;      // fp16 mode: nrms_encoder_bwd has done everything
+    if (desc->precision == NRMS_PRECISION_FP16) return fused_bwd16_join((hipStream_t)stream);   // the GEMMs run already: order them
     NRMS_REQUIRE(acts && grads && workspace, "encoder_bwd_wqkv: null argument");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv, "encoder_bwd_wqkv: null gradient buffer");
     const bool gather = desc->vocab > 0;

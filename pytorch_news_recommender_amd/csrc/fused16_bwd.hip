@@ -858,6 +858,7 @@ struct SideStreams {
     hipStream_t s[2] = {nullptr, nullptr};
     hipEvent_t fork[2] = {nullptr, nullptr}, join[2] = {nullptr, nullptr};
     bool ok = false, tried = false;
+    bool pending = false;          // a deferred join is outstanding (Fused16Bwd::defer_join)
     void init() {
         if (tried) return;
         tried = true;
@@ -946,6 +947,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     float* partial_qkv = (float*)(base + L.partial);
     float* partial_add = (float*)(base + L.partial + up256((size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4));
     g_side.init();
+    if (g_side.pending) { const int jr = fused_bwd16_join(stream); if (jr) return jr; }      // an un-joined earlier call: order it first
     // NRMS_NO_SIDE_STREAMS is read per call so that a profiler pass can serialise the step (exclusive kernel durations)
     const bool side = g_side.ok && getenv("NRMS_NO_SIDE_STREAMS") == nullptr;
     hipStream_t s_add = side ? g_side.s[0] : stream, s_qkv = side ? g_side.s[1] : stream;
@@ -1039,10 +1041,24 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         rc = check_launch("gemm16_dx");
     }
     if (side) {                                                     // join: the caller's stream continues after both GEMMs
-        (void)hipStreamWaitEvent(stream, g_side.join[0], 0);
-        (void)hipStreamWaitEvent(stream, g_side.join[1], 0);
+        if (f.defer_join) g_side.pending = true;                    // ... or later, in fused_bwd16_join
+        else {
+            (void)hipStreamWaitEvent(stream, g_side.join[0], 0);
+            (void)hipStreamWaitEvent(stream, g_side.join[1], 0);
+        }
     }
     return rc;
+}
+
+// The other half of Fused16Bwd::defer_join: work enqueued on `stream` after this sees d(W_qkv), d(b_qkv), d(W_add), d(b_add).
+int fused_bwd16_join(hipStream_t stream) {
+    if (!g_side.pending) return NRMS_OK;
+    g_side.pending = false;
+    if (hipStreamWaitEvent(stream, g_side.join[0], 0) != hipSuccess || hipStreamWaitEvent(stream, g_side.join[1], 0) != hipSuccess) {
+        set_error("fused_bwd16_join: hipStreamWaitEvent failed");
+        return NRMS_ELAUNCH;
+    }
+    return NRMS_OK;
 }
 
 }  // namespace nrms

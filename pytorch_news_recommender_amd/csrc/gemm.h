@@ -369,8 +369,11 @@ struct Fused16Bwd {
     Dropout drop;             // context dropout
     float* dw_qkv; float* db_qkv; float* dw_add; float* db_add; float* dq_vec;           // accumulated
     float* dx;                // [rows][d] fp32 (rows as pos / tokens): gradient w.r.t. the encoder input
+    bool defer_join;          // leave the two weight-gradient GEMMs running on their helper streams when the call returns
+                              // (dx is complete in stream order); fused_bwd16_join() orders them before later work
 };
 int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream);
+int fused_bwd16_join(hipStream_t stream);
 
 // embed.hip
 // dst[i] = src[i] if 0 <= src[i] < vocab else 0; *n_bad += ids replaced (dst may alias src)
