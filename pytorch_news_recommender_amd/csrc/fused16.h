@@ -27,6 +27,14 @@ __device__ __forceinline__ int p16_pos(int fpad) {           // natural padded f
     return 16 * b + 8 * hh + j;
 }
 
+// Timing experiments ("what does the kernel cost without this store?") are compiled in only with -DNRMS_F16_EXPERIMENTS
+// and then switched by the NRMS_F16_DBG environment variable; they make results WRONG, so a normal build has none of them.
+#ifdef NRMS_F16_EXPERIMENTS
+#define F16_DBG(flags, bit) ((flags) & (bit))
+#else
+#define F16_DBG(flags, bit) 0
+#endif
+
 constexpr int F16_WAVES = 4;            // waves (= sequences) per workgroup; two workgroups share a CU (one wave per SIMD each),
 constexpr int F16_THREADS = 64 * F16_WAVES;   // so the two waves of a SIMD are in different phases: one's MFMAs cover the other's VALU / waits
 // Pitches are compile-time constants (every inner loop fully unrolled, no guards: a guarded MFMA costs a branch
@@ -61,7 +69,7 @@ struct TileRing {
     h8 stg[F16_STG];
     __device__ __forceinline__ void load(int n) {
         if (n >= n_tiles) return;
-        if (dbg & 1) return;
+        if (F16_DBG(dbg, 1)) return;
         const _Float16* t = src + (long)n * (32 * F16_KP) + tid * 8;
 #pragma unroll
         for (int i = 0; i < F16_STG; ++i)
@@ -70,7 +78,7 @@ struct TileRing {
     }
     __device__ __forceinline__ void store(int n) {
         if (n >= n_tiles) return;
-        if (dbg & 1) return;
+        if (F16_DBG(dbg, 1)) return;
         char* dst = smem + (n % 3) * F16_SLOT;
 #pragma unroll
         for (int i = 0; i < F16_STG; ++i) {

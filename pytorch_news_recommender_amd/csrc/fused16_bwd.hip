@@ -179,7 +179,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                     }
                     zf[b][s] = dz;
                     // (zero beyond the sequence: ds = 0 there)
-                    if (valid && !(a.dbg & 4)) *reinterpret_cast<h8*>(a.dz16 + frag_off((long)seq * SB + b, QP / 16, s, l32, hh)) = dz;
+                    if (valid && !F16_DBG(a.dbg, 4)) *reinterpret_cast<h8*>(a.dz16 + frag_off((long)seq * SB + b, QP / 16, s, l32, hh)) = dz;
                     // transposing products: D[tok][n] = X[tok][q = 32 t + n]  (rows = tokens in registers)
                     accz = mfma32h(dz, sel[s2], accz);
                     accu = mfma32h(u, sel[s2], accu);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 f32x16 dct = zero16();
-                if (!(a.dbg & 8)) tile_mma<true>(dct, ring, n, zf[b]);
+                if (!F16_DBG(a.dbg, 8)) tile_mma<true>(dct, ring, n, zf[b]);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     dct[r] += wgt[b] * (float)d0[r];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                         for (int e = 0; e < 8; ++e) dct[8 * c + e] *= sc[e];
                     }
                 }
-                if (live && !(a.dbg & 4)) {                     // (zero beyond the sequence: dZ and w are 0 there); the
+                if (live && !F16_DBG(a.dbg, 4)) {                     // (zero beyond the sequence: dZ and w are 0 there); the
                     // attention kernel reads the rows of titles with a real token only
                     _Float16* dcrow = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
                     *reinterpret_cast<h8*>(dcrow) = acc_frag(dct, 0);
@@ -972,7 +972,10 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     a.btiles = btiles; a.bqkv32 = bqkv32; a.qv16 = qv16;
     a.ctx16 = (const _Float16*)f.ctx16; a.t16 = (const _Float16*)f.t16; a.w = f.w; a.dout16 = dout16;
     a.dz16 = dz16; a.dctx16 = dctx16; a.dqkv16 = dqkv16; a.red = red; a.drop = f.drop;
+    a.dbg = 0;
+#ifdef NRMS_F16_EXPERIMENTS
     { const char* e = getenv("NRMS_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     const int n_wg = a.n_groups < L.n_wg ? a.n_groups : L.n_wg;
     {
         const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4;
