@@ -176,6 +176,9 @@ int nrms_encoder_bwd_wqkv(const nrms_encoder_desc* desc, const int64_t* ids, con
  * dst[i] = src[i] if 0 <= src[i] < vocab, else 0 (the padding id); *n_bad += number of ids replaced
  * (device int32 the caller zeroes and reads back when it chooses to synchronise).  dst may alias src. */
 int nrms_sanitize_ids(const int64_t* src, int64_t* dst, int64_t n, int32_t vocab, int32_t* n_bad, void* stream);
+/* The same from int32 ids (a feed that keeps its ids in 32 bits moves half the bytes; the encoder entry points take the
+ * validated int64 copy either way). */
+int nrms_sanitize_ids_i32(const int32_t* src, int64_t* dst, int64_t n, int32_t vocab, int32_t* n_bad, void* stream);
 
 /* Evaluation encodes every DISTINCT title once (get_news_vector, nrms_v0.py:278-289, is the reference's hook for
  * caching news vectors; an impression padded to max_candidate_size = 300 slots, data_handler.py:174-177, is mostly

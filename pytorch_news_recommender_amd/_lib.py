@@ -67,6 +67,7 @@ SIGNATURES = {
     "nrms_encoder_bwd_wqkv": (C.c_int, [C.POINTER(EncoderDesc), C.c_void_p, C.c_void_p, C.POINTER(EncoderActs),
                                         C.POINTER(EncoderGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "nrms_sanitize_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "nrms_sanitize_ids_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "nrms_title_dedup": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "nrms_click_score_indexed": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -701,7 +701,13 @@ extern "C" int nrms_news_features_bwd(const nrms_news_features* f, const float* 
 extern "C" int nrms_sanitize_ids(const int64_t* src, int64_t* dst, int64_t n, int32_t vocab, int32_t* n_bad, void* stream) {
     NRMS_REQUIRE(n >= 0 && vocab > 0, "sanitize_ids: n=%ld vocab=%d", (long)n, vocab);
     NRMS_REQUIRE(n == 0 || (src && dst && n_bad), "sanitize_ids: null argument");
-    return launch_sanitize_ids((long)n, src, dst, vocab, n_bad, (hipStream_t)stream);
+    return launch_sanitize_ids((long)n, src, false, dst, vocab, n_bad, (hipStream_t)stream);
+}
+
+extern "C" int nrms_sanitize_ids_i32(const int32_t* src, int64_t* dst, int64_t n, int32_t vocab, int32_t* n_bad, void* stream) {
+    NRMS_REQUIRE(n >= 0 && vocab > 0, "sanitize_ids_i32: n=%ld vocab=%d", (long)n, vocab);
+    NRMS_REQUIRE(n == 0 || (src && dst && n_bad), "sanitize_ids_i32: null argument");
+    return launch_sanitize_ids((long)n, src, true, dst, vocab, n_bad, (hipStream_t)stream);
 }
 
 extern "C" int nrms_title_dedup(const int64_t* ids, int64_t n_titles, int32_t seq_len, int32_t* table, int64_t table_size,

@@ -374,10 +374,11 @@ int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* 
 // dst[i] = src[i] if 0 <= src[i] < vocab else 0 (the padding id); *n_bad += number of ids replaced.  The encoder
 // kernels index the table, the histogram and the placement arrays with the raw id: every id stream goes through
 // here first (nn.Embedding raises on an out-of-range index, nrms_v0.py:134-139).
-__global__ __launch_bounds__(256) void sanitize_ids_kernel(long n, const int64_t* src, int64_t* dst, long vocab, int* n_bad) {
+template <class SRC>
+__global__ __launch_bounds__(256) void sanitize_ids_kernel(long n, const SRC* src, int64_t* dst, long vocab, int* n_bad) {
     int bad = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int64_t v = src[i];
+        const int64_t v = (int64_t)src[i];
         const bool ok = v >= 0 && v < vocab;
         bad += ok ? 0 : 1;
         dst[i] = ok ? v : 0;
@@ -389,12 +390,16 @@ __global__ __launch_bounds__(256) void sanitize_ids_kernel(long n, const int64_t
     }
 }
 
-int launch_sanitize_ids(long n, const int64_t* src, int64_t* dst, int vocab, int* n_bad, hipStream_t stream) {
+// src: int64 ids (the reference's batch dict), or int32 ids (half the bytes over PCIe for a caller that keeps them so)
+int launch_sanitize_ids(long n, const void* src, bool src_is_int32, int64_t* dst, int vocab, int* n_bad, hipStream_t stream) {
     if (n <= 0) return NRMS_OK;
     int blocks = cdiv(n, 256 * 4);
     if (blocks > 256 * 8) blocks = 256 * 8;
     TimingScope ts("sanitize_ids", stream);
-    hipLaunchKernelGGL(sanitize_ids_kernel, dim3(blocks), dim3(256), 0, stream, n, src, dst, (long)vocab, n_bad);
+    if (src_is_int32)
+        hipLaunchKernelGGL(sanitize_ids_kernel<int32_t>, dim3(blocks), dim3(256), 0, stream, n, (const int32_t*)src, dst, (long)vocab, n_bad);
+    else
+        hipLaunchKernelGGL(sanitize_ids_kernel<int64_t>, dim3(blocks), dim3(256), 0, stream, n, (const int64_t*)src, dst, (long)vocab, n_bad);
     return check_launch("sanitize_ids");
 }
 

@@ -377,7 +377,7 @@ int fused_bwd16_join(hipStream_t stream);
 
 // embed.hip
 // dst[i] = src[i] if 0 <= src[i] < vocab else 0; *n_bad += ids replaced (dst may alias src)
-int launch_sanitize_ids(long n, const int64_t* src, int64_t* dst, int vocab, int* n_bad, hipStream_t stream);
+int launch_sanitize_ids(long n, const void* src, bool src_is_int32, int64_t* dst, int vocab, int* n_bad, hipStream_t stream);
 // keys[t] = 64-bit hash of the L word ids of title t
 int launch_title_dedup(long n, int L, const int64_t* ids, int* table, long table_size, int* inverse, int* rep_rows,
                        int* n_unique, hipStream_t stream);

@@ -213,8 +213,8 @@ class NRMSEngine:
         n = src.numel()
         if n == 0:
             return dst
-        rc = self.lib.nrms_sanitize_ids(_lib.ptr(src), _lib.ptr(dst), C.c_int64(n), int(self.dims.n_words),
-                                        _lib.ptr(self._bad_ids), _stream())
+        fn = self.lib.nrms_sanitize_ids_i32 if src.dtype == torch.int32 else self.lib.nrms_sanitize_ids
+        rc = fn(_lib.ptr(src), _lib.ptr(dst), C.c_int64(n), int(self.dims.n_words), _lib.ptr(self._bad_ids), _stream())
         _lib.check(rc, "nrms_sanitize_ids")
         self._bad_host.copy_(self._bad_ids, non_blocking=True)
         ev = torch.cuda.Event()

@@ -79,6 +79,13 @@ def _load_table(config, pretrained_word_embedding):
     return torch.as_tensor(np.asarray(pretrained_word_embedding, dtype=np.float32)).clone()
 
 
+def _ids_on(dev, x):
+    """Word ids on the device: int32 feeds stay int32 over PCIe (the library validates either width into its own
+    int64 copy), anything else becomes the reference's int64."""
+    t = torch.as_tensor(x)
+    return t.to(dev, dtype=torch.int32 if t.dtype == torch.int32 else torch.int64, non_blocking=True)
+
+
 class _NRMSFunction(torch.autograd.Function):
     """scores = NRMS(batch; params) with the backward in HIP (autograd sees one node)."""
 
@@ -218,8 +225,7 @@ class Model(nn.Module):
         'browsed_titles' [B,H,L], 'candidate_titles' [B,C,L] and 'candidate_mask' [B,C] are read
         (nrms_v0.py:248,250,272).  Returns click logits [B,C] on the GPU."""
         dev = self._prepare()
-        bt = torch.as_tensor(batch["browsed_titles"]).to(dev, dtype=torch.int64, non_blocking=True)
-        ct = torch.as_tensor(batch["candidate_titles"]).to(dev, dtype=torch.int64, non_blocking=True)
+        bt, ct = _ids_on(dev, batch["browsed_titles"]), _ids_on(dev, batch["candidate_titles"])
         mask = batch.get("candidate_mask") if hasattr(batch, "get") else batch["candidate_mask"]
         if mask is not None:
             mask = torch.as_tensor(mask).to(dev, dtype=torch.uint8, non_blocking=True)
@@ -245,7 +251,7 @@ class Model(nn.Module):
     def get_news_vector(self, news):
         """news [N, L] title ids -> [N, d] (nrms_v0.py:278-289); inference only."""
         dev = self._prepare()
-        ids = torch.as_tensor(news).to(dev, dtype=torch.int64)
+        ids = _ids_on(dev, news)
         p_drop = float(self.config.dropout) if self.training else 0.0
         p_embed = 0.0 if self._dims.style == "v1" else p_drop
         return self._engine.encode_titles(self._flat, ids, p_embed=p_embed, p_ctx=p_drop,
@@ -276,8 +282,7 @@ class Model(nn.Module):
         the mean loss over the global batch."""
         dev = self._prepare()
         eng = self._engine
-        bt = torch.as_tensor(batch["browsed_titles"]).to(dev, dtype=torch.int64, non_blocking=True)
-        ct = torch.as_tensor(batch["candidate_titles"]).to(dev, dtype=torch.int64, non_blocking=True)
+        bt, ct = _ids_on(dev, batch["browsed_titles"]), _ids_on(dev, batch["candidate_titles"])
         mask = batch.get("candidate_mask")
         if mask is not None:
             mask = torch.as_tensor(mask).to(dev, dtype=torch.uint8, non_blocking=True)

@@ -428,6 +428,36 @@ def test_out_of_range_word_id_is_reported():
     assert ref.shape == (shape.batch_size, shape.n_candidates)
 
 
+@pytest.mark.parametrize("mode", MODES + ["fp16"])
+def test_int32_word_ids_give_the_same_results(mode):
+    """The C ABI validates int32 or int64 ids into its own int64 copy (nrms_sanitize_ids / _i32): a feed that keeps its ids
+    in 32 bits gets bit-identical scores, gradients and error reporting."""
+    from pytorch_news_recommender_amd._lib import NrmsError
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=11)
+    batch = synth.make_batch(shape, seed=12, ragged=True, mask_some_candidates=True)
+    b64 = tbatch(batch)
+    b32 = {k: (v.to(torch.int32) if k.endswith("titles") else v) for k, v in b64.items()}
+    model = make_model(shape, params, precision=mode).train()
+    s64, l64, g64 = fwd_bwd(model, batch)
+    model.zero_grad()
+    scores = model(b32)
+    loss = torch.nn.CrossEntropyLoss()(scores, torch.zeros(len(scores), dtype=torch.long, device=scores.device))
+    loss.backward()
+    assert np.array_equal(scores.detach().cpu().numpy(), s64)
+    t = "news_encoder.word_embedding.0.weight"
+    assert np.array_equal(dict(model.named_parameters())[t].grad.cpu().numpy(), g64[t])
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(model(b32), model(b64))                 # the de-duplicating inference path too
+    b32["candidate_titles"] = b32["candidate_titles"].clone()
+    b32["candidate_titles"][0, 0, 0] = -7
+    with torch.no_grad():
+        model(b32)
+    with pytest.raises(NrmsError, match="outside"):
+        model.engine.check_ids()
+
+
 def test_second_training_forward_invalidates_the_first_backward():
     """One slot of saved activations: a backward for an earlier training forward must raise, not run on the
     activations of a later one (the reference's autograd would keep both graphs).  Inference calls in between
