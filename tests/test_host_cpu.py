@@ -414,3 +414,32 @@ def test_nrms_naml_wrapper_names_layout_and_loud_failure_on_cpu(tmp_path):
     bad = _lib.EncoderDesc(n_seq=512, seq_len=50, d_model=800, n_heads=8, q_dim=400, vocab=0, precision=0,
                            use_output_proj=1, p_drop_attn=0.2, p_drop_ctx=0.1, seed=1)
     assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(bad)) == 0 and b"p_drop_ctx" in lib.nrms_last_error()
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/nrms_hip.h compiles as C99 (-pedantic) and a C program linked against
+    libnrms_hip.so agrees with the ctypes mirror on the descriptor size and gets the argument validation (no GPU needed)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi_check.c"
+    src.write_text(
+        '#include "nrms_hip.h"\n#include <stdio.h>\n#include <string.h>\n'
+        "int main(void) {\n"
+        "    nrms_encoder_desc d; memset(&d, 0, sizeof d);\n"
+        "    d.n_seq = 4; d.seq_len = 30; d.d_model = 300; d.n_heads = 10; d.q_dim = 200; d.vocab = 100;\n"
+        "    size_t ok = nrms_encoder_bwd_workspace_bytes(&d);\n"
+        "    d.seq_len = 65;\n"
+        "    size_t bad = nrms_encoder_bwd_workspace_bytes(&d);\n"
+        '    printf("%zu %zu %zu %s\\n", sizeof(nrms_encoder_desc), ok, bad, nrms_last_error());\n'
+        "    return 0;\n}\n")
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "abi_check"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                    str(src), "-o", str(exe), "-L", lib_dir, "-lnrms_hip", "-Wl,-rpath," + lib_dir,
+                    "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(None, 3)
+    assert int(out[0]) == ctypes.sizeof(_lib.EncoderDesc) == 64
+    assert int(out[1]) > 4 * 120 * 300 * 4 and int(out[2]) == 0 and "seq_len" in out[3]
