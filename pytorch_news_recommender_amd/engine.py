@@ -388,6 +388,8 @@ class NRMSEngine:
         d = self.dims.word_embed_size
         N = B * (H + Cn)
         self.loss_scale = float(2 ** math.ceil(math.log2(128.0 * max(B, 1))))     # fp16 mode: d(scores) ~ 1 / batch
+        if getattr(self, "loss_scale_override", None):
+            self.loss_scale = float(self.loss_scale_override)                     # experiments (tools/fp16_grad_stats.py)
         nv, user = sv["nv"], sv["user"]
         hist = nv[:B * H]
         cand = nv[B * H:]
