@@ -122,6 +122,8 @@ class Model(nrms_hip.Model):
         params = [p for _, p in self._ordered_params()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _NamlFunction.apply(self, ids, mask, p_drop, seed, *params)
+        # evaluation: every distinct news item of the batch is encoded once (model.dedup_inference = False: every slot)
+        self._engine.dedup_inference = bool(getattr(self, "dedup_inference", True))
         return self._engine.forward(self._flat, ids, mask, training=False, p_drop=p_drop, seed=seed)
 
     def get_news_vector(self, *a, **k):

@@ -261,6 +261,8 @@ class NamlEngine(NRMSEngine):
         sfx = "" if training else "_eval"
         (B, H, Cn, N), ids_t, ids_a, categ, subcateg = self._slot_inputs(batch, sfx)
         F = self.dims.news_feature_size
+        if not training and p_drop == 0.0 and getattr(self, "dedup_inference", True):
+            return self._forward_dedup(flat, (B, H, Cn, N), ids_t, ids_a, categ, subcateg, cand_mask)
         feat = self._buf("feat" + sfx, N * F)[:N * F].view(N, F)
         self.news_features(flat, ids_t, ids_a, categ, subcateg, p_drop, seed, sfx, out=feat)
         stats = self._buf("ln_stats" + sfx, 2 * B * H)[:2 * B * H]
@@ -276,6 +278,26 @@ class NamlEngine(NRMSEngine):
             self._saved = dict(B=B, H=H, C=Cn, N=N, ids_t=ids_t, ids_a=ids_a, categ=categ, subcateg=subcateg, feat=feat,
                                stats=stats, normed=normed, user=user, mask=cand_mask, p=float(p_drop), seed=seed, gen=self._gen)
         return scores
+
+    def _forward_dedup(self, flat, dims, ids_t, ids_a, categ, subcateg, cand_mask):
+        """Inference over the DISTINCT news of the batch (an evaluation impression is padded to 300 candidate slots,
+        data_handler.py:174-177, mostly padding and repeats): slots are grouped exactly by their (title, abstract, category,
+        sub-category) ids on the device (nrms_title_dedup), one feature row is computed per group, the history rows are
+        gathered for LayerNorm and the user encoder, the candidates are scored by index."""
+        B, H, Cn, N = dims
+        F = self.dims.news_feature_size
+        key = torch.cat([ids_t, ids_a, categ.view(N, 1), subcateg.view(N, 1)], 1).contiguous()
+        inverse, rep, U = self.group_rows(key)
+        r = rep.to(torch.int64)
+        feat = self.news_features(flat, ids_t.index_select(0, r), ids_a.index_select(0, r), categ.index_select(0, r),
+                                  subcateg.index_select(0, r), 0.0, 0, "_uniq")
+        self.last_unique_news = U
+        hist = feat.index_select(0, inverse[:B * H])
+        normed = self.layernorm(flat, hist)
+        user = self.encode_users(flat, normed.view(B, H, F), 0.0, 0, "user_eval")
+        if cand_mask is not None:
+            cand_mask = cand_mask.contiguous()
+        return self.click_scores_indexed(feat, inverse[B * H:], user, B, Cn, cand_mask)
 
     def backward(self, flat, gflat, dscores, gen=None, table_grad_ready=None):
         """Accumulates every parameter gradient of the saved training forward into gflat (same layout as flat)."""

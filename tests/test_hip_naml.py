@@ -231,3 +231,37 @@ def test_run_v0_entry_point_with_nrms_naml(tmp_path, monkeypatch):
     sd = torch.load(os.path.join(tmp_path / "save", ckpts[0]), map_location="cpu", weights_only=True)
     assert "model.norm.weight" in sd and "model.news_encoder.category_embedding.weight" in sd
     assert sd["model.user_encoder.additive_attention.linear.weight"].shape == (400, 800)
+
+
+def test_inference_over_distinct_news_equals_every_slot():
+    """Evaluation-shaped batch (many repeated news items and padding slots): the grouped path (one feature row per distinct
+    (title, abstract, category, sub-category)) against encoding every slot, and against the oracle."""
+    from oracle import naml_oracle as nml
+    shape = synth.NamlShape(n_words=90, word_embed_size=48, title_heads_num=6, query_vector_dim=20, category_nums=5,
+                            subcategory_nums=9, cate_embed_size=16, user_heads_num=8, query_vector_dim_large=36,
+                            batch_size=6, history_len=12, n_candidates=40, n_words_title=7, n_words_abst=11)
+    params = synth.make_params_naml(shape, seed=41)
+    batch = synth.make_batch_naml(shape, seed=42)
+    # impressions padded to 40 slots: 8 shown, the rest padding; histories repeat two news items
+    for k in ("candidate_titles", "candidate_absts"):
+        batch[k][:, 8:, :] = 0
+    for k in ("candidate_categ_ids", "candidate_subcateg_ids"):
+        batch[k][:, 8:] = 0
+    batch["candidate_mask"][:, 8:] = 0
+    for k in ("browsed_titles", "browsed_absts", "browsed_categ_ids", "browsed_subcateg_ids"):
+        batch[k][:, 2:] = batch[k][:, :1].repeat(shape.history_len - 2, axis=1)
+    model = make_model(shape, params).eval()
+    with torch.no_grad():
+        model.dedup_inference = True
+        s_dedup = model(tbatch(batch)).cpu().numpy()
+        n_unique = model.engine.last_unique_news
+        model.dedup_inference = False
+        s_plain = model(tbatch(batch)).cpu().numpy()
+    assert n_unique < 0.3 * shape.batch_size * (shape.history_len + shape.n_candidates)
+    live = batch["candidate_mask"] != 0
+    np.testing.assert_allclose(s_dedup[live], s_plain[live], rtol=0, atol=2e-6)
+    assert (s_dedup[~live] == np.float32(-1e9)).all()
+    p = nml.to_torch(params)
+    with torch.no_grad():
+        ref = nml.forward(p, tbatch(batch), shape.title_heads_num, shape.user_heads_num).numpy()
+    np.testing.assert_allclose(s_dedup[live], ref[live], rtol=0, atol=2e-5)
