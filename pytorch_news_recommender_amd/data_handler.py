@@ -274,3 +274,101 @@ class SyntheticMind:
             samples.append([hist, self._cat(hist), self._sub(hist), imps, self._cat(imps), self._sub(imps)])
             labels.append([y[i] for i in perm])
         return samples, labels
+
+
+class DeviceFeed:
+    """The same batch dicts as ``DataLoader(MyDataset(config, samples, type), batch_size)`` -- same 13 keys, dtypes, padding
+    and sample order -- assembled ON THE DEVICE: the news corpus (title and abstract word ids, 31 MB for MIND's 130 k news at
+    30 words) lives in HBM once, the samples are packed into padded id arrays once, and a batch is two row gathers.
+    ``MyDataset.__getitem__`` builds every sample in Python (55 dictionary lookups each, data_handler.py:185-250): eight
+    loader workers deliver a few thousand users per second, the train step consumes a hundred and fifty thousand.
+
+    Iterable like a DataLoader (``len()`` = batches per epoch); ``shuffle`` draws a fresh permutation per epoch from ``seed``.
+    """
+
+    def __init__(self, config, samples, type=0, id2title_dict=None, id2abst_dict=None, batch_size=None, device="cuda",
+                 shuffle=False, drop_last=False, seed=0):
+        self.config, self.data_type = config, type
+        if id2title_dict is None:
+            if getattr(config, 'mode', 'large') == 'demo':
+                id2title_dict, id2abst_dict = get_Demo_Words_Infos(config)
+            else:
+                id2title_dict, id2abst_dict = get_Words_Infos(config)
+        self.device = torch.device(device)
+        self.batch_size = int(batch_size or config.batch_size)
+        self.shuffle, self.drop_last, self.seed, self.epoch = bool(shuffle), bool(drop_last), int(seed), 0
+        H, L, A = config.history_len, config.n_words_title, config.n_words_abst
+        S = config.sample_size + 1 if type < 1 else config.max_candidate_size
+        self.S = S
+
+        def table(d, width):
+            n = (max(d) + 1) if len(d) else 0                       # news index i lives in row i + 1 (0 = padding slot)
+            t = np.zeros((n + 1, width), dtype=np.int64)
+            for i, words in d.items():
+                w = list(words)[:width]
+                t[i + 1, :len(w)] = w
+            return torch.from_numpy(t).to(self.device)
+
+        self.titles = table(id2title_dict, L)
+        self.absts = table(id2abst_dict, A) if id2abst_dict is not None else None
+        n = len(samples)
+        hist = np.zeros((n, H), dtype=np.int64)
+        hcat, hsub = np.zeros((n, H), dtype=np.int64), np.zeros((n, H), dtype=np.int64)
+        cand = np.zeros((n, S), dtype=np.int64)
+        ccat, csub = np.zeros((n, S), dtype=np.int64), np.zeros((n, S), dtype=np.int64)
+        hlen, clen = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        for k, data in enumerate(samples):
+            h = list(data[0])[:H]
+            x = len(h)
+            hist[k, :x] = h
+            hlen[k] = x
+            if x and len(data) > 2 and data[1] is not None:
+                hcat[k, :x] = np.asarray(data[1])[:x]
+                hsub[k, :x] = np.asarray(data[2])[:x]
+            c = list(data[3])[:S]
+            y = len(c)
+            cand[k, :y] = c
+            clen[k] = y
+            if y and len(data) > 5 and data[4] is not None:
+                ss = min(len(data[4]), S)
+                ccat[k, :ss] = np.asarray(data[4])[:ss]
+                csub[k, :ss] = np.asarray(data[5])[:ss]
+        dev = lambda a: torch.from_numpy(a).to(self.device)
+        self.packed = dict(hist=dev(hist), hcat=dev(hcat), hsub=dev(hsub), cand=dev(cand), ccat=dev(ccat), csub=dev(csub),
+                           hlen=dev(hlen), clen=dev(clen))
+        self.n = n
+
+    def __len__(self):
+        return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
+
+    def batch(self, rows):
+        """rows: int64 device tensor of sample indices -> the batch dict (device tensors)."""
+        p, cfg = self.packed, self.config
+        hist, cand = p["hist"].index_select(0, rows), p["cand"].index_select(0, rows)
+        hlen, clen = p["hlen"].index_select(0, rows), p["clen"].index_select(0, rows)
+        H, S, A = cfg.history_len, self.S, cfg.n_words_abst
+        B = rows.shape[0]
+        zeros = lambda slots: torch.zeros(B, slots, A, dtype=torch.int64, device=self.device)
+        return {'browsed_lens': hlen,
+                'browsed_ids': hist,
+                'browsed_titles': self.titles.index_select(0, hist.reshape(-1)).view(B, H, -1),
+                'browsed_absts': self.absts.index_select(0, hist.reshape(-1)).view(B, H, -1) if self.absts is not None else zeros(H),
+                'browsed_categ_ids': p["hcat"].index_select(0, rows),
+                'browsed_subcateg_ids': p["hsub"].index_select(0, rows),
+                'browsed_mask': (torch.arange(H, device=self.device)[None, :] < hlen[:, None]).to(torch.uint8),
+                'candidate_ids': cand,
+                'candidate_titles': self.titles.index_select(0, cand.reshape(-1)).view(B, S, -1),
+                'candidate_absts': self.absts.index_select(0, cand.reshape(-1)).view(B, S, -1) if self.absts is not None else zeros(S),
+                'candidate_categ_ids': p["ccat"].index_select(0, rows),
+                'candidate_subcateg_ids': p["csub"].index_select(0, rows),
+                'candidate_mask': (torch.arange(S, device=self.device)[None, :] < clen[:, None]).to(torch.uint8)}
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).to(self.device)
+            self.epoch += 1
+        else:
+            order = torch.arange(self.n, device=self.device)
+        for b in range(len(self)):
+            yield self.batch(order[b * self.batch_size:(b + 1) * self.batch_size])

@@ -19,7 +19,7 @@ from torch.utils.data import DataLoader
 
 from . import parallel
 from .config import Config
-from .data_handler import MyDataset, SyntheticMind, load_dataset, read_dev_labels
+from .data_handler import DeviceFeed, MyDataset, SyntheticMind, load_dataset, read_dev_labels
 from .model import Model
 from .train_eval import test, train
 
@@ -38,6 +38,8 @@ def build_parser():
     parser.add_argument('--batch_size', type=int, default=512)
     parser.add_argument('--precision', type=str, default=None, help='fp32 | bf16x3 | bf16 | fp16 (HIP path)')
     parser.add_argument('--num_workers', type=int, default=6)
+    parser.add_argument('--feed', type=str, default='device', help="device: batches assembled in HBM from a resident news "
+                        "table (DeviceFeed); loader: the reference's DataLoader(MyDataset) with --num_workers processes")
     parser.add_argument('--data_path', type=str, default=None, help='overrides config.data_path (./data_processed/)')
     parser.add_argument('--save_path', type=str, default=None, help='overrides config.save_path (./save_model/)')
     return parser
@@ -95,6 +97,9 @@ def main(argv=None):
         print(model_name, config.device, sum(p.numel() for p in recommender.parameters()), 'parameters')
 
     def loader(samples, typ, shuffle):
+        if args.feed == 'device':
+            return DeviceFeed(config, samples, type=typ, id2title_dict=titles, id2abst_dict=absts, batch_size=config.batch_size,
+                              device=config.device, shuffle=shuffle, drop_last=(world > 1 and typ == 0), seed=422 + rank)
         return DataLoader(MyDataset(config, samples, type=typ, id2title_dict=titles, id2abst_dict=absts), batch_size=config.batch_size,
                           num_workers=args.num_workers, drop_last=(world > 1 and typ == 0), shuffle=shuffle,
                           pin_memory=True)

@@ -443,3 +443,45 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(None, 3)
     assert int(out[0]) == ctypes.sizeof(_lib.EncoderDesc) == 64
     assert int(out[1]) > 4 * 120 * 300 * 4 and int(out[2]) == 0 and "seq_len" in out[3]
+
+
+def test_device_feed_yields_the_batches_of_the_reference_shaped_loader():
+    """data_handler.DeviceFeed (news tables and packed samples resident on the device, a batch = row gathers) against
+    DataLoader(MyDataset(...)) -- whose items are pinned to the reference's own MyDataset by fixture g6 -- on the same
+    samples: identical 13 keys, dtypes and values, training (type 0) and evaluation (type 1) padding, ragged last batch."""
+    from torch.utils.data import DataLoader
+    from pytorch_news_recommender_amd.config import Config
+    from pytorch_news_recommender_amd.data_handler import DeviceFeed, MyDataset, SyntheticMind
+    fx = synth.dataset_fixture_inputs()
+    cfg = Config("feed")
+    cfg.__nrms__()
+    for k, v in fx["config"].items():
+        setattr(cfg, k, v)
+    for typ, samples in ((0, fx["train_samples"]), (1, fx["eval_samples"])):
+        ref = list(DataLoader(MyDataset(cfg, samples, type=typ, id2title_dict=fx["id2title_dict"], id2abst_dict=fx["id2abst_dict"]),
+                              batch_size=2, shuffle=False, num_workers=0))
+        feed = DeviceFeed(cfg, samples, type=typ, id2title_dict=fx["id2title_dict"], id2abst_dict=fx["id2abst_dict"],
+                          batch_size=2, device="cpu")
+        got = list(feed)
+        assert len(got) == len(ref) == len(feed)
+        for a, b in zip(got, ref):
+            assert list(a) == list(b)
+            for k in b:
+                assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), (typ, k)
+    # a larger synthetic corpus with categories, shuffled epochs: every sample exactly once per epoch, different orders
+    cfg2 = Config("feed2")
+    cfg2.__nrms__()
+    cfg2.n_words_title, cfg2.n_words = 12, 500
+    corpus = SyntheticMind(cfg2, n_news=60, n_topics=3, seed=2, vocab=500)
+    samples = corpus.train_samples(37)
+    feed = DeviceFeed(cfg2, samples, type=0, id2title_dict=corpus.id2title_dict, id2abst_dict=corpus.id2abst_dict, batch_size=8,
+                      device="cpu", shuffle=True, seed=5)
+    e1 = torch.cat([b["candidate_ids"] for b in feed])
+    e2 = torch.cat([b["candidate_ids"] for b in feed])
+    want = torch.tensor([s[3] for s in samples])
+    assert e1.shape == want.shape and not torch.equal(e1, e2)
+    key = lambda t: sorted(map(tuple, t.tolist()))
+    assert key(e1) == key(want) == key(e2)
+    b0 = next(iter(DeviceFeed(cfg2, samples, type=0, id2title_dict=corpus.id2title_dict, id2abst_dict=corpus.id2abst_dict,
+                              batch_size=8, device="cpu")))
+    assert int(b0["browsed_categ_ids"].max()) >= 1 and b0["browsed_absts"].shape == (8, cfg2.history_len, cfg2.n_words_abst)
