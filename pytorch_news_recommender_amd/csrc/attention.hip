@@ -41,6 +41,7 @@ struct AttnArgs {
                             // (model/nrms_v1.py:27-33); null = v0 (no mask at all)
     Dropout pdrop;          // dropout on the attention PROBABILITIES (nrms_naml.py:36-39), site 2, element
                             // ((seq * h + head) * S + query) * S + key; thresh 0 = none
+    bool split;             // products as split-bf16 (the bf16x3 / bf16 modes) instead of exact f32 MFMA
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -179,8 +180,31 @@ __device__ __forceinline__ void zero_padding(float* img, int n_img, int SP, int 
             *reinterpret_cast<float2*>(img + (i * SP + S) * RS + 2 * idx) = z;
 }
 
+// ---- split-bf16 products (the bf16x3 / bf16 modes): a 16-deep k-step is three v_mfma_f32_32x32x16_bf16 (hi.hi + hi.lo +
+// lo.hi, ~2^-16 relative) instead of eight v_mfma_f32_32x32x2_f32 -- 96 matrix-pipe cycles instead of 512.  A lane supplies
+// k = 8 hh + j of the step for both operands; an accumulator tile enters as a B operand through its registers 8s..8s+7
+// (k-step s), whose rows are 16 s + 8 (j >> 2) + 4 hh + (j & 3): the A side reads the same rows.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Sp8 { bf16x8 hi, lo; };
+__device__ __forceinline__ Sp8 split8(const float (&x)[8]) {
+    Sp8 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        s.hi[i] = h;
+        s.lo[i] = (__bf16)(x[i] - (float)h);
+    }
+    return s;
+}
+__device__ __forceinline__ f32x16 mma3(const Sp8& a, const Sp8& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+}
+__device__ __forceinline__ int krow16(int s, int j, int hh) { return 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3); }
+
 // S^T (or dP^T) tiles: out[jt][it] += sum_d A[j][d] B[i][d]
-template <int NS, int ND>
+template <int NS, int ND, bool SPLIT = false>
 __device__ __forceinline__ void abt_tiles(const float* A, const float* B, int RS, int l32, int hh,
                                           f32x16 (&out)[NS][NS]) {
 #pragma unroll
@@ -190,6 +214,21 @@ __device__ __forceinline__ void abt_tiles(const float* A, const float* B, int RS
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (SPLIT) {
+#pragma unroll
+                for (int t = 0; t < 2 * ND; ++t) {
+                    float av[8], bv[8];
+                    const float* ap = A + (jt * 32 + l32) * RS + 16 * t + 8 * hh;
+                    const float* bp = B + (it * 32 + l32) * RS + 16 * t + 8 * hh;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[4 + e] = a1[e]; bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                    acc = mma3(split8(av), split8(bv), acc);
+                }
+                out[jt][it] = acc;
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < 4 * ND; ++t) {
                 // k permutation: lane half hh supplies d = 8t + 4hh + e for MFMA e (both operands)
@@ -279,7 +318,7 @@ __device__ __forceinline__ void prob_dropout(f32x16 (&xt)[NS][NS], const Dropout
 }
 
 // out^T[dd][i] = sum_j A[j][dd] X^T[j][i], X^T an accumulator tile set (keys in registers)
-template <int NS, int ND>
+template <int NS, int ND, bool SPLIT = false>
 __device__ __forceinline__ void at_x_tiles(const float* A, int RS, int l32, int hh, const f32x16 (&xt)[NS][NS],
                                            f32x16 (&out)[ND][NS]) {
 #pragma unroll
@@ -289,6 +328,22 @@ __device__ __forceinline__ void at_x_tiles(const float* A, int RS, int l32, int 
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (SPLIT) {
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            av[j] = A[(jt * 32 + krow16(ks, j, hh)) * RS + dt * 32 + l32];
+                            bv[j] = xt[jt][it][8 * ks + j];
+                        }
+                        acc = mma3(split8(av), split8(bv), acc);
+                    }
+                out[dt][it] = acc;
+                continue;
+            }
 #pragma unroll
             for (int jt = 0; jt < NS; ++jt)
 #pragma unroll
@@ -305,7 +360,7 @@ __device__ __forceinline__ void at_x_tiles(const float* A, int RS, int l32, int 
 // [SP][33] floats whatever the sequence length, so it always fits over the dead V tile (a full [64][65] image
 // cost the 64-row kernels a third of their occupancy).
 constexpr int TSH = 33;
-template <int NS, int ND>
+template <int NS, int ND, bool SPLIT = false>
 __device__ __forceinline__ void at_lds_transposed(const float* A, int RS, float* T, const f32x16 (&xt)[NS][NS], int l32,
                                                   int hh, f32x16 (&out)[ND][NS]) {
 #pragma unroll
@@ -321,6 +376,21 @@ __device__ __forceinline__ void at_lds_transposed(const float* A, int RS, float*
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (SPLIT) {
+#pragma unroll
+                for (int t = 0; t < 2 * NS; ++t) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 16 * t + 8 * hh + j;
+                        av[j] = A[i * RS + dt * 32 + l32];
+                        bv[j] = T[i * TSH + l32];
+                    }
+                    acc = mma3(split8(av), split8(bv), acc);
+                }
+                out[dt][jt] = acc;
+                continue;
+            }
 #pragma unroll 8
             for (int t = 0; t < 16 * NS; ++t) {
                 const int i = 2 * t + hh;
@@ -347,7 +417,7 @@ __device__ __forceinline__ void stage_out(float* dst, int RS, const f32x16 (&o)[
 }
 
 // ---------------------------------------------------------------------------------------
-template <int NS, int ND, int WPB, bool MASKED, bool APAD>
+template <int NS, int ND, int WPB, bool MASKED, bool APAD, bool SPLIT>
 __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, WF = 3 * SP * RS + 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -412,11 +482,11 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 
         if (!allpad) {
             f32x16 st[NS][NS];
-            abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
+            abt_tiles<NS, ND, SPLIT>(Ks, Qs, RS, l32, hh, st);
             softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, Ms);
             if (a.pdrop.thresh != 0u) prob_dropout<NS>(st, a.pdrop, u, a.S, l32, hh);
             f32x16 o[ND][NS];
-            at_x_tiles<NS, ND>(Vs, RS, l32, hh, st, o);
+            at_x_tiles<NS, ND, SPLIT>(Vs, RS, l32, hh, st, o);
             wave_sync();
             stage_out<NS, ND>(Qs, RS, o, a.S, a.dk, l32, hh);
         } else {
@@ -491,7 +561,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
 // 32x32 transpose through a wave-private LDS image each.
 // (second launch bound: the 32x32 instantiations must stay at two waves per SIMD, i.e. <= 256 registers; the
 // COMPACT variants would otherwise settle at 260 and lose half their occupancy)
-template <int NS, int ND, int WPB, bool MASKED, bool COMPACT>
+template <int NS, int ND, int WPB, bool MASKED, bool COMPACT, bool SPLIT>
 __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kernel(AttnArgs a) {
     constexpr bool PF = NS == 1;      // prefetch across the compute only where registers allow
     constexpr int SP = 32 * NS, DKP = 32 * ND, RS = DKP + 4, TS = TSH;
@@ -568,10 +638,10 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
 
         if (!allpad) {
         f32x16 st[NS][NS], dp[NS][NS];
-        abt_tiles<NS, ND>(Ks, Qs, RS, l32, hh, st);
+        abt_tiles<NS, ND, SPLIT>(Ks, Qs, RS, l32, hh, st);
         const float* msk = Ms;
         softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, msk);  // st = P^T
-        abt_tiles<NS, ND>(Vs, Gs, RS, l32, hh, dp);         // dp = dP^T
+        abt_tiles<NS, ND, SPLIT>(Vs, Gs, RS, l32, hh, dp);         // dp = dP^T
         // probability dropout: the product above is the gradient of the DROPPED probabilities; through the mask it is
         // dP.  The mask is regenerated here and once more below (for dV) rather than kept in 16 NS^2 registers
         if (a.pdrop.thresh != 0u) prob_dropout<NS>(dp, a.pdrop, u, a.S, l32, hh);
@@ -597,18 +667,18 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         // region); dV stays in registers until that image has also served dK
         f32x16 dv[ND][NS];
         if (a.pdrop.thresh != 0u) prob_dropout<NS>(st, a.pdrop, u, a.S, l32, hh);     // P is dead after dS: dV wants dropped P
-        at_lds_transposed<NS, ND>(Gs, RS, Tb, st, l32, hh, dv);
+        at_lds_transposed<NS, ND, SPLIT>(Gs, RS, Tb, st, l32, hh, dv);
         // dQ^T = K^T dS^T  (keys summed: dS^T straight from registers); K is dead afterwards -> stage dQ there
         {
             f32x16 dq[ND][NS];
-            at_x_tiles<NS, ND>(Ks, RS, l32, hh, dp, dq);
+            at_x_tiles<NS, ND, SPLIT>(Ks, RS, l32, hh, dp, dq);
             wave_sync();
             stage_out<NS, ND>(Ks, RS, dq, a.S, a.dk, l32, hh);
         }
         // dK^T = Q^T dS ; dO is dead -> stage dK there
         {
             f32x16 dkk[ND][NS];
-            at_lds_transposed<NS, ND>(Qs, RS, Tb, dp, l32, hh, dkk);
+            at_lds_transposed<NS, ND, SPLIT>(Qs, RS, Tb, dp, l32, hh, dkk);
             wave_sync();
             stage_out<NS, ND>(Gs, RS, dkk, a.S, a.dk, l32, hh);
         }
@@ -708,8 +778,8 @@ __global__ __launch_bounds__(256) void padsum_reduce_kernel(const float* padsum,
 
 size_t attention_padsum_floats() { return (size_t)(256 * 16 + 256) * 4 * PADSUM_STRIDE; }   // grid cap + up to n_heads - 1 extra blocks, 4 waves each
 
-template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT>
-static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream) {
+template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT, bool SPLIT>
+static int launch_attn_inst4(const AttnArgs& a, float* dbias, hipStream_t stream) {
     constexpr int SP = 32 * NS, RS = 32 * ND + 4;
     constexpr bool ALIAS = SP * 33 <= SP * RS;          // half-width transpose image: always over the V tile
     constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : SP * 33) + 64 + (COMPACT ? 64 + 3 * 32 * ND : 0)) : (3 * SP * RS + 64);
@@ -722,15 +792,15 @@ static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream
         while ((blocks * WPB) % a.h != 0) ++blocks;
     const char* name = BWD ? "attn_bwd" : "attn_fwd";
     hipError_t e;
-    if (BWD) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT>,
+    if (BWD) e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT, SPLIT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    else e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NS, ND, WPB, MASKED, COMPACT && !MASKED>,
+    else e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NS, ND, WPB, MASKED, COMPACT && !MASKED, SPLIT>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
     {
         TimingScope ts(name, stream);
-        if (BWD) hipLaunchKernelGGL((attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB, MASKED, COMPACT && !MASKED>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
+        if (BWD) hipLaunchKernelGGL((attn_bwd_kernel<NS, ND, WPB, MASKED, COMPACT, SPLIT>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<NS, ND, WPB, MASKED, COMPACT && !MASKED, SPLIT>), dim3(blocks), dim3(64 * WPB), bytes, stream, a);
         const int rc = check_launch(name);
         if (rc) return rc;
     }
@@ -741,6 +811,12 @@ static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream
         return check_launch("padsum_reduce");
     }
     return NRMS_OK;
+}
+
+template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT>
+static int launch_attn_inst3(const AttnArgs& a, float* dbias, hipStream_t stream) {
+    return a.split ? launch_attn_inst4<NS, ND, WPB, BWD, MASKED, COMPACT, true>(a, dbias, stream)
+                   : launch_attn_inst4<NS, ND, WPB, BWD, MASKED, COMPACT, false>(a, dbias, stream);
 }
 
 template <int NS, int ND, int WPB, bool BWD>
@@ -756,8 +832,9 @@ static int launch_attn_inst(const AttnArgs& a, float* dbias, hipStream_t stream)
 // backward: pos / padsum / dbias (all three or none) = compact dQKV, see AttnArgs
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
                      const float* dctx, float* dqkv, const uint8_t* mask, const int64_t* ids, const float* bias_hm,
-                     const int* pos, float* padsum, float* dbias, hipStream_t stream, const Dropout* pdrop) {
+                     const int* pos, float* padsum, float* dbias, hipStream_t stream, const Dropout* pdrop, bool split) {
     AttnArgs a;
+    a.split = split;
     a.mask = mask;
     a.pdrop = pdrop != nullptr ? *pdrop : make_dropout(0, 0.f);
     a.n_seq = n_seq; a.S = S; a.d = d; a.h = h; a.dk = d / h;

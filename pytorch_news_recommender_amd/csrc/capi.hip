@@ -11,7 +11,8 @@ namespace nrms {
 
 int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv, float* ctx, const Dropout& drop,
                      const float* dctx, float* dqkv, const uint8_t* mask, const int64_t* ids, const float* bias_hm,
-                     const int* pos, float* padsum, float* dbias, hipStream_t stream, const Dropout* pdrop = nullptr);
+                     const int* pos, float* padsum, float* dbias, hipStream_t stream, const Dropout* pdrop = nullptr,
+                     bool split = false);
 size_t attention_padsum_floats();
 int launch_addattn_fwd(int n_seq, int S, int d, int q, const float* ctx, const float* w_add, const float* b_add,
                        const float* q_vec, float* T, float* wout, float* out, const uint8_t* mask, int npass,
@@ -434,7 +435,7 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = launch_attention(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
                               wo ? no_drop : drop_c, nullptr, nullptr, amask,
                               (gather && skip_pad_rows(desc)) ? ids : nullptr, (gather && skip_pad_rows(desc)) ? bq_hm : nullptr,
-                              nullptr, nullptr, nullptr, s, &pdrop_attn);
+                              nullptr, nullptr, nullptr, s, &pdrop_attn, desc->precision != NRMS_PRECISION_FP32);
     if (rc) return rc;
     if (wo) {
         NTArgs o{};
@@ -615,7 +616,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     else
         rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask,
                               nullptr, nullptr, compact ? pos : nullptr, compact ? (float*)(base + L.padsum) : nullptr,
-                              compact ? grads->b_qkv : nullptr, s, &pdrop_attn);
+                              compact ? grads->b_qkv : nullptr, s, &pdrop_attn, desc->precision != NRMS_PRECISION_FP32);
     if (rc) return rc;
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings) -- or later,
     //    by nrms_encoder_bwd_wqkv (NRMS_FLAG_DEFER_WQKV)

@@ -3,7 +3,7 @@ imported reference's ``model.nrms_naml.Model``: odd widths and the real 300 / 80
 a dropout replay (the keep masks the kernels used -- attention probabilities and feature rows -- fed to the oracle), LayerNorm
 on its own and the fused train step.
 
-Tolerances: scores 1e-4 absolute (north_star); gradients |got - ref| <= rtol |ref| + atol + scale * max|ref| per tensor
+Tolerances: scores 2e-5 (fp32) / 1e-4 (bf16x3, north_star's bar; measured 5e-5 on scores of magnitude 9) absolute; gradients |got - ref| <= rtol |ref| + atol + scale * max|ref| per tensor
 (fp32: summation order; bf16x3: ~2^-16 relative per product)."""
 import os
 
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 MODES = ["fp32", "bf16x3"]
 TOL = {"fp32": dict(score=2e-5, rtol=1e-3, atol=2e-6, scale=3e-6),
-       "bf16x3": dict(score=5e-5, rtol=1e-3, atol=2e-6, scale=4e-5)}
+       "bf16x3": dict(score=1e-4, rtol=1e-3, atol=2e-6, scale=4e-5)}     # scores here are O(10): 1e-4 = 1e-5 relative
 
 
 def make_model(shape, params, dropout=0.0, precision="fp32"):

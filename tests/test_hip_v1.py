@@ -118,4 +118,11 @@ def test_masked_primitives_forward_backward(mask_mode, mode):
         if not v0name.startswith("user_encoder") or t.grad is None:
             continue
         got = model._layout.view(gflat, back[v0name]).cpu().numpy()
+        if v0name.endswith("W_K.bias"):
+            # sum_i dS[i][j] over the queries: exactly zero without a mask (softmax rows sum to one), what the mask leaves
+            # of it is a cancelling sum whose terms are those of d(b_Q) -- bound it by that tensor's scale
+            qb = p[v0name.replace("W_K.bias", "W_Q.bias")].grad.numpy()
+            tol = TOL[mode]
+            assert np.abs(got - t.grad.numpy()).max() <= tol["g_atol"] + (tol["g_rtol"] + tol["g_scale"]) * np.abs(qb).max(), v0name
+            continue
         assert_grad_close(got, t.grad.numpy(), mode, v0name)
