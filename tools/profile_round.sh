@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the per-round profiles on the GPU box (run through gpurun from the repo root):
 #   bash tools/profile_round.sh r01 [bf16x3]
-# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> per-kernel average durations
+# 1. rocprofv3 --kernel-trace --stats of the default bench command (default --steps / --warmup; --no-cpu-baseline only drops
+#    the CPU baseline and the secondary legs, whose kernels would pollute the table)  -> per-kernel average durations
 # 2. FETCH_SIZE and WRITE_SIZE in two separate --pmc passes (MI355X_MICROARCH.md, HBM section: the two
 #    counters do not fit one pass; never combined with any trace domain other than the kernel trace)
 # Raw output lands in gpurun_out/; tools/summarize_profile.py turns it into the files under profiles/.
@@ -11,7 +12,7 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 echo "[profile] kernel stats" >&2
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 \
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" \
     --precision $PREC --no-cpu-baseline > "$OUT/bench_under_profiler.json" 2> "$OUT/stats.err"
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "[profile] pmc $C" >&2
