@@ -397,39 +397,51 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
 
 // order[0][..] = titles with at least one non-padding token, order[1][..] = all-padding titles (each list in
 // whatever order the block counters resolve: titles are independent, results do not depend on it); cnt[0..1] = sizes.
+// 256 titles per workgroup (64 per wave): the id loads of 16 titles are issued together (one dependent load per title made
+// the kernel a 16-long latency chain), and a workgroup reserves its two output ranges with ONE pair of atomics.
 __global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, const int64_t* ids, int* order, int* cnt) {
-    __shared__ int flag[64];
-    __shared__ int base[2];
+    __shared__ int flag[256];
+    __shared__ int wcount[4][2], base[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t0 = blockIdx.x * 64;
-    for (int i = 0; i < 16; ++i) {
-        const int t = t0 + wave * 16 + i;
-        bool pad = true;
-        if (t < n_seq && lane < S) pad = ids[(long)t * S + lane] == 0;
-        const bool empty = __ballot(pad) == ~0ull;
-        if (lane == 0) flag[wave * 16 + i] = t < n_seq ? (empty ? 1 : 0) : -1;
-    }
-    __syncthreads();
-    int f = -1, rank = 0;
-    if (threadIdx.x < 64) {
-        f = flag[threadIdx.x];
-        const unsigned long long m_ne = __ballot(f == 0), m_e = __ballot(f == 1);
-        const unsigned long long below = (1ull << threadIdx.x) - 1ull;
-        rank = f == 0 ? __popcll(m_ne & below) : __popcll(m_e & below);
-        if (threadIdx.x == 0) {
-            base[0] = atomicAdd(cnt + 0, __popcll(m_ne));
-            base[1] = atomicAdd(cnt + 1, __popcll(m_e));
+    const int t0 = blockIdx.x * 256;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        int64_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {           // unconditional loads from clamped addresses: a predicated load is a branch + wait each
+            const int t = min(t0 + wave * 64 + r * 16 + i, n_seq - 1);
+            v[i] = ids[(long)t * S + min(lane, S - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = t0 + wave * 64 + r * 16 + i;
+            const bool empty = __ballot(lane < S && v[i] != 0) == 0ull;
+            if (lane == 0) flag[wave * 64 + r * 16 + i] = t < n_seq ? (empty ? 1 : 0) : -1;
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64 && f >= 0) order[(long)f * n_seq + base[f] + rank] = t0 + threadIdx.x;
+    const int f = flag[threadIdx.x];
+    const unsigned long long m_ne = __ballot(f == 0), m_e = __ballot(f == 1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rank = f == 0 ? __popcll(m_ne & below) : __popcll(m_e & below);
+    if (lane == 0) { wcount[wave][0] = __popcll(m_ne); wcount[wave][1] = __popcll(m_e); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base[0] = atomicAdd(cnt + 0, wcount[0][0] + wcount[1][0] + wcount[2][0] + wcount[3][0]);
+        base[1] = atomicAdd(cnt + 1, wcount[0][1] + wcount[1][1] + wcount[2][1] + wcount[3][1]);
+    }
+    __syncthreads();
+    if (f >= 0) {
+        for (int w = 0; w < wave; ++w) rank += wcount[w][f];
+        order[(long)f * n_seq + base[f] + rank] = t0 + threadIdx.x;
+    }
 }
 
 int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream) {
     if (n_seq <= 0) return NRMS_OK;
     if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) { set_error("title_order: memset failed"); return NRMS_ELAUNCH; }
     TimingScope ts("title_order", stream);
-    hipLaunchKernelGGL(title_order_kernel, dim3(cdiv(n_seq, 64)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+    hipLaunchKernelGGL(title_order_kernel, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
     return check_launch("title_order");
 }
 

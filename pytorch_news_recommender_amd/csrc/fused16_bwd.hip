@@ -789,11 +789,16 @@ __global__ void tn16_reduce_kernel(const float* partial, int splits, int N, int 
         const int nd = nmap[n], kd = kmap[k];
         if (nd < 0 || kd < 0) continue;
         const float* pp = partial + idx;
-        float s0 = 0.f, s1 = 0.f;
+        // eight independent partial sums: eight loads in flight per thread (two made this kernel latency-bound); the
+        // association is fixed, so the result is reproducible
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int sp = 0;
-        for (; sp + 1 < splits; sp += 2) { s0 += pp[(long)sp * total]; s1 += pp[(long)(sp + 1) * total]; }
-        if (sp < splits) s0 += pp[(long)sp * total];
-        dW[(long)nd * ldw + kd] += (s0 + s1) * nscale[n];
+        for (; sp + 8 <= splits; sp += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += pp[(long)(sp + u) * total];
+        }
+        for (; sp < splits; ++sp) s[0] += pp[(long)sp * total];
+        dW[(long)nd * ldw + kd] += (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * nscale[n];
     }
 }
 
@@ -805,8 +810,19 @@ __global__ __launch_bounds__(1024) void red16_kernel(const float* red, int n_wg,
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + c;
     float s = 0.f;
-    if (i < B16_RED)
-        for (int g = rg; g < n_wg; g += 32) s += red[(long)g * B16_RED + i];
+    if (i < B16_RED) {
+        // four loads in flight per thread (one made the kernel a chain of n_wg / 32 dependent loads); fixed association
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int g = rg;
+        for (; g + 96 < n_wg; g += 128) {
+            s0 += red[(long)g * B16_RED + i];
+            s1 += red[(long)(g + 32) * B16_RED + i];
+            s2 += red[(long)(g + 64) * B16_RED + i];
+            s3 += red[(long)(g + 96) * B16_RED + i];
+        }
+        for (; g < n_wg; g += 32) s0 += red[(long)g * B16_RED + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
     part[rg][c] = s;
     __syncthreads();
     if (rg != 0 || i >= B16_RED) return;
