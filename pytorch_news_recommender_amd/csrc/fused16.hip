@@ -120,7 +120,11 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? F16_FWD_WGS : 1) void fused_
             for (int s = 0; s < F16_KS; ++s) xf[b][s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    __asm__ volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the first two tiles have landed
+    // the first two tiles and the x fragments have landed.  The wait is the BUILTIN (vmcnt(0), encoded for gfx9): hipcc's
+    // wait-count pass does not see inline assembly, would still believe the x-fragment loads pending at the loop header and
+    // put a vmcnt(0) in front of every tile's first MFMA -- draining the DMA of the tile after next on every step
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     int n = n_begin;
 #pragma unroll 1
