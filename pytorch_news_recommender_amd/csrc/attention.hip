@@ -152,6 +152,8 @@ struct PrefetchQKV {
                                          int lane) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
+            // (skipping the iterations past the block -- half of them at S = 40, d_k = 50 -- with a wave-uniform branch was
+            // measured: the forward got 13 % slower, every load in a basic block of its own)
             const BlockPos b = at(it, ld, RS, total, w2, hw, magic, lane);    // clamped: raw values only (see Prefetch)
             v[it] = *reinterpret_cast<const float2*>(src + 2 * b.goff);
         }
@@ -416,6 +418,188 @@ __device__ __forceinline__ void stage_out(float* dst, int RS, const f32x16 (&o)[
             for (int r = 0; r < 16; ++r) dst[(it * 32 + l32) * RS + dt * 32 + crow32(r, hh)] = o[dt][it][r];
 }
 
+// ---- query-block forms (the 64-row backward): one 32-query column block `it` of the transposed tile set at a time, so
+// that P^T and dS^T of a unit are 2 NS tiles instead of 2 NS^2 -- the full-set form of the 64 x 64 backward needed ~400
+// registers for tiles alone and spilled up to 405 of them.  Softmax and D are per query, so a block is self-contained;
+// dV and dK (sums over the queries) accumulate across the blocks.
+template <int NS, int ND, bool SPLIT>
+__device__ __forceinline__ void abt_col(const float* A, const float* Bq, int RS, int l32, int hh, f32x16 (&out)[NS]) {
+#pragma unroll
+    for (int jt = 0; jt < NS; ++jt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (SPLIT) {
+#pragma unroll
+            for (int t = 0; t < 2 * ND; ++t) {
+                float av[8], bv[8];
+                const float* ap = A + (jt * 32 + l32) * RS + 16 * t + 8 * hh;
+                const float* bp = Bq + l32 * RS + 16 * t + 8 * hh;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[4 + e] = a1[e]; bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                acc = mma3(split8(av), split8(bv), acc);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4 * ND; ++t) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + (jt * 32 + l32) * RS + 8 * t + 4 * hh);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bq + l32 * RS + 8 * t + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma32(a4[e], b4[e], acc);
+            }
+        }
+        out[jt] = acc;
+    }
+}
+
+template <int NS, bool MASKED>
+__device__ __forceinline__ void softmax_col(f32x16 (&st)[NS], float scale, int S, int it, int l32, int hh, const float* msk) {
+    const float mi = MASKED ? msk[it * 32 + l32] : 1.0f;
+    float mx = -1e30f;
+#pragma unroll
+    for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jt * 32 + crow32(r, hh);
+            float s = st[jt][r] * scale;
+            if (MASKED) s = (mi * msk[j] != 0.f) ? s : -1e9f;
+            s = j < S ? s : -1e30f;
+            st[jt][r] = s;
+            mx = fmaxf(mx, s);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(st[jt][r] - mx);
+            st[jt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[jt][r] *= inv;
+}
+
+// Probability-dropout decisions of one query block as a bit mask (bit 16 jt + r = keep key crow32(r) of key block jt for this
+// lane's query): generated ONCE per block and applied to dP^T and, later, to P^T -- a Philox call is ~100 instructions,
+// and the backward needs the same mask twice (one register instead of 16 NS of scales or a second generation).
+template <int NS>
+__device__ __forceinline__ uint32_t prob_keep_bits_col(const Dropout& pd, long unit, int S, int it, int l32, int hh) {
+    static_assert(NS <= 2, "32 mask bits");
+    const uint64_t row0 = (uint64_t)((unit * S + it * 32 + l32) * S);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint64_t e0 = row0 + jt * 32 + 8 * g + 4 * hh;
+            const f32x4 lo = dropout_scale4(pd.seed, 2u, e0 >> 2, pd.thresh, pd.inv_keep);
+            if ((S & 3) == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bits |= (lo[e] != 0.f ? 1u : 0u) << (16 * jt + 4 * g + e);
+            } else {
+                // the four keys straddle two Philox groups: elements sh..3 of this one, 0..sh-1 of the next
+                const f32x4 hi = dropout_scale4(pd.seed, 2u, (e0 >> 2) + 1, pd.thresh, pd.inv_keep);
+                const int sh = (int)(e0 & 3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = lo[e], a1 = e + 1 < 4 ? lo[(e + 1) & 3] : hi[(e + 1) & 3];
+                    const float a2 = e + 2 < 4 ? lo[(e + 2) & 3] : hi[(e + 2) & 3], a3 = e + 3 < 4 ? lo[(e + 3) & 3] : hi[(e + 3) & 3];
+                    const float sc = sh == 0 ? a0 : (sh == 1 ? a1 : (sh == 2 ? a2 : a3));
+                    bits |= (sc != 0.f ? 1u : 0u) << (16 * jt + 4 * g + e);
+                }
+            }
+        }
+    return bits;
+}
+__device__ __forceinline__ void apply_keep_tile(f32x16& x, uint32_t bits16, float inv_keep) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] *= ((bits16 >> r) & 1u) != 0u ? inv_keep : 0.f;
+}
+
+// out^T[dd][i] = sum_j A[j][dd] X^T[j][i] for the queries i of one block
+template <int NS, int ND, bool SPLIT>
+__device__ __forceinline__ void at_x_col(const float* A, int RS, int l32, int hh, const f32x16 (&xt)[NS], f32x16 (&out)[ND]) {
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NS; ++jt) {
+            if (SPLIT) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        av[j] = A[(jt * 32 + krow16(ks, j, hh)) * RS + dt * 32 + l32];
+                        bv[j] = xt[jt][8 * ks + j];
+                    }
+                    acc = mma3(split8(av), split8(bv), acc);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc = mfma32(A[(jt * 32 + crow32(r, hh)) * RS + dt * 32 + l32], xt[jt][r], acc);
+            }
+        }
+        out[dt] = acc;
+    }
+}
+
+// out^T[dd][j] += sum over the block's queries i of Aq[i][dd] X[i][j]  (Aq = the block's 32 rows; X^T[j][i] through the
+// [32][33] image T, one key block at a time)
+template <int NS, int ND, bool SPLIT>
+__device__ __forceinline__ void at_lds_transposed_col(const float* Aq, int RS, float* T, const f32x16 (&xt)[NS], int l32, int hh,
+                                                      f32x16 (&out)[ND][NS]) {
+#pragma unroll
+    for (int jt = 0; jt < NS; ++jt) {
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[l32 * TSH + crow32(r, hh)] = xt[jt][r];
+        wave_sync();
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            f32x16 acc = out[dt][jt];
+            if (SPLIT) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 16 * t + 8 * hh + j;
+                        av[j] = Aq[i * RS + dt * 32 + l32];
+                        bv[j] = T[i * TSH + l32];
+                    }
+                    acc = mma3(split8(av), split8(bv), acc);
+                }
+            } else {
+#pragma unroll 8
+                for (int t = 0; t < 16; ++t) {
+                    const int i = 2 * t + hh;
+                    acc = mfma32(Aq[i * RS + dt * 32 + l32], T[i * TSH + l32], acc);
+                }
+            }
+            out[dt][jt] = acc;
+        }
+    }
+}
+
+template <int ND>
+__device__ __forceinline__ void stage_out_col(float* dstq, int RS, const f32x16 (&o)[ND], int l32, int hh) {
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dstq[l32 * RS + dt * 32 + crow32(r, hh)] = o[dt][r];
+}
+
 // ---------------------------------------------------------------------------------------
 template <int NS, int ND, int WPB, bool MASKED, bool APAD, bool SPLIT>
 __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
@@ -568,8 +752,9 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
     // the 32x32 transpose image fits inside the V region once V is dead (after dP^T): no LDS of its
     // own -> 18.7 KB per wave instead of 22.9 KB, i.e. 8 waves per CU instead of 6 (this kernel is a
     // long chain of LDS round trips, so it lives off occupancy)
-    constexpr bool ALIAS = SP * TS <= SP * RS;
-    constexpr int WF = 4 * SP * RS + (ALIAS ? 0 : SP * TS) + 64 + (COMPACT ? 64 + 3 * DKP : 0);
+    // (the 64-row form walks the queries in blocks and needs V in every block: its [32][33] image has a region of its own)
+    constexpr bool ALIAS = NS == 1;
+    constexpr int WF = 4 * SP * RS + (ALIAS ? 0 : 32 * TS) + 64 + (COMPACT ? 64 + 3 * DKP : 0);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
@@ -578,7 +763,26 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
     float* Vs = Ks + SP * RS;
     float* Gs = Vs + SP * RS;
     float* Tb = ALIAS ? Vs : Gs + SP * RS;
-    float* Ms = Gs + SP * RS + (ALIAS ? 0 : SP * TS);
+    float* Ms = Gs + SP * RS + (ALIAS ? 0 : 32 * TS);
+    float* dQs = NS == 1 ? Ks : Qs;                     // where dQ is staged (see the two forms below)
+    // 64-column heads (ROWIO): the Q|K|V block of a row is walked by (row, lane) instead of a flat index -- a lane's column,
+    // operand and LDS offsets are constants of the wave, a row's compact position is wave-uniform.  (The flat walk of
+    // PrefetchQKV recomputes row / operand / offsets per element: 96 iterations of ~45 instructions and two dependent LDS
+    // round trips each per unit, with one wave per SIMD to hide them -- most of this kernel's time at S = 40, d_k = 50.)
+    constexpr bool ROWIO = ND == 2;
+    constexpr bool TOPLOAD = ROWIO && !PF;
+    constexpr int KR = 2;                               // float2 per row: 3 d_k / 2 <= 96
+    int rcol[KR], rin[KR], rout[KR];
+    if (ROWIO) {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int c = lane + 64 * k, cc = min(c, a.w2 - 1);
+            const int which = (cc >= a.hw ? 1 : 0) + (cc >= 2 * a.hw ? 1 : 0), col = cc - which * a.hw;
+            rcol[k] = c < a.w2 ? 2 * cc : -1;
+            rin[k] = which * SP * RS + 2 * col;
+            rout[k] = (which == 0 ? (int)(dQs - Qs) : (which == 1 ? (int)(Gs - Qs) : (int)(Vs - Qs))) + 2 * col;
+        }
+    }
     int* Ps = reinterpret_cast<int*>(Ms + 64);          // COMPACT: compact row of each row of the unit (-1 = padding)
     float* Acc = reinterpret_cast<float*>(Ps + 64);    // COMPACT: [3][DKP] column sums of the padding rows of dQ, dK, dV
                                                         // (kept in LDS: three more registers would cost a wave per SIMD)
@@ -606,8 +810,10 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
             ap0 = !MASKED && __ballot(p_cur >= 0) == 0ull;
         }
         pf.init(ld, RS, blk, a.w2, a.hw, a.magic, lane);
-        if (!ap0) pf.load(a.qkv + seq * a.S * ld + head * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
-        pg.load(a.dctx + seq * a.S * a.d + head * a.dk, a.d, a.S, a.dk, lane);
+        if (!TOPLOAD) {
+            if (!ap0) pf.load(a.qkv + seq * a.S * ld + head * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lane);
+            pg.load(a.dctx + seq * a.S * a.d + head * a.dk, a.d, a.S, a.dk, lane);
+        }
     }
     for (; u < total; u += ustride) {
         const long seq = u / a.h;
@@ -621,8 +827,29 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
             allpad = !MASKED && __ballot(p_cur >= 0) == 0ull;        // no live token in this sequence
             ap_next = !MASKED && __ballot(p_n1 >= 0) == 0ull;
         }
+        // 64 x 64 tiles: no registers to carry the next unit across the compute (a conditional load at the end of the
+        // previous iteration kept all 192 of them live through it) -- this unit's operands are loaded here
+        if (TOPLOAD) pg.load(a.dctx + seq * a.S * a.d + head * a.dk, a.d, a.S, a.dk, lane);
         if (!allpad) {
-            pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            if (TOPLOAD) {
+                const float* src = a.qkv + seq * a.S * ld + head * 3 * a.dk;
+                constexpr int RB = 32;                          // 64 row pieces in flight: S = 40 pays the memory latency twice
+                for (int r0 = 0; r0 < a.S; r0 += RB) {
+                    float2 t[RB][KR];
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+#pragma unroll
+                        for (int k = 0; k < KR; ++k)
+                            t[i][k] = *reinterpret_cast<const float2*>(src + (long)min(r0 + i, a.S - 1) * ld + max(rcol[k], 0));
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+#pragma unroll
+                        for (int k = 0; k < KR; ++k)
+                            if (rcol[k] >= 0 && r0 + i < a.S) *reinterpret_cast<float2*>(Qs + rin[k] + (r0 + i) * RS) = t[i][k];
+                }
+            } else {
+                pf.store(Qs, SP * RS, ld, RS, blk, a.w2, a.hw, a.magic, lv);
+            }
             zero_padding(Qs, 3, SP, RS, DKP, a.S, a.dk, lane);
         }
         pg.store(Gs, RS, a.S, a.dk, lane);      // dctx arrives already masked (dctx GEMM epilogue)
@@ -637,14 +864,70 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         if (COMPACT) { p_cur = p_n1; p_n1 = p_n2; p_n2 = pos_of(u + 3 * ustride); }
 
         if (!allpad) {
+        const float* msk = Ms;
+        if constexpr (NS > 1) {
+            // query-block form: per block of 32 queries P^T, dP^T -> dS^T, the block's dQ (complete), and its
+            // contribution to dV and dK; dQ is staged over the block's own Q rows once dK has read them
+            f32x16 dv[ND][NS], dkk[ND][NS];
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { dv[dt][jt][r] = 0.f; dkk[dt][jt][r] = 0.f; }
+#pragma unroll
+            for (int it = 0; it < NS; ++it) {
+                f32x16 st[NS], dp[NS];
+                abt_col<NS, ND, SPLIT>(Ks, Qs + it * 32 * RS, RS, l32, hh, st);
+                softmax_col<NS, MASKED>(st, a.scale, a.S, it, l32, hh, msk);          // st = P^T
+                abt_col<NS, ND, SPLIT>(Vs, Gs + it * 32 * RS, RS, l32, hh, dp);        // dp = dP^T (of the dropped P)
+                uint32_t keep = 0;
+                if (a.pdrop.thresh != 0u) {
+                    keep = prob_keep_bits_col<NS>(a.pdrop, u, a.S, it, l32, hh);
+#pragma unroll
+                    for (int jt = 0; jt < NS; ++jt) apply_keep_tile(dp[jt], keep >> (16 * jt), a.pdrop.inv_keep);
+                }
+                float D = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) D += st[jt][r] * dp[jt][r];
+                D += __shfl_xor(D, 32, 64);
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float dsv = st[jt][r] * (dp[jt][r] - D) * a.scale;                                     // dS^T
+                        if (MASKED && msk[it * 32 + l32] * msk[jt * 32 + crow32(r, hh)] == 0.f) dsv = 0.f;
+                        dp[jt][r] = dsv;
+                    }
+                if (a.pdrop.thresh != 0u) {                                         // dV wants the dropped P
+#pragma unroll
+                    for (int jt = 0; jt < NS; ++jt) apply_keep_tile(st[jt], keep >> (16 * jt), a.pdrop.inv_keep);
+                }
+                at_lds_transposed_col<NS, ND, SPLIT>(Gs + it * 32 * RS, RS, Tb, st, l32, hh, dv);       // dV^T += dO^T P
+                at_lds_transposed_col<NS, ND, SPLIT>(Qs + it * 32 * RS, RS, Tb, dp, l32, hh, dkk);      // dK^T += Q^T dS
+                f32x16 dq[ND];
+                at_x_col<NS, ND, SPLIT>(Ks, RS, l32, hh, dp, dq);                                       // dQ^T = K^T dS^T
+                wave_sync();
+                stage_out_col<ND>(Qs + it * 32 * RS, RS, dq, l32, hh);
+            }
+            wave_sync();                                           // K, V, dO are dead
+            stage_out<NS, ND>(Gs, RS, dkk, a.S, a.dk, l32, hh);
+            stage_out<NS, ND>(Vs, RS, dv, a.S, a.dk, l32, hh);
+            wave_sync();
+        } else {
         f32x16 st[NS][NS], dp[NS][NS];
         abt_tiles<NS, ND, SPLIT>(Ks, Qs, RS, l32, hh, st);
-        const float* msk = Ms;
         softmax_cols<NS, MASKED>(st, a.scale, a.S, l32, hh, msk);  // st = P^T
         abt_tiles<NS, ND, SPLIT>(Vs, Gs, RS, l32, hh, dp);         // dp = dP^T
         // probability dropout: the product above is the gradient of the DROPPED probabilities; through the mask it is
-        // dP.  The mask is regenerated here and once more below (for dV) rather than kept in 16 NS^2 registers
-        if (a.pdrop.thresh != 0u) prob_dropout<NS>(dp, a.pdrop, u, a.S, l32, hh);
+        // dP.  The keep decisions are generated once, as 16 bits, and used again below (for dV)
+        uint32_t keep = 0;
+        if (a.pdrop.thresh != 0u) {
+            keep = prob_keep_bits_col<1>(a.pdrop, u, a.S, 0, l32, hh);
+            apply_keep_tile(dp[0][0], keep, a.pdrop.inv_keep);
+        }
 #pragma unroll
         for (int it = 0; it < NS; ++it) {
             float D = 0.f;
@@ -666,7 +949,7 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         // dV^T = dO^T P  (queries summed: P through the transpose image, which may live in the dead V
         // region); dV stays in registers until that image has also served dK
         f32x16 dv[ND][NS];
-        if (a.pdrop.thresh != 0u) prob_dropout<NS>(st, a.pdrop, u, a.S, l32, hh);     // P is dead after dS: dV wants dropped P
+        if (a.pdrop.thresh != 0u) apply_keep_tile(st[0][0], keep, a.pdrop.inv_keep);   // P is dead after dS: dV wants dropped P
         at_lds_transposed<NS, ND, SPLIT>(Gs, RS, Tb, st, l32, hh, dv);
         // dQ^T = K^T dS^T  (keys summed: dS^T straight from registers); K is dead afterwards -> stage dQ there
         {
@@ -684,18 +967,41 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         }
         stage_out<NS, ND>(Vs, RS, dv, a.S, a.dk, l32, hh);     // transpose image is dead now
         wave_sync();
+        }
 
         // dQ | dK | dV of this head: one contiguous block per row again, written densely
         {
             float* ob = a.dqkv + (COMPACT ? 0 : seq * a.S * ld) + head * 3 * a.dk;
-            constexpr int OIT = 24 * NS * ND;
+            constexpr int OIT = ROWIO ? 0 : 24 * NS * ND;
+            if (ROWIO) {
+                for (int r0 = 0; r0 < a.S; r0 += 4) {
+                    int crow[4];
+                    float2 t[4][KR];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // row r of the unit lives in row Ps[r] of the compact dqkv (-1: a padding token, no row)
+                        const int r = min(r0 + i, a.S - 1);
+                        crow[i] = COMPACT ? __builtin_amdgcn_readfirstlane(Ps[r]) : r;
+                        if (r0 + i >= a.S) crow[i] = -1;
+#pragma unroll
+                        for (int k = 0; k < KR; ++k) t[i][k] = *reinterpret_cast<const float2*>(Qs + rout[k] + r * RS);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (crow[i] >= 0) {
+#pragma unroll
+                            for (int k = 0; k < KR; ++k)
+                                if (rcol[k] >= 0) *reinterpret_cast<float2*>(ob + (long)crow[i] * ld + rcol[k]) = t[i][k];
+                        }
+                }
+            }
 #pragma unroll                                   // full: a run-time `it` would push pos[] into scratch
             for (int it = 0; it < OIT; ++it) {
                 // (the scheduler would otherwise hoist all 24 strip reads ahead of the stores: +8 live registers,
                 // which is one wave per SIMD at this kernel's 256)
                 if (COMPACT && (it & 3) == 0) __builtin_amdgcn_sched_barrier(0);
                 const BlockPos b = pf.at(it, ld, RS, blk, a.w2, a.hw, a.magic, lv);
-                const float* img = b.which == 0 ? Ks : (b.which == 1 ? Gs : Vs);   // dQ, dK, dV staging images
+                const float* img = b.which == 0 ? dQs : (b.which == 1 ? Gs : Vs);   // dQ, dK, dV staging images
                 if (COMPACT) {
                     // same block, but row r of the unit lives in row Ps[r] of the compact dqkv
                     const int crow = Ps[b.ok ? b.row : 0];
@@ -716,7 +1022,7 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
 #pragma unroll 4
                 for (int r = rg; r < a.S; r += RG) {
                     const float m = Ps[r] < 0 ? 1.0f : 0.0f;
-                    s0 += m * Ks[r * RS + col];
+                    s0 += m * dQs[r * RS + col];
                     s1 += m * Gs[r * RS + col];
                     s2 += m * Vs[r * RS + col];
                 }
@@ -744,7 +1050,7 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
             if (ND != 1 || hh == 0) Acc[2 * DKP + col] += s2;
         }
         wave_sync();
-        if (!PF) {                            // big tiles: no registers to spare, load after the compute
+        if (!PF && !TOPLOAD) {                // 64 x 32 tiles: no registers to spare, load after the compute
             const long un = min(u + ustride, total - 1), sn = un / a.h;
             const int hn = (int)(un - sn * a.h);
             if (!ap_next) pf.load(a.qkv + sn * a.S * ld + hn * 3 * a.dk, ld, RS, blk, a.w2, a.hw, a.magic, lv);
@@ -776,13 +1082,228 @@ __global__ __launch_bounds__(256) void padsum_reduce_kernel(const float* padsum,
     if (lane == 0) dbias[perm.src(np)] += s;
 }
 
+// ---------------------------------------------------------------------------------------
+// Backward of the 64 x 64 units (S > 32 and d_k > 32: nrms_naml's abstracts, S = 40, d_k = 50), TWO waves per unit.
+// A wave's four [64][68] operand images are 70 KB of LDS: with a wave per unit only two units fit a CU and two of its four
+// SIMDs sit idle, each wave a single dependent chain of LDS round trips and MFMAs.  Here wave w owns query block w of the
+// unit (the block form above): its P^T / dS^T, the block's dQ (complete) and its share of dV and dK (sums over ITS
+// queries); the two shares meet in the staging images (wave 0 stores dK and wave 1 dV, then each adds its share of the
+// other, a fixed order).  Same LDS per unit, every SIMD busy, half the time per unit.
+template <bool MASKED, bool COMPACT, bool SPLIT>
+__global__ __launch_bounds__(128, 1) void attn_bwd_coop_kernel(AttnArgs a) {
+    constexpr int NS = 2, ND = 2, SP = 64, DKP = 64, RS = DKP + 4, TS = TSH, KR = 2;
+    constexpr int WF = 4 * SP * RS + 2 * 32 * TS + 64 + (COMPACT ? 64 + 3 * DKP : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l32 = lane & 31, hh = lane >> 5;
+    float* Qs = lds;
+    float* Ks = Qs + SP * RS;
+    float* Vs = Ks + SP * RS;
+    float* Gs = Vs + SP * RS;
+    float* Tb = Gs + SP * RS + w * 32 * TS;              // this wave's transpose image
+    float* Ms = Gs + SP * RS + 2 * 32 * TS;
+    int* Ps = reinterpret_cast<int*>(Ms + 64);
+    float* Acc = reinterpret_cast<float*>(Ps + 64);
+    for (int i = threadIdx.x; i < WF; i += 128) Qs[i] = 0.f;
+    __syncthreads();
+
+    const long total = (long)a.n_seq * a.h;
+    const long ld = 3L * a.d;
+    int rcol[KR], rin[KR], rout[KR];                    // see ROWIO in attn_bwd_kernel; dQ is staged over Q
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int c = lane + 64 * k, cc = min(c, a.w2 - 1);
+        const int which = (cc >= a.hw ? 1 : 0) + (cc >= 2 * a.hw ? 1 : 0), col = cc - which * a.hw;
+        rcol[k] = c < a.w2 ? 2 * cc : -1;
+        rin[k] = which * SP * RS + 2 * col;
+        rout[k] = (which == 0 ? 0 : (which == 1 ? 3 * SP * RS : 2 * SP * RS)) + 2 * col;     // dQ in Qs, dK in Gs, dV in Vs
+    }
+    const int Sw = min(32, a.S - 32 * w);               // rows of this wave's query block (S > 32: at least 1)
+    float* Qw = Qs + w * 32 * RS;
+    float* Gw = Gs + w * 32 * RS;
+    auto pos_of = [&](long uu) { return lane < a.S ? a.pos[(min(uu, total - 1) / a.h) * a.S + lane] : -1; };
+    int p_cur = 0, p_n1 = 0;
+    if (COMPACT) { p_cur = pos_of(blockIdx.x); p_n1 = pos_of((long)blockIdx.x + gridDim.x); }
+
+    for (long u = blockIdx.x; u < total; u += gridDim.x) {
+        const long seq = u / a.h;
+        const int head = (int)(u - seq * a.h);
+        bool allpad = false;
+        if (COMPACT) {
+            if (w == 0) Ps[lane] = lane < a.S ? p_cur : 0;
+            allpad = !MASKED && __ballot(p_cur >= 0) == 0ull;        // no live token in this sequence
+        }
+        // each wave brings its block's dO rows and its half of the Q|K|V rows
+        Prefetch<1, ND> pg;
+        pg.load(a.dctx + (seq * a.S + 32 * w) * a.d + head * a.dk, a.d, Sw, a.dk, lane);
+        if (!allpad) {
+            const float* src = a.qkv + seq * a.S * ld + head * 3 * a.dk;
+            const int r0 = 32 * w;
+            float2 t[32][KR];
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+#pragma unroll
+                for (int k = 0; k < KR; ++k)
+                    t[i][k] = *reinterpret_cast<const float2*>(src + (long)min(r0 + i, a.S - 1) * ld + max(rcol[k], 0));
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+#pragma unroll
+                for (int k = 0; k < KR; ++k)
+                    if (rcol[k] >= 0 && r0 + i < a.S) *reinterpret_cast<float2*>(Qs + rin[k] + (r0 + i) * RS) = t[i][k];
+            if (w == 0) zero_padding(Qs, 2, SP, RS, DKP, a.S, a.dk, lane);
+            else zero_padding(Vs, 1, SP, RS, DKP, a.S, a.dk, lane);
+        }
+        pg.store(Gw, RS, Sw, a.dk, lane);               // dctx arrives already masked (dctx GEMM epilogue)
+        if (MASKED && w == 0) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
+        if (COMPACT) { p_cur = p_n1; p_n1 = pos_of(u + 2L * gridDim.x); }
+        __syncthreads();
+
+        if (!allpad) {
+            const float* msk = Ms;
+            f32x16 st[NS], dp[NS];
+            abt_col<NS, ND, SPLIT>(Ks, Qw, RS, l32, hh, st);
+            softmax_col<NS, MASKED>(st, a.scale, a.S, w, l32, hh, msk);              // st = P^T
+            abt_col<NS, ND, SPLIT>(Vs, Gw, RS, l32, hh, dp);                          // dp = dP^T (of the dropped P)
+            uint32_t keep = 0;
+            if (a.pdrop.thresh != 0u) {
+                keep = prob_keep_bits_col<NS>(a.pdrop, u, a.S, w, l32, hh);
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt) apply_keep_tile(dp[jt], keep >> (16 * jt), a.pdrop.inv_keep);
+            }
+            float D = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) D += st[jt][r] * dp[jt][r];
+            D += __shfl_xor(D, 32, 64);
+#pragma unroll
+            for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float dsv = st[jt][r] * (dp[jt][r] - D) * a.scale;                                         // dS^T
+                    if (MASKED && msk[w * 32 + l32] * msk[jt * 32 + crow32(r, hh)] == 0.f) dsv = 0.f;
+                    dp[jt][r] = dsv;
+                }
+            if (a.pdrop.thresh != 0u) {                                             // dV wants the dropped P
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt) apply_keep_tile(st[jt], keep >> (16 * jt), a.pdrop.inv_keep);
+            }
+            f32x16 dv[ND][NS], dkk[ND][NS];
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { dv[dt][jt][r] = 0.f; dkk[dt][jt][r] = 0.f; }
+            at_lds_transposed_col<NS, ND, SPLIT>(Gw, RS, Tb, st, l32, hh, dv);           // this block's dO^T P
+            at_lds_transposed_col<NS, ND, SPLIT>(Qw, RS, Tb, dp, l32, hh, dkk);          // this block's Q^T dS
+            f32x16 dq[ND];
+            at_x_col<NS, ND, SPLIT>(Ks, RS, l32, hh, dp, dq);                            // dQ^T = K^T dS^T, complete
+            wave_sync();
+            stage_out_col<ND>(Qw, RS, dq, l32, hh);
+            __syncthreads();                                   // K, V, dO are dead in both waves
+            if (w == 0) stage_out<NS, ND>(Gs, RS, dkk, a.S, a.dk, l32, hh);
+            else stage_out<NS, ND>(Vs, RS, dv, a.S, a.dk, l32, hh);
+            __syncthreads();
+            {
+                float* dst = w == 0 ? Vs : Gs;                 // the other wave's share is there: add this one's
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                    for (int it = 0; it < NS; ++it)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dst[(it * 32 + l32) * RS + dt * 32 + crow32(r, hh)] += w == 0 ? dv[dt][it][r] : dkk[dt][it][r];
+            }
+            __syncthreads();
+
+            // dQ | dK | dV of this head, one contiguous block per row; the waves take alternate groups of four rows
+            float* ob = a.dqkv + (COMPACT ? 0 : seq * a.S * ld) + head * 3 * a.dk;
+            for (int r0 = 4 * w; r0 < a.S; r0 += 8) {
+                int crow[4];
+                float2 t[4][KR];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = min(r0 + i, a.S - 1);
+                    crow[i] = COMPACT ? __builtin_amdgcn_readfirstlane(Ps[r]) : r;
+                    if (r0 + i >= a.S) crow[i] = -1;
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) t[i][k] = *reinterpret_cast<const float2*>(Qs + rout[k] + r * RS);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (crow[i] >= 0) {
+#pragma unroll
+                        for (int k = 0; k < KR; ++k)
+                            if (rcol[k] >= 0) *reinterpret_cast<float2*>(ob + (long)crow[i] * ld + rcol[k]) = t[i][k];
+                    }
+            }
+            if (COMPACT) {
+                // padding rows: their dQ | dK (wave 0) and dV (wave 1) column sums, one column per lane
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+                for (int r = 0; r < a.S; ++r) {
+                    const float m = Ps[r] < 0 ? 1.0f : 0.0f;
+                    if (w == 0) { s0 += m * Qs[r * RS + lane]; s1 += m * Gs[r * RS + lane]; }
+                    else s0 += m * Vs[r * RS + lane];
+                }
+                if (w == 0) { Acc[lane] += s0; Acc[DKP + lane] += s1; }
+                else Acc[2 * DKP + lane] += s0;
+            }
+        } else if (w == 1) {
+            // all-padding sequence: dQ = dK = 0, every dV row the mean of the dO rows; only the rows' dV sum counts
+            float s2 = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < a.S; ++r) s2 += Gs[r * RS + lane];
+            Acc[2 * DKP + lane] += s2;
+        }
+        __syncthreads();
+    }
+    if (COMPACT && w == 0 && lane < a.dk) {
+        float* out = a.padsum + (long)blockIdx.x * PADSUM_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i * a.dk + lane] = Acc[i * DKP + lane];
+    }
+}
+
+template <bool MASKED, bool COMPACT>
+static int launch_attn_bwd_coop2(const AttnArgs& a, float* dbias, hipStream_t stream) {
+    constexpr size_t bytes = (4 * 64 * 68 + 2 * 32 * 33 + 64 + (COMPACT ? 64 + 3 * 64 : 0)) * sizeof(float);
+    const long total = (long)a.n_seq * a.h;
+    int blocks = (int)(total < 256 * 16 ? total : 256 * 16);
+    if (COMPACT)                            // every workgroup keeps one head: unit stride = multiple of h
+        while (blocks % a.h != 0) ++blocks;
+    auto kern = a.split ? attn_bwd_coop_kernel<MASKED, COMPACT, true> : attn_bwd_coop_kernel<MASKED, COMPACT, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    {
+        TimingScope ts("attn_bwd", stream);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), bytes, stream, a);
+        const int rc = check_launch("attn_bwd");
+        if (rc) return rc;
+    }
+    if (COMPACT) {
+        TimingScope ts("padsum_reduce", stream);
+        hipLaunchKernelGGL(padsum_reduce_kernel, dim3(cdiv(3 * a.d, 4)), dim3(256), 0, stream, a.padsum, blocks, a.h, a.dk,
+                           HeadPerm{a.dk, a.h}, dbias);
+        return check_launch("padsum_reduce");
+    }
+    return NRMS_OK;
+}
+
+static int launch_attn_bwd_coop(const AttnArgs& a, float* dbias, hipStream_t stream) {
+    if (a.pos != nullptr)
+        return a.mask != nullptr ? launch_attn_bwd_coop2<true, true>(a, dbias, stream) : launch_attn_bwd_coop2<false, true>(a, dbias, stream);
+    return a.mask != nullptr ? launch_attn_bwd_coop2<true, false>(a, dbias, stream) : launch_attn_bwd_coop2<false, false>(a, dbias, stream);
+}
+
 size_t attention_padsum_floats() { return (size_t)(256 * 16 + 256) * 4 * PADSUM_STRIDE; }   // grid cap + up to n_heads - 1 extra blocks, 4 waves each
 
 template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT, bool SPLIT>
 static int launch_attn_inst4(const AttnArgs& a, float* dbias, hipStream_t stream) {
     constexpr int SP = 32 * NS, RS = 32 * ND + 4;
-    constexpr bool ALIAS = SP * 33 <= SP * RS;          // half-width transpose image: always over the V tile
-    constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : SP * 33) + 64 + (COMPACT ? 64 + 3 * 32 * ND : 0)) : (3 * SP * RS + 64);
+    constexpr bool ALIAS = NS == 1;                     // 32-row units: the transpose image lives over the dead V tile
+    constexpr size_t wf = BWD ? (4 * SP * RS + (ALIAS ? 0 : 32 * 33) + 64 + (COMPACT ? 64 + 3 * 32 * ND : 0)) : (3 * SP * RS + 64);
     constexpr size_t bytes = wf * WPB * sizeof(float);
     const long total = (long)a.n_seq * a.h;
     int blocks = (int)((total + WPB - 1) / WPB);
@@ -858,7 +1379,7 @@ int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv,
     if (ns == 1 && nd == 1) return launch_attn_inst<1, 1, 2, true>(a, dbias, stream);
     if (ns == 2 && nd == 1) return launch_attn_inst<2, 1, 1, true>(a, dbias, stream);
     if (ns == 1 && nd == 2) return launch_attn_inst<1, 2, 1, true>(a, dbias, stream);
-    return launch_attn_inst<2, 2, 1, true>(a, dbias, stream);
+    return launch_attn_bwd_coop(a, dbias, stream);      // 64 x 64 units: two waves per unit
 }
 
 }  // namespace nrms
