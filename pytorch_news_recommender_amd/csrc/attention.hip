@@ -1297,6 +1297,129 @@ static int launch_attn_bwd_coop(const AttnArgs& a, float* dbias, hipStream_t str
     return a.mask != nullptr ? launch_attn_bwd_coop2<true, false>(a, dbias, stream) : launch_attn_bwd_coop2<false, false>(a, dbias, stream);
 }
 
+// ---------------------------------------------------------------------------------------
+// Forward of the 64 x 64 units, two waves per unit (see attn_bwd_coop_kernel): wave w loads half of the Q|K|V rows and
+// computes the context rows of query block w -- scores against all keys, softmax, probability dropout, P V -- which
+// it stages over its own Q rows and writes out.  No operand prefetch across units (it cost 192 registers and ~45
+// instructions per float2 in the flat walk); six waves per CU instead of three hide the load instead.
+template <bool MASKED, bool APAD, bool SPLIT>
+__global__ __launch_bounds__(128, 2) void attn_fwd_coop_kernel(AttnArgs a) {
+    constexpr int NS = 2, ND = 2, SP = 64, DKP = 64, RS = DKP + 4, KR = 2;
+    constexpr int WF = 3 * SP * RS + 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l32 = lane & 31, hh = lane >> 5;
+    float* Qs = lds;
+    float* Ks = Qs + SP * RS;
+    float* Vs = Ks + SP * RS;
+    float* Ms = Vs + SP * RS;
+    for (int i = threadIdx.x; i < WF; i += 128) Qs[i] = 0.f;
+    __syncthreads();
+
+    const long total = (long)a.n_seq * a.h;
+    const long ld = 3L * a.d;
+    int rcol[KR], rin[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int c = lane + 64 * k, cc = min(c, a.w2 - 1);
+        const int which = (cc >= a.hw ? 1 : 0) + (cc >= 2 * a.hw ? 1 : 0), col = cc - which * a.hw;
+        rcol[k] = c < a.w2 ? 2 * cc : -1;
+        rin[k] = which * SP * RS + 2 * col;
+    }
+    const int rend = min(a.S, 32 * w + 32);             // this wave's rows: [32 w, rend)
+    float* Qw = Qs + w * 32 * RS;
+    auto id_of = [&](long uu) { return lane < a.S ? a.ids[(min(uu, total - 1) / a.h) * a.S + lane] : 0; };
+    long id_cur = 1, id_n1 = 1;
+    if (APAD) { id_cur = id_of(blockIdx.x); id_n1 = id_of((long)blockIdx.x + gridDim.x); }
+
+    for (long u = blockIdx.x; u < total; u += gridDim.x) {
+        const long seq = u / a.h;
+        const int head = (int)(u - seq * a.h);
+        const bool allpad = APAD && __ballot(id_cur != 0) == 0ull;
+        if (APAD) { id_cur = id_n1; id_n1 = id_of(u + 2L * gridDim.x); }
+        if (!allpad) {
+            const float* src = a.qkv + seq * a.S * ld + head * 3 * a.dk;
+            const int r0 = 32 * w;
+            float2 t[32][KR];
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+#pragma unroll
+                for (int k = 0; k < KR; ++k)
+                    t[i][k] = *reinterpret_cast<const float2*>(src + (long)min(r0 + i, a.S - 1) * ld + max(rcol[k], 0));
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+#pragma unroll
+                for (int k = 0; k < KR; ++k)
+                    if (rcol[k] >= 0 && r0 + i < a.S) *reinterpret_cast<float2*>(Qs + rin[k] + (r0 + i) * RS) = t[i][k];
+            if (w == 0) zero_padding(Qs, 2, SP, RS, DKP, a.S, a.dk, lane);
+            else zero_padding(Vs, 1, SP, RS, DKP, a.S, a.dk, lane);
+            if (MASKED && w == 0) Ms[lane] = (lane < a.S && a.mask[seq * a.S + lane] != 0) ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (!allpad) {
+            f32x16 st[NS];
+            abt_col<NS, ND, SPLIT>(Ks, Qw, RS, l32, hh, st);
+            softmax_col<NS, MASKED>(st, a.scale, a.S, w, l32, hh, Ms);
+            if (a.pdrop.thresh != 0u) {
+                const uint32_t keep = prob_keep_bits_col<NS>(a.pdrop, u, a.S, w, l32, hh);
+#pragma unroll
+                for (int jt = 0; jt < NS; ++jt) apply_keep_tile(st[jt], keep >> (16 * jt), a.pdrop.inv_keep);
+            }
+            f32x16 o[ND];
+            at_x_col<NS, ND, SPLIT>(Vs, RS, l32, hh, st, o);
+            wave_sync();
+            stage_out_col<ND>(Qw, RS, o, l32, hh);
+        } else {
+            // uniform attention over identical rows: every context row is the V bias of this head
+            const float* bv = a.bias_hm + head * 3 * a.dk + 2 * a.dk;
+            for (int i = lane; i < 32 * a.hw; i += 64) {
+                const int r = i / a.hw, c2 = i - r * a.hw;
+                *reinterpret_cast<float2*>(Qw + r * RS + 2 * c2) = *reinterpret_cast<const float2*>(bv + 2 * c2);
+            }
+        }
+        wave_sync();
+        // ctx[seq*S + r][head*dk + c] of this wave's rows through dropout site 1: 32 lanes per row
+        {
+            const int c2 = l32;
+            if (2 * c2 < a.dk) {
+                for (int r = 32 * w + hh; r < rend; r += 2) {
+                    float2 v = *reinterpret_cast<const float2*>(Qs + r * RS + 2 * c2);
+                    const long m = seq * a.S + r;
+                    const int col = head * a.dk + 2 * c2;
+                    if (a.drop.thresh != 0u) {
+                        uint32_t rnd[4];
+                        const uint64_t e = (uint64_t)(m * a.d + col);
+                        philox4x32_7(a.drop.seed, e >> 2, 1u, rnd);
+                        const int q = (int)(e & 3);          // 0 or 2: col is even
+                        v.x = (q == 0 ? rnd[0] : rnd[2]) >= a.drop.thresh ? v.x * a.drop.inv_keep : 0.f;
+                        v.y = (q == 0 ? rnd[1] : rnd[3]) >= a.drop.thresh ? v.y * a.drop.inv_keep : 0.f;
+                    }
+                    *reinterpret_cast<float2*>(a.ctx + m * a.d + col) = v;
+                }
+            }
+        }
+        __syncthreads();                                   // the other wave may still be reading K and V
+    }
+}
+
+template <bool MASKED, bool APAD>
+static int launch_attn_fwd_coop2(const AttnArgs& a, hipStream_t stream) {
+    constexpr size_t bytes = (3 * 64 * 68 + 64) * sizeof(float);
+    const long total = (long)a.n_seq * a.h;
+    const int blocks = (int)(total < 256 * 24 ? total : 256 * 24);
+    auto kern = a.split ? attn_fwd_coop_kernel<MASKED, APAD, true> : attn_fwd_coop_kernel<MASKED, APAD, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    TimingScope ts("attn_fwd", stream);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), bytes, stream, a);
+    return check_launch("attn_fwd");
+}
+
+static int launch_attn_fwd_coop(const AttnArgs& a, hipStream_t stream) {
+    if (a.mask != nullptr) return launch_attn_fwd_coop2<true, false>(a, stream);     // (the shortcut needs an unmasked unit)
+    return a.ids != nullptr ? launch_attn_fwd_coop2<false, true>(a, stream) : launch_attn_fwd_coop2<false, false>(a, stream);
+}
+
 size_t attention_padsum_floats() { return (size_t)(256 * 16 + 256) * 4 * PADSUM_STRIDE; }   // grid cap + up to n_heads - 1 extra blocks, 4 waves each
 
 template <int NS, int ND, int WPB, bool BWD, bool MASKED, bool COMPACT, bool SPLIT>
@@ -1374,7 +1497,7 @@ int launch_attention(bool bwd, int n_seq, int S, int d, int h, const float* qkv,
         if (ns == 1 && nd == 1) return launch_attn_inst<1, 1, 4, false>(a, dbias, stream);
         if (ns == 2 && nd == 1) return launch_attn_inst<2, 1, 2, false>(a, dbias, stream);
         if (ns == 1 && nd == 2) return launch_attn_inst<1, 2, 2, false>(a, dbias, stream);
-        return launch_attn_inst<2, 2, 1, false>(a, dbias, stream);
+        return launch_attn_fwd_coop(a, stream);          // 64 x 64 units: two waves per unit
     }
     if (ns == 1 && nd == 1) return launch_attn_inst<1, 1, 2, true>(a, dbias, stream);
     if (ns == 2 && nd == 1) return launch_attn_inst<2, 1, 1, true>(a, dbias, stream);
