@@ -58,16 +58,19 @@ class GradAllReduce:
     """callable(flat_grad): in-place sum over ranks of the single flat gradient buffer
     (57.6 MB at V=45 800).  One large message, as the xGMI mesh prefers."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force: issue the collectives even in a one-rank group (tests/test_hip_dp.py runs the RCCL calls, their stream
+        # ordering and the overlap with the deferred d(W_qkv) GEMMs on a single GPU that way)
+        self.active = self.world > 1 or (force and dist.is_initialized())
 
     def start(self, part: torch.Tensor):
         """Begin the in-place sum of `part` over the ranks and return a handle with .wait().  With RCCL the
         collective runs on the process group's own stream, ordered after the work already enqueued on the
         current stream, and .wait() makes the current stream wait for it -- no host synchronisation: kernels
         enqueued between start() and wait() overlap with it."""
-        if self.world <= 1:
+        if not self.active:
             return _Done()
         if part.is_cuda and dist.get_backend(self.group) == "gloo":
             self(part)                           # test rigs only: synchronous, staged through the host
@@ -75,7 +78,7 @@ class GradAllReduce:
         return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def __call__(self, flat_grad: torch.Tensor):
-        if self.world > 1:
+        if self.active:
             if flat_grad.is_cuda and dist.get_backend(self.group) == "gloo":
                 # test rigs only (several ranks sharing one GPU): stage through the host
                 host = flat_grad.cpu()
