@@ -279,6 +279,9 @@ def test_adam_step_kernel_alone():
                 batch_size=1, history_len=1, n_candidates=1, n_words_title=1),       # minimum sizes
     synth.Shape(n_words=1000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                 batch_size=16, history_len=50, n_candidates=5, n_words_title=30),    # bench shape, small batch
+    synth.Shape(n_words=300, word_embed_size=100, num_attention_heads=2, query_vector_dim=32,
+                batch_size=3, history_len=6, n_candidates=2, n_words_title=40),      # 40 words, d_k = 50: the two-wave 64 x 64
+                                                                                     # attention on the padding-skipping path
 ])
 def test_shape_sweep_against_oracle(shape, mode):
     from oracle import nrms_oracle as orc

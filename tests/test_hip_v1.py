@@ -41,6 +41,8 @@ def fwd_bwd(model, batch):
                  batch_size=6, history_len=50, n_candidates=5, n_words_title=20), 6),       # res_logs.md:4 setup: L=20, h=6/10
     (synth.Shape(n_words=90, word_embed_size=48, num_attention_heads=4, query_vector_dim=16,
                  batch_size=3, history_len=5, n_candidates=2, n_words_title=7), 2),
+    (synth.Shape(n_words=200, word_embed_size=100, num_attention_heads=2, query_vector_dim=32,
+                 batch_size=3, history_len=40, n_candidates=2, n_words_title=40), 2),       # masked 64 x 64 units (d_k = 50) in both encoders
 ])
 def test_v1_model_forward_backward_vs_oracle(shape, title_heads, mode):
     from oracle import nrms_oracle as orc
