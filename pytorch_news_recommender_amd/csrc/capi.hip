@@ -638,7 +638,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         if (rc) return rc;
     }
     if (gather) {
-        static const bool atomic_scatter = getenv("NRMS_ATOMIC_SCATTER") != nullptr;      // A/B switch
+        const bool atomic_scatter = getenv("NRMS_ATOMIC_SCATTER") != nullptr;      // A/B switch, read per call (no latched state)
         if (atomic_scatter) rc = launch_scatter_dropout_compact((long)M, d, ids, live, n_live, dctx, drop_e, grads->table, s);
         else rc = launch_scatter_grouped((long)M, desc->vocab, d, ids, live, n_live, dctx, drop_e, grads->table,
                                          (int*)(base + L.sscr), s);
