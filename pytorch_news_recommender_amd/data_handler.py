@@ -21,6 +21,7 @@ import csv
 import os
 import pickle
 from ast import literal_eval
+from collections.abc import Mapping
 
 import numpy as np
 import torch
@@ -276,6 +277,25 @@ class SyntheticMind:
         return samples, labels
 
 
+class LazyBatch(Mapping):
+    """A read-only batch dict whose values are produced on first access and kept (keys, order and ``len`` are those of the
+    eager dict; ``items()`` / ``values()`` materialise everything)."""
+
+    def __init__(self, makers):
+        self._makers, self._vals = makers, {}
+
+    def __getitem__(self, key):
+        if key not in self._vals:
+            self._vals[key] = self._makers[key]()
+        return self._vals[key]
+
+    def __iter__(self):
+        return iter(self._makers)
+
+    def __len__(self):
+        return len(self._makers)
+
+
 class DeviceFeed:
     """The same batch dicts as ``DataLoader(MyDataset(config, samples, type), batch_size)`` -- same 13 keys, dtypes, padding
     and sample order -- assembled ON THE DEVICE: the news corpus (title and abstract word ids, 31 MB for MIND's 130 k news at
@@ -342,26 +362,40 @@ class DeviceFeed:
         return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
 
     def batch(self, rows):
-        """rows: int64 device tensor of sample indices -> the batch dict (device tensors)."""
+        """rows: int64 device tensor of sample indices -> the batch dict (device tensors).  The dict is LAZY: a value is
+        gathered when it is first read (nrms_v0 reads 3 of the 13 keys, nrms_naml 9; gathering all of them cost 0.6 ms of GPU
+        time per 512-user batch against a 3.3 ms train step)."""
         p, cfg = self.packed, self.config
-        hist, cand = p["hist"].index_select(0, rows), p["cand"].index_select(0, rows)
-        hlen, clen = p["hlen"].index_select(0, rows), p["clen"].index_select(0, rows)
         H, S, A = cfg.history_len, self.S, cfg.n_words_abst
         B = rows.shape[0]
-        zeros = lambda slots: torch.zeros(B, slots, A, dtype=torch.int64, device=self.device)
-        return {'browsed_lens': hlen,
-                'browsed_ids': hist,
-                'browsed_titles': self.titles.index_select(0, hist.reshape(-1)).view(B, H, -1),
-                'browsed_absts': self.absts.index_select(0, hist.reshape(-1)).view(B, H, -1) if self.absts is not None else zeros(H),
-                'browsed_categ_ids': p["hcat"].index_select(0, rows),
-                'browsed_subcateg_ids': p["hsub"].index_select(0, rows),
-                'browsed_mask': (torch.arange(H, device=self.device)[None, :] < hlen[:, None]).to(torch.uint8),
-                'candidate_ids': cand,
-                'candidate_titles': self.titles.index_select(0, cand.reshape(-1)).view(B, S, -1),
-                'candidate_absts': self.absts.index_select(0, cand.reshape(-1)).view(B, S, -1) if self.absts is not None else zeros(S),
-                'candidate_categ_ids': p["ccat"].index_select(0, rows),
-                'candidate_subcateg_ids': p["csub"].index_select(0, rows),
-                'candidate_mask': (torch.arange(S, device=self.device)[None, :] < clen[:, None]).to(torch.uint8)}
+        memo = {}
+
+        def sel(name):                                                # rows of one packed array, gathered once
+            if name not in memo:
+                memo[name] = p[name].index_select(0, rows)
+            return memo[name]
+
+        def text(table, slots, width):
+            if table is None:
+                return torch.zeros(B, sel(slots).shape[1], width, dtype=torch.int64, device=self.device)
+            return table.index_select(0, sel(slots).reshape(-1)).view(B, sel(slots).shape[1], -1)
+
+        def mask(n_slots, lens):
+            return (torch.arange(n_slots, device=self.device)[None, :] < sel(lens)[:, None]).to(torch.uint8)
+
+        return LazyBatch({'browsed_lens': lambda: sel("hlen"),
+                          'browsed_ids': lambda: sel("hist"),
+                          'browsed_titles': lambda: text(self.titles, "hist", cfg.n_words_title),
+                          'browsed_absts': lambda: text(self.absts, "hist", A),
+                          'browsed_categ_ids': lambda: sel("hcat"),
+                          'browsed_subcateg_ids': lambda: sel("hsub"),
+                          'browsed_mask': lambda: mask(H, "hlen"),
+                          'candidate_ids': lambda: sel("cand"),
+                          'candidate_titles': lambda: text(self.titles, "cand", cfg.n_words_title),
+                          'candidate_absts': lambda: text(self.absts, "cand", A),
+                          'candidate_categ_ids': lambda: sel("ccat"),
+                          'candidate_subcateg_ids': lambda: sel("csub"),
+                          'candidate_mask': lambda: mask(S, "clen")})
 
     def __iter__(self):
         if self.shuffle:
