@@ -904,8 +904,12 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     L.dqkv16 = take((size_t)(M + 32) * B16_DQ * 2);
     L.red = take((size_t)2 * L.n_wg * B16_RED * 4);      // pool kernel + attention kernel
     L.maps = take((size_t)(B16_DQ * 2 + F16_KP + F16_QP * 2 + F16_DP) * 4);
-    // TN partial slabs (one workgroup per CU and round): the larger of the two products
-    L.tn_splits_qkv = 44;      // x 6 output blocks of 320 x 160 = 264 workgroups (a multiple of 8: XCD mapping)
+    // TN partial slabs.  The kernel's ~200 registers allow two waves per SIMD, i.e. exactly ONE 8-wave workgroup per CU:
+    // the grid must not exceed the 256 CUs, or the surplus workgroups run as a second round on an otherwise idle GPU
+    // (44 splits x 6 blocks = 264 workgroups took 0.39 ms alone, 40 x 6 = 240 take 0.23 ms; inside the step, where the
+    // kernel shares the GPU with the main stream's kernels and they fill that idle round, the step time is the same), and
+    // it stays a multiple of 8 for the XCD mapping (42 x 6 = 252 loses the L2 locality of the re-read rows: 0.29 ms)
+    L.tn_splits_qkv = 40;      // x 6 output blocks of 320 x 160 = 240 workgroups
     L.tn_splits_add = 128;     // x 2 = 256
     if (const char* e = getenv("NRMS_TN_SPLITS_QKV")) L.tn_splits_qkv = atoi(e);      // tuning only
     if (const char* e = getenv("NRMS_TN_SPLITS_ADD")) L.tn_splits_add = atoi(e);
