@@ -622,13 +622,23 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void gemm16_dx_kernel(D
 // workgroups into partial slabs, summed in fixed order by tn16_reduce_kernel (which also maps the internal row /
 // column order back to the reference's parameter layout and removes the loss scale).
 constexpr int T16_MC = 32, T16_THREADS = 512;
-constexpr int T16_AW = 320, T16_BW = 160;                 // staged columns per workgroup: n x k output block
-constexpr int T16_PA = 336, T16_PB = 176;                 // pitches in halves (168 / 88 dwords = 8 * odd)
-constexpr int T16_A_BYTES = T16_MC * T16_PA * 2, T16_B_BYTES = T16_MC * T16_PB * 2;
-constexpr int T16_STAGE = T16_A_BYTES + T16_B_BYTES;
-constexpr int T16_A_IT = (T16_MC * T16_AW / 8 + T16_THREADS - 1) / T16_THREADS;      // 16-byte chunks per thread: 3 (2.5)
-constexpr int T16_B_IT = (T16_MC * T16_BW / 8 + T16_THREADS - 1) / T16_THREADS;      // 2 (1.25)
-constexpr int T16_NTN = 5, T16_NTK = 5;
+// Geometry of one instantiation: WN x WK = 8 waves, NTN x NTK tiles of 16 x 16 per wave; the workgroup's output block is
+// AW x BW = (16 WN NTN) x (16 WK NTK).  d(W_qkv) [960 x 320]: 4 x 2 waves of 5 x 5 tiles = 320 x 160 blocks (3 x 2 of them);
+// d(W_add) [224 x 320]: 2 x 4 waves of 7 x 5 tiles = ONE 224 x 320 block (with the 320 x 160 blocks 30 % of its MFMAs
+// multiplied padding columns and every dZ row was staged twice).
+template <int WN, int NTN, int WK, int NTK>
+struct Tn16Geom {
+    static_assert(WN * WK * 64 == T16_THREADS, "eight waves");
+    static constexpr int AW = 16 * WN * NTN, BW = 16 * WK * NTK;       // staged columns per workgroup: n x k output block
+    static constexpr int PA = AW + 16, PB = BW + 16;                   // pitches in halves: (AW + 16) / 2 dwords = 8 * odd
+    static_assert(((PA / 2) % 16) == 8 && ((PB / 2) % 16) == 8, "pitch = 8 * odd dwords (conflict-free transposed reads)");
+    static constexpr int A_BYTES = T16_MC * PA * 2, B_BYTES = T16_MC * PB * 2;
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_IT = (T16_MC * AW / 8 + T16_THREADS - 1) / T16_THREADS;     // 16-byte chunks per thread
+    static constexpr int B_IT = (T16_MC * BW / 8 + T16_THREADS - 1) / T16_THREADS;
+};
+typedef Tn16Geom<4, 5, 2, 5> Tn16Qkv;
+typedef Tn16Geom<2, 7, 4, 5> Tn16Add;
 
 struct Tn16Args {
     int M;                    // upper bound of the rows
@@ -636,7 +646,7 @@ struct Tn16Args {
     const _Float16* A; int lda, N;       // [M][lda], N used columns (multiple of 16)
     const _Float16* B; int ldb, K;       // [M][ldb], K used columns (multiple of 16)
     float* partial;           // [splits][N][K]
-    int splits, n_blk, k_blk; // output blocks of T16_AW x T16_BW
+    int splits, n_blk, k_blk; // output blocks of AW x BW
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -658,12 +668,15 @@ __device__ __forceinline__ h8 tr16_frag(const char* plane, int pitch_b, int col0
 
 // FL: both operands are in the fragment order of fused16.h ([block of 32 rows][k-step][row][16]): a stage (32 rows) is ONE
 // contiguous block per operand; otherwise plain row-major [M][ld].
-template <bool FL>
+template <bool FL, int WN, int NTN, int WK, int NTK>
 __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
+    typedef Tn16Geom<WN, NTN, WK, NTK> G;
+    constexpr int T16_AW = G::AW, T16_BW = G::BW, T16_PA = G::PA, T16_PB = G::PB, T16_A_BYTES = G::A_BYTES;
+    constexpr int T16_STAGE = G::STAGE, T16_A_IT = G::A_IT, T16_B_IT = G::B_IT, T16_NTN = NTN, T16_NTK = NTK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WK, wk = wave % WK;
     const int out_blocks = a.n_blk * a.k_blk;
     // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, and the out_blocks workgroups of one M-split read the
     // same rows (each A chunk k_blk times, each B chunk n_blk times): give an XCD a contiguous range of (split, block)
@@ -910,7 +923,10 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     // kernel shares the GPU with the main stream's kernels and they fill that idle round, the step time is the same), and
     // it stays a multiple of 8 for the XCD mapping (42 x 6 = 252 loses the L2 locality of the re-read rows: 0.29 ms)
     L.tn_splits_qkv = 40;      // x 6 output blocks of 320 x 160 = 240 workgroups
-    L.tn_splits_add = 128;     // x 2 = 256
+    // d(W_add) reads all of dZ16 and ctx16 once (1 GB: HBM-bound at ~4.5 TB/s whatever the tile shape -- the 224 x 320
+    // block removed 30 % of its MFMAs and 40 % of its LDS traffic at unchanged time); 192 workgroups leave a quarter of the
+    // CUs to the main stream's kernels it runs beside (same-box A/B: 128 / 192 / 256 splits within noise, 192 ahead)
+    L.tn_splits_add = 192;     // x 1 output block of 224 x 320
     if (const char* e = getenv("NRMS_TN_SPLITS_QKV")) L.tn_splits_qkv = atoi(e);      // tuning only
     if (const char* e = getenv("NRMS_TN_SPLITS_ADD")) L.tn_splits_add = atoi(e);
     const size_t p1 = (size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4, p2 = (size_t)L.tn_splits_add * F16_QP * F16_DP * 4;
@@ -924,15 +940,17 @@ static int launch_tn16(bool frag_layout, const _Float16* A, int lda, int N, cons
                        hipStream_t stream, const char* name) {
     Tn16Args t{};
     t.M = M; t.m_dev = m_dev; t.A = A; t.lda = lda; t.N = N; t.B = B; t.ldb = ldb; t.K = K; t.partial = partial;
-    t.splits = splits; t.n_blk = cdiv(N, T16_AW); t.k_blk = cdiv(K, T16_BW);
-    const size_t lds = 2 * (size_t)T16_STAGE;
-    const void* fn = frag_layout ? (const void*)gemm16_tn_kernel<true> : (const void*)gemm16_tn_kernel<false>;
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // fragment-order operands = the additive product (one 224 x 320 block), row-major = the Q|K|V product (320 x 160 blocks)
+    typedef void (*Kern)(Tn16Args);
+    const Kern fn = frag_layout ? (Kern)gemm16_tn_kernel<true, 2, 7, 4, 5> : (Kern)gemm16_tn_kernel<false, 4, 5, 2, 5>;
+    const int aw = frag_layout ? Tn16Add::AW : Tn16Qkv::AW, bw = frag_layout ? Tn16Add::BW : Tn16Qkv::BW;
+    t.splits = splits; t.n_blk = cdiv(N, aw); t.k_blk = cdiv(K, bw);
+    const size_t lds = 2 * (size_t)(frag_layout ? Tn16Add::STAGE : Tn16Qkv::STAGE);
+    const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
     {
         TimingScope ts(name, stream);
-        if (frag_layout) hipLaunchKernelGGL(gemm16_tn_kernel<true>, dim3(splits * t.n_blk * t.k_blk), dim3(T16_THREADS), lds, stream, t);
-        else hipLaunchKernelGGL(gemm16_tn_kernel<false>, dim3(splits * t.n_blk * t.k_blk), dim3(T16_THREADS), lds, stream, t);
+        hipLaunchKernelGGL(fn, dim3(splits * t.n_blk * t.k_blk), dim3(T16_THREADS), lds, stream, t);
     }
     int rc = check_launch(name);
     if (rc) return rc;
