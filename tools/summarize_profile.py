@@ -13,7 +13,7 @@ from collections import defaultdict
 
 # kernel symbol -> bench.py timer name (news-encoder instantiations at the bench shape)
 TIMER_OF = [("fused_fwd16_kernel", "fused_fwd16"), ("fused_bwd16_pool_kernel", "fused_bwd16_pool"),
-            ("fused_bwd16_attn_kernel", "fused_bwd16_attn"), ("gemm16_tn_kernel<true>", "dwadd_bwd"), ("gemm16_tn_kernel<false>", "dwqkv_bwd"),
+            ("fused_bwd16_attn_kernel", "fused_bwd16_attn"), ("gemm16_tn_kernel<true", "dwadd_bwd"), ("gemm16_tn_kernel<false", "dwqkv_bwd"),
             ("gemm16_dx_kernel", "dx_bwd"), ("gather16_kernel", "gather_dropout"), ("scatter_grouped_kernel", "scatter_dropout"),
             ("attn_bwd_kernel", "attn_bwd"), ("attn_fwd_kernel", "attn_fwd"),
             ("gemm_nt_bf16_kernel<19, 0, 0", "qkv_proj_fwd"), ("gemm_nt_bf16_kernel<19, 2, 1", "dctx_bwd"),
