@@ -136,6 +136,14 @@ def test_train_evaluate_checkpoint_loop(tmp_path):
     m2.dedup_inference = False
     assert abs(train_eval.evaluate(cfg, m2, dl, dev_labels, verbose=False) - auc1) < 1e-6
     m2.dedup_inference = True
+    # the same trained weights scored in the other precision modes: the dev AUC moves by less than two rank flips (one flip
+    # among ~20 candidates of one of 256 impressions is ~2e-4 here; at bench size, 1 024 impressions: 4.4e-6, tools/train_parity.py)
+    for prec in ("bf16x3", "fp16"):
+        cfg.precision = prec
+        auc_p = train_eval.evaluate(cfg, m2, dl, dev_labels, verbose=False)
+        assert m2.engine.precision == prec
+        assert abs(auc_p - auc1) < 4e-4, (prec, auc_p, auc1)
+    cfg.precision = "fp32"
     out = train_eval.test(cfg, m2, dl, [len(y) for y in dev_labels], out_file=str(tmp_path / "sub.txt"))
     first = open(out).readline().split(" ", 1)
     assert first[0] == "1" and sorted(eval(first[1])) == list(range(1, len(dev_labels[0]) + 1))
