@@ -14,9 +14,11 @@
  *     are caller buffers; workspace sizes come from the *_workspace_bytes queries.
  *   - every call is asynchronous on `stream`, re-entrant across streams, and returns
  *     0 on success or a negative NRMS_E* code; nrms_last_error() gives the (thread-local) text.
- *     One exception to the re-entrancy: the NRMS_PRECISION_FP16 backward forks onto two helper streams the library
- *     creates once per process, so one fp16 backward may be in flight per process at a time (serialise them if several
- *     host threads train in one process; one process per GPU -- the deployment this library is built for -- never does).
+ *     One exception to the re-entrancy: nrms_encoder_bwd forks its weight-gradient GEMMs onto helper streams the library
+ *     creates once per process (two for NRMS_PRECISION_FP16, one for the other modes) and joins them before it returns
+ *     (or in nrms_encoder_bwd_wqkv, NRMS_FLAG_DEFER_WQKV), so one backward may be in flight per process at a time
+ *     (serialise them if several host threads train in one process; one process per GPU -- the deployment this library is
+ *     built for -- never does).  The environment variable NRMS_NO_SIDE_STREAMS keeps everything on `stream`.
  *   - all matrices are row-major and dense; fp32 unless stated.  M = n_seq * seq_len.
  *   - gradients are ACCUMULATED (+=) into the caller's buffers (zero them per step, as
  *     `model.zero_grad()` does at train_eval.py:115).

@@ -472,6 +472,27 @@ extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc
 }
 
 // step 5 of the backward (shared by nrms_encoder_bwd and nrms_encoder_bwd_wqkv)
+// One helper stream for the weight-gradient (TN) GEMMs of the fp32 / split-bf16 backward: d(W_add), d(W_O) and d(W_qkv)
+// feed nothing inside the call, so they run beside the main stream's chain (d(ctx) GEMM, attention backward -- a long
+// latency-bound kernel that leaves most of the matrix pipe idle --, dX GEMM, scatter).  In order among themselves (they
+// share the partial-slab workspace), forked from the main stream where their inputs are complete, joined at the end of
+// the call.  Created once per process; like the fp16 backward's helper streams (fused16_bwd.hip), one such backward may be
+// in flight per process.  NRMS_NO_SIDE_STREAMS (read per call) serialises everything onto the caller's stream.
+struct GemmSideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // 0..2 forks, 3 d(W_O) done, 4 join
+    bool ok = false, tried = false;
+    void init() {
+        if (tried) return;
+        tried = true;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+        for (int i = 0; i < 5; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
+        ok = true;
+    }
+};
+static GemmSideStream g_gemm_side;
+
 static int bwd_wqkv(const nrms_encoder_desc* desc, const float* xin, const float* dqkv, const int* n_live,
                     const nrms_encoder_grads* grads, float* tn_partial, hipStream_t s) {
     const int d = desc->d_model, M = desc->n_seq * desc->seq_len;
@@ -546,6 +567,13 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     float* dq_partial = (float*)(base + L.dq_partial);
     void* wplanes = (void*)(base + L.wplanes);
 
+    g_gemm_side.init();
+    const bool side = g_gemm_side.ok && getenv("NRMS_NO_SIDE_STREAMS") == nullptr;
+    hipStream_t s2 = side ? g_gemm_side.s : s;
+    auto fork = [&](int i) {                      // the helper stream continues from here on the main stream
+        if (side) { (void)hipEventRecord(g_gemm_side.ev[i], s); (void)hipStreamWaitEvent(s2, g_gemm_side.ev[i], 0); }
+    };
+
     // 1. pooling rows: ds, d(q_vec)
     if (wide_additive(desc))
         rc = launch_addattn_rows_bwd_wide(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
@@ -554,6 +582,16 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
                                      pmask, s);
     if (rc) return rc;
+    // 3. d(w_add), d(b_add) = dZ^T [ctx | 1]: needs ds only -- on the helper stream, beside everything below
+    fork(0);
+    {
+        TNArgs t{};
+        t.M = M; t.N = q; t.K = d; t.amode = A_DZ;
+        t.ds = ds; t.qv = w->q_vec; t.T = acts->t; t.B = acts->ctx; t.ldb = d;
+        t.dW = grads->w_add; t.dbias = grads->b_add; t.partial = tn_partial;
+        rc = tn_gemm(desc, t, s2, "dwadd_bwd");
+        if (rc) return rc;
+    }
     // 2. d(ctx) = dZ Wa + w_s dout, then through the context-dropout mask in the GEMM's coalesced
     //    epilogue (one Philox call per float4) -- the attention backward then carries no RNG work.
     rc = launch_transpose(w->w_add, wadd_t, q, d, s);
@@ -568,24 +606,17 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = nt_gemm(desc, A_DZ, E_DCTX, g, wplanes, s, "dctx_bwd");
         if (rc) return rc;
     }
-    // 3. d(w_add), d(b_add) = dZ^T [ctx | 1]
-    {
-        TNArgs t{};
-        t.M = M; t.N = q; t.K = d; t.amode = A_DZ;
-        t.ds = ds; t.qv = w->q_vec; t.T = acts->t; t.B = acts->ctx; t.ldb = d;
-        t.dW = grads->w_add; t.dbias = grads->b_add; t.partial = tn_partial;
-        rc = tn_gemm(desc, t, s, "dwadd_bwd");
-        if (rc) return rc;
-    }
     const float* dattn_in = dctx;
     if (wo) {
-        // 3b. output projection: d(W_O), d(b_O) = dC^T [attn | 1];  d(attn) = dC W_O
+        // 3b. output projection: d(W_O), d(b_O) = dC^T [attn | 1] (helper stream: reads d(ctx));  d(attn) = dC W_O
+        fork(1);
         TNArgs t{};
         t.M = M; t.N = d; t.K = d; t.amode = A_PLAIN;
         t.A = dctx; t.lda = d; t.B = acts->attn; t.ldb = d;
         t.dW = grads->w_o; t.dbias = grads->b_o; t.partial = tn_partial;
-        rc = tn_gemm(desc, t, s, "dwo_bwd");
+        rc = tn_gemm(desc, t, s2, "dwo_bwd");
         if (rc) return rc;
+        if (side) (void)hipEventRecord(g_gemm_side.ev[3], s2);          // d(ctx) may be overwritten after this (step 6)
         rc = launch_transpose(w->w_o, wo_t, d, d, s);
         if (rc) return rc;
         NTArgs g{};
@@ -621,7 +652,8 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings) -- or later,
     //    by nrms_encoder_bwd_wqkv (NRMS_FLAG_DEFER_WQKV)
     if ((desc->flags & NRMS_FLAG_DEFER_WQKV) == 0) {
-        rc = bwd_wqkv(desc, gather ? acts->x : x, dqkv, n_live, grads, tn_partial, s);
+        fork(2);                                   // after the attention backward AND its padding-row sums into d(b_qkv)
+        rc = bwd_wqkv(desc, gather ? acts->x : x, dqkv, n_live, grads, tn_partial, s2);
         if (rc) return rc;
     }
     // 6. dX = dQKV Wqkv.  User encoder: that is the answer.  News encoder: compact dX into the (now
@@ -634,6 +666,7 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t;
         g.C = gather ? dctx : dx; g.ldc = d;
         if (gather) { g.a_rows = compact ? nullptr : live; g.m_dev = n_live; }
+        if (side && wo && gather) (void)hipStreamWaitEvent(s, g_gemm_side.ev[3], 0);     // dX lands in the d(ctx) buffer d(W_O) reads
         rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "dx_bwd");
         if (rc) return rc;
     }
@@ -642,6 +675,10 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         if (atomic_scatter) rc = launch_scatter_dropout_compact((long)M, d, ids, live, n_live, dctx, drop_e, grads->table, s);
         else rc = launch_scatter_grouped((long)M, desc->vocab, d, ids, live, n_live, dctx, drop_e, grads->table,
                                          (int*)(base + L.sscr), s);
+    }
+    if (side) {                                    // the caller's stream continues after the weight gradients too
+        (void)hipEventRecord(g_gemm_side.ev[4], s2);
+        (void)hipStreamWaitEvent(s, g_gemm_side.ev[4], 0);
     }
     return rc;
 }
