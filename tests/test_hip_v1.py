@@ -88,22 +88,25 @@ def test_v1_dropout_only_after_attention_replayed(mode):
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("mask_mode", [1, 2, 3])
-def test_masked_primitives_forward_backward(mask_mode, mode):
+@pytest.mark.parametrize("geom", [(11, 300, 6), (33, 204, 6), (64, 128, 2)], ids=["S11_dk50", "S33_dk34", "S64_dk64"])
+def test_masked_primitives_forward_backward(mask_mode, mode, geom):
     """User encoder with v1's masks (UserEncoder.forward(news_vectors, attn_masks), nrms_v1.py:208-211):
     pairwise attention mask (bit 0) and masked additive attention (bit 1), including a fully masked
-    sequence (uniform attention over its real positions, as masked_fill(-1e9) gives)."""
+    sequence (uniform attention over its real positions, as masked_fill(-1e9) gives).  Geometries: a 32 x 64 unit, and
+    the edges of the two-wave 64 x 64 units (one query row in the second block / d_k just above 32; everything full)."""
     from oracle import nrms_oracle as orc
-    shape = synth.Shape(n_words=50, word_embed_size=300, num_attention_heads=6, query_vector_dim=200,
-                        batch_size=5, history_len=11, n_candidates=2, n_words_title=4)
+    H, d, heads = geom
+    shape = synth.Shape(n_words=50, word_embed_size=d, num_attention_heads=heads, query_vector_dim=200,
+                        batch_size=5, history_len=H, n_candidates=2, n_words_title=4)
     params = synth.make_params_v1(shape, seed=31)
     SCORE_TOL = TOL[mode]["score"]
-    model = make_v1(shape, params, title_heads=6, precision=mode)
+    model = make_v1(shape, params, title_heads=heads, precision=mode)
     eng, flat = model.engine, model._flat
     rng = np.random.default_rng(5)
-    X = rng.normal(0, 0.5, size=(5, 11, 300)).astype(np.float32)
-    lens = np.array([11, 7, 1, 0, 9])
-    mask = (np.arange(11)[None, :] < lens[:, None]).astype(np.uint8)
-    dout = rng.normal(0, 1, size=(5, 300)).astype(np.float32)
+    X = rng.normal(0, 0.5, size=(5, H, d)).astype(np.float32)
+    lens = np.array([H, (2 * H) // 3, 1, 0, H - 2])
+    mask = (np.arange(H)[None, :] < lens[:, None]).astype(np.uint8)
+    dout = rng.normal(0, 1, size=(5, d)).astype(np.float32)
     Xd, md, dd = (torch.from_numpy(a).cuda() for a in (X, mask, dout))
     out = eng.encode_users(flat, Xd, save=True, mask=md, mask_mode=mask_mode)
     gflat = torch.zeros_like(flat)
