@@ -118,12 +118,16 @@ def naml_keep_masks(model, shape, batch, seed, p):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_dropout_replay_against_oracle(mode):
-    """Training forward + backward with dropout 0.2: the masks the kernels drew, replayed through the oracle."""
+@pytest.mark.parametrize("geom", [(96, 17), (204, 37)], ids=["dk16_S17", "dk34_S37"])
+def test_dropout_replay_against_oracle(mode, geom):
+    """Training forward + backward with dropout 0.2: the masks the kernels drew, replayed through the oracle.  Second
+    geometry: 37-word abstracts with 34-wide heads -- the two-wave 64 x 64 attention units with the probability-dropout
+    mask of a sequence length that is not a multiple of 4 (a lane's four keys straddle two Philox groups)."""
     from oracle import naml_oracle as nml
-    shape = synth.NamlShape(n_words=120, word_embed_size=96, title_heads_num=6, query_vector_dim=40, category_nums=7,
+    d_word, n_abst = geom
+    shape = synth.NamlShape(n_words=120, word_embed_size=d_word, title_heads_num=6, query_vector_dim=40, category_nums=7,
                             subcategory_nums=11, cate_embed_size=32, user_heads_num=8, query_vector_dim_large=72,
-                            batch_size=4, history_len=9, n_candidates=4, n_words_title=10, n_words_abst=17)
+                            batch_size=4, history_len=9, n_candidates=4, n_words_title=10, n_words_abst=n_abst)
     params = synth.make_params_naml(shape, seed=5)
     batch = synth.make_batch_naml(shape, seed=6)
     p = 0.2
