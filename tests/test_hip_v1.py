@@ -131,3 +131,37 @@ def test_masked_primitives_forward_backward(mask_mode, mode, geom):
             assert np.abs(got - t.grad.numpy()).max() <= tol["g_atol"] + (tol["g_rtol"] + tol["g_scale"]) * np.abs(qb).max(), v0name
             continue
         assert_grad_close(got, t.grad.numpy(), mode, v0name)
+
+
+@pytest.mark.parametrize("mode", MODES + ["fp16"])
+def test_helper_streams_do_not_change_a_bit(mode, monkeypatch):
+    """The backward forks its weight-gradient GEMMs onto helper streams (capi.hip GemmSideStream, fused16_bwd.hip
+    SideStreams); with NRMS_NO_SIDE_STREAMS everything runs on the caller's stream.  Same kernels, same accumulation
+    order into every gradient buffer: the two must agree bit for bit (a missing dependency between the streams would show
+    as a difference).  v1 topology in the fp32 / bf16x3 modes (output projection, token gather), v0 in fp16."""
+    shape = synth.Shape(n_words=400, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=24, history_len=50, n_candidates=5, n_words_title=20 if mode != "fp16" else 30)
+    batch = synth.make_batch(shape, seed=44, ragged=True, min_title=1, mask_some_candidates=True)
+    res = []
+    for no_side in (False, True, False):
+        if no_side:
+            monkeypatch.setenv("NRMS_NO_SIDE_STREAMS", "1")
+        else:
+            monkeypatch.delenv("NRMS_NO_SIDE_STREAMS", raising=False)
+        if mode == "fp16":
+            from tests.test_hip_parity import make_model
+            model = make_model(shape, synth.make_params(shape, seed=43), precision="fp16").train()
+        else:
+            model = make_v1(shape, synth.make_params_v1(shape, seed=43), 6, precision=mode).train()
+        res.append(fwd_bwd(model, batch))
+        torch.cuda.synchronize()
+    for other in (res[1], res[2]):
+        assert np.array_equal(res[0][0], other[0])
+        for n in res[0][2]:
+            a, b = res[0][2][n], other[2][n]
+            if mode == "fp16" and (n.endswith("bias") or n.endswith("query_vector")):
+                # the fused kernels collect these column sums with LDS float atomics of a workgroup's four waves: their
+                # order is not fixed from run to run (last-bit differences), with or without helper streams
+                assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), n
+            else:
+                assert np.array_equal(a, b), n
