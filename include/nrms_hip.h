@@ -99,7 +99,9 @@ typedef struct nrms_encoder_desc {
                               power of two and the results divided by it (<= 0: 65536).  Pick ~128 x the global batch:
                               d(scores) is O(1/batch) and fp16 runs out of range below 6e-5 */
     float    p_drop_attn;  /* dropout on the attention PROBABILITIES (nrms_naml.py:36-39, dropout site 2; 0 in nrms_v0 /
-                              nrms_v1); not combinable with NRMS_FLAG_PAD_ROW_ZERO or NRMS_PRECISION_FP16 */
+                              nrms_v1); not combinable with NRMS_PRECISION_FP16.  With NRMS_FLAG_PAD_ROW_ZERO an
+                              all-padding sequence keeps a closed form: context of query i = b_v x (kept keys of i) /
+                              (seq_len (1 - p)) */
 } nrms_encoder_desc;
 
 /* Parameters, in the reference's own tensor layout ([out,in] Linear weights).

@@ -32,7 +32,8 @@ struct AttnArgs {
     // All-padding sequences (NRMS_FLAG_PAD_ROW_ZERO, no attention mask): every Q|K|V row equals the bias, the
     // attention is uniform, ctx = b_v; dS = 0, dQ = dK = 0 and every dV row is the mean of the dO rows.  The
     // forward (ids + bias_hm given) writes dropout(b_v); the COMPACT backward only adds the column sum of dO
-    // to the padding-row sums of dV.
+    // to the padding-row sums of dV.  With dropout on the probabilities (pdrop) a query's context is
+    // b_v x (its kept keys) / (S (1 - p)) and the dO rows enter that sum with the same factors (allpad_keep_factor).
     const int64_t* ids;
     const float* bias_hm;
     int w2, hw;             // float2 per row of one head block (3 d_k / 2) and of one operand (d_k / 2)
@@ -524,6 +525,31 @@ __device__ __forceinline__ void apply_keep_tile(f32x16& x, uint32_t bits16, floa
     for (int r = 0; r < 16; ++r) x[r] *= ((bits16 >> r) & 1u) != 0u ? inv_keep : 0.f;
 }
 
+// All-padding unit under probability dropout: every Q|K|V row is the bias, so P = 1/S before the mask and the context of
+// query i is b_v x c_i with c_i = (kept keys of query i) / (S (1 - p)); backward: dQ = 0, the dK rows sum to zero (each
+// query's dS row sums to zero) and the dV rows sum to sum_i c_i dO_i.  Returns c_i of query 32 it + l32 (both lane halves).
+template <int NS>
+__device__ __forceinline__ float allpad_keep_factor(const Dropout& pd, long unit, int S, int it, int l32, int hh) {
+    const uint32_t bits = prob_keep_bits_col<NS>(pd, unit, S, it, l32, hh);
+    int cnt = 0;
+#pragma unroll
+    for (int jt = 0; jt < NS; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            cnt += (jt * 32 + crow32(r, hh) < S && ((bits >> (16 * jt + r)) & 1u) != 0u) ? 1 : 0;
+    cnt += __shfl_xor(cnt, 32, 64);
+    return (float)cnt * pd.inv_keep / (float)S;
+}
+// the factors of all queries of the unit into fac[0..32 NS) (wave-private LDS; 1.0 without probability dropout)
+template <int NS>
+__device__ __forceinline__ void allpad_factors(const Dropout& pd, long unit, int S, int l32, int hh, float* fac) {
+#pragma unroll
+    for (int it = 0; it < NS; ++it) {
+        const float c = pd.thresh != 0u ? allpad_keep_factor<NS>(pd, unit, S, it, l32, hh) : 1.0f;
+        if (hh == 0) fac[it * 32 + l32] = c;
+    }
+}
+
 // out^T[dd][i] = sum_j A[j][dd] X^T[j][i] for the queries i of one block
 template <int NS, int ND, bool SPLIT>
 __device__ __forceinline__ void at_x_col(const float* A, int RS, int l32, int hh, const f32x16 (&xt)[NS], f32x16 (&out)[ND]) {
@@ -674,11 +700,16 @@ __global__ __launch_bounds__(64 * WPB) void attn_fwd_kernel(AttnArgs a) {
             wave_sync();
             stage_out<NS, ND>(Qs, RS, o, a.S, a.dk, l32, hh);
         } else {
-            // uniform attention over identical rows: every context row is the V bias of this head
+            // uniform attention over identical rows: every context row is the V bias of this head (times the query's
+            // kept-key factor under probability dropout; Ms is free: the shortcut needs an unmasked unit)
+            allpad_factors<NS>(a.pdrop, u, a.S, l32, hh, Ms);
+            wave_sync();
             const float* bv = a.bias_hm + head * 3 * a.dk + 2 * a.dk;
             for (int i = lane; i < a.S * a.hw; i += 64) {
                 const int r = i / a.hw, c2 = i - r * a.hw;
-                *reinterpret_cast<float2*>(Qs + r * RS + 2 * c2) = *reinterpret_cast<const float2*>(bv + 2 * c2);
+                float2 v = *reinterpret_cast<const float2*>(bv + 2 * c2);
+                v.x *= Ms[r]; v.y *= Ms[r];
+                *reinterpret_cast<float2*>(Qs + r * RS + 2 * c2) = v;
             }
         }
         wave_sync();
@@ -1041,11 +1072,14 @@ __global__ __launch_bounds__(64 * WPB, NS * ND == 1 ? 2 : 1) void attn_bwd_kerne
         } else {
             // all-padding sequence: identical Q|K|V rows => uniform attention, dS = 0, dQ = dK = 0 and every
             // dV row = mean of the dO rows; nothing is written (padding rows), the rows' dV sum = sum of dO
+            // (under probability dropout the rows enter with their kept-key factors; Ms is free: unmasked unit)
+            allpad_factors<NS>(a.pdrop, u, a.S, l32, hh, Ms);
+            wave_sync();
             constexpr int RG = ND == 1 ? 2 : 1;
             const int col = ND == 1 ? l32 : lane, rg = ND == 1 ? hh : 0;
             float s2 = 0.f;
 #pragma unroll 4
-            for (int r = rg; r < a.S; r += RG) s2 += Gs[r * RS + col];
+            for (int r = rg; r < a.S; r += RG) s2 += Ms[r] * Gs[r * RS + col];
             if (ND == 1) s2 += __shfl_xor(s2, 32, 64);
             if (ND != 1 || hh == 0) Acc[2 * DKP + col] += s2;
         }
@@ -1250,12 +1284,18 @@ __global__ __launch_bounds__(128, 1) void attn_bwd_coop_kernel(AttnArgs a) {
                 if (w == 0) { Acc[lane] += s0; Acc[DKP + lane] += s1; }
                 else Acc[2 * DKP + lane] += s0;
             }
-        } else if (w == 1) {
-            // all-padding sequence: dQ = dK = 0, every dV row the mean of the dO rows; only the rows' dV sum counts
-            float s2 = 0.f;
+        } else {
+            // all-padding sequence: dQ = 0, the dK rows sum to zero, the dV rows sum to sum_i c_i dO_i (c_i = 1 without
+            // probability dropout, see allpad_keep_factor); wave w supplies the factors of its query block
+            const float c = a.pdrop.thresh != 0u ? allpad_keep_factor<NS>(a.pdrop, u, a.S, w, l32, hh) : 1.0f;
+            if (hh == 0) Ms[w * 32 + l32] = c;
+            __syncthreads();
+            if (w == 1) {
+                float s2 = 0.f;
 #pragma unroll 4
-            for (int r = 0; r < a.S; ++r) s2 += Gs[r * RS + lane];
-            Acc[2 * DKP + lane] += s2;
+                for (int r = 0; r < a.S; ++r) s2 += Ms[r] * Gs[r * RS + lane];
+                Acc[2 * DKP + lane] += s2;
+            }
         }
         __syncthreads();
     }
@@ -1370,11 +1410,17 @@ __global__ __launch_bounds__(128, 2) void attn_fwd_coop_kernel(AttnArgs a) {
             wave_sync();
             stage_out_col<ND>(Qw, RS, o, l32, hh);
         } else {
-            // uniform attention over identical rows: every context row is the V bias of this head
+            // uniform attention over identical rows: every context row is the V bias of this head (times the query's
+            // kept-key factor under probability dropout); this wave's rows, factors in its half of Ms
+            const float c = a.pdrop.thresh != 0u ? allpad_keep_factor<NS>(a.pdrop, u, a.S, w, l32, hh) : 1.0f;
+            if (hh == 0) Ms[w * 32 + l32] = c;
+            wave_sync();
             const float* bv = a.bias_hm + head * 3 * a.dk + 2 * a.dk;
             for (int i = lane; i < 32 * a.hw; i += 64) {
                 const int r = i / a.hw, c2 = i - r * a.hw;
-                *reinterpret_cast<float2*>(Qw + r * RS + 2 * c2) = *reinterpret_cast<const float2*>(bv + 2 * c2);
+                float2 v = *reinterpret_cast<const float2*>(bv + 2 * c2);
+                v.x *= Ms[w * 32 + r]; v.y *= Ms[w * 32 + r];
+                *reinterpret_cast<float2*>(Qw + r * RS + 2 * c2) = v;
             }
         }
         wave_sync();

@@ -118,8 +118,8 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
         NRMS_REQUIRE(!(d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO)) && d->p_drop_ctx == 0.f,
                      "%s: d_k > 64 or odd d_k (the shape-general attention) supports neither NRMS_FLAG_PAD_ROW_ZERO nor "
                      "p_drop_ctx", who);
-    NRMS_REQUIRE(d->p_drop_attn == 0.f || !(d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO)),
-                 "%s: p_drop_attn is not combinable with NRMS_FLAG_PAD_ROW_ZERO (an all-padding title is no longer a closed form)", who);
+    // (p_drop_attn with NRMS_FLAG_PAD_ROW_ZERO: the token compaction stays exact; the closed form of an all-padding
+    //  sequence gains the per-query kept-key factors, see allpad_keep_factor in attention.hip)
     NRMS_REQUIRE(d->vocab >= 0, "%s: vocab=%d", who, d->vocab);
     NRMS_REQUIRE(d->p_drop_embed >= 0.f && d->p_drop_embed < 1.f && d->p_drop_ctx >= 0.f && d->p_drop_ctx < 1.f,
                  "%s: dropout probabilities must be in [0,1)", who);

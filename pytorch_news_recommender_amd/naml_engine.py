@@ -133,7 +133,8 @@ class NamlEngine(NRMSEngine):
         d = self.dims
         return _lib.EncoderDesc(n_seq=n_seq, seq_len=seq_len, d_model=d.width(enc), n_heads=d.heads(enc), q_dim=d.q(enc),
                                 vocab=d.n_words if enc == "news_encoder" else 0, p_drop_embed=0.0, p_drop_ctx=0.0,
-                                precision=_lib.PRECISIONS[self.precision], use_output_proj=1, mask_mode=0, flags=0,
+                                precision=_lib.PRECISIONS[self.precision], use_output_proj=1, mask_mode=0,
+                                flags=(_lib.NRMS_FLAG_PAD_ROW_ZERO if (self.pad_row_zero and enc == "news_encoder") else 0),
                                 seed=int(seed) & 0xFFFFFFFFFFFFFFFF, loss_scale=0.0, p_drop_attn=float(p_attn))
 
     def _ptrs(self, cls, flat, enc):
