@@ -224,7 +224,8 @@ def naml_leg(dev, B):
 
 
 def v1_leg(dev, B):
-    """SURVEY a-3' / f-3: one nrms_v1 train step (model/nrms_v1.py: W_O, pairwise attention masks, candidate mask) with
+    """SURVEY a-3' / f-3: one nrms_v1 train step (model/nrms_v1.py: W_O, per-encoder heads, candidate mask; like the
+    reference's forward, nrms_v1.py:286, the model applies no attention mask -- the masked primitives are tested apart) with
     the reference's v1 configuration (config.py: 20-word titles, 6 title heads of 50 / 10 user heads of 30), dropout 0.2,
     in the bf16x3 mode (the fused fp16 kernels cover the v0 topology only)."""
     from pytorch_news_recommender_amd.model.nrms_v1_hip import Model as V1Model
@@ -244,7 +245,7 @@ def v1_leg(dev, B):
     n = 5
     t = timed(lambda: m.train_step(batch), n)
     return {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n, "precision": "bf16x3",
-            "workload": "B=%d, H=50, C=5, title 20 words, d=300, 6 title heads / 10 user heads, W_O, masks" % B}
+            "workload": "B=%d, H=50, C=5, title 20 words, d=300, 6 title heads / 10 user heads, W_O, candidate mask" % B}
 
 
 def main():
