@@ -269,3 +269,38 @@ def test_inference_over_distinct_news_equals_every_slot():
     with torch.no_grad():
         ref = nml.forward(p, tbatch(batch), shape.title_heads_num, shape.user_heads_num).numpy()
     np.testing.assert_allclose(s_dedup[live], ref[live], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_padding_token_skip_equals_dense_path_with_dropout(mode):
+    """nrms_naml at the reference's widths (d = 300, 6 heads of 50, 20-word titles, 40-word abstracts: the two-wave 64 x 64
+    attention units) with dropout 0.2: the padding-skipping path -- compact Q|K|V / d(W_qkv) / dX rows, all-padding
+    sequences through the kept-key closed form -- against the dense path (skip_padding_tokens = False) drawing the same
+    masks.  Same function, different summation orders: scores and every gradient agree to rounding."""
+    shape = synth.NamlShape(n_words=300, batch_size=4, history_len=12, n_candidates=3)
+    assert shape.word_embed_size == 300 and shape.n_words_abst == 40 and shape.title_heads_num == 6
+    params = synth.make_params_naml(shape, seed=15)
+    batch = synth.make_batch_naml(shape, seed=16)
+    n_empty = int((batch["browsed_absts"].reshape(-1, shape.n_words_abst) == 0).all(1).sum())
+    assert n_empty >= 5                                   # empty history slots: the closed form is exercised
+    out = []
+    for skip in (True, False):
+        torch.manual_seed(1234)
+        model = make_model(shape, params, dropout=0.2, precision=mode).train()
+        model.config.skip_padding_tokens = skip
+        res = fwd_bwd(model, batch)
+        assert model.engine.pad_row_zero == skip
+        out.append(res)
+    (s1, l1, g1), (s0, l0, g0) = out
+    live = batch["candidate_mask"] != 0
+    tol = 2e-5 if mode == "fp32" else 1e-4
+    assert np.abs(s1[live] - s0[live]).max() < tol, np.abs(s1[live] - s0[live]).max()
+    assert abs(l1 - l0) < tol
+    for n in g0:
+        if n.endswith("linear_layers.1.bias"):            # the K bias: an analytically zero gradient, rounding noise in both
+            continue
+        scale = float(np.abs(g0[n]).max())
+        rel = 2e-5 if mode == "fp32" else 2e-4
+        if n.endswith("additive_attention.linear.bias"):  # sum_s ds_s = 0: a cancelling sum, ~1e-2 relative noise (DESIGN section 1)
+            rel = 2e-2
+        assert np.abs(g1[n] - g0[n]).max() <= rel * scale + 1e-9, (n, float(np.abs(g1[n] - g0[n]).max()), scale)
