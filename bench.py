@@ -44,7 +44,7 @@ PARITY = {"fp32": "<=1.5e-7", "bf16x3": "<=5e-7", "bf16": "~3e-4 (fails 1e-4)", 
 FLOP_PER_USER_TRAIN = 3558309000.0  # BASELINE.md section 2 / SURVEY 8d: nrms_v0, H=50, C=5, L=30, d=300, h=10, q=200
 
 
-def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news):
+def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news, fp16_user=False):
     """Per kernel timer: (declared bound, algorithmic flop per step, algorithmic HBM bytes per step).
     flop = 2mnk of the contractions the kernel owns, counted on what cannot be skipped exactly:
     Q|K|V projection / d(w_qkv) / dX on the non-padding token rows, attention on the titles with a real token, the
@@ -74,10 +74,21 @@ def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news):
         w["dx_bwd"] = ("mfma", dx_n + qkv_u, (live_rows + Mu) * (2.0 * 960 + 4.0 * d))
         w["dwadd_bwd"] = ("mfma", add_n + add_u, 2.0 * (Mn + Mu) * (224 + 320))
         w["gather_dropout"] = ("hbm", 0.0, live_rows * (4.0 * d + 2.0 * 320))
-        # user encoder (histories of 50 rows): the 64-row variants of the same kernels
-        w["fused64_fwd16"] = ("mfma", qkv_u + att_u + add_u, 2.0 * Mu * (320 + 320 + 224))
-        w["fused64_bwd16_pool"] = ("mfma", add_u, 2.0 * Mu * (2 * 320 + 2 * 224))
-        w["fused64_bwd16_attn"] = ("mfma", 2.0 * att_u, 2.0 * Mu * (320 + 320 + 960))
+        if fp16_user:
+            # user encoder (histories of 50 rows): the 64-row variants of the same kernels
+            w["fused64_fwd16"] = ("mfma", qkv_u + att_u + add_u, 2.0 * Mu * (320 + 320 + 224))
+            w["fused64_bwd16_pool"] = ("mfma", add_u, 2.0 * Mu * (2 * 320 + 2 * 224))
+            w["fused64_bwd16_attn"] = ("mfma", 2.0 * att_u, 2.0 * Mu * (320 + 320 + 960))
+        else:
+            # user encoder in bf16x3 (the default of the fp16 mode): the unfused fp32-storage kernels on its 3 % of the flops
+            # (its TN / dX GEMMs share the dwqkv_bwd / dx_bwd / dwadd_bwd timers with the news encoder's fp16 GEMMs)
+            Mdu, Mqu = 4.0 * Mu * d, 4.0 * Mu * q
+            w["qkv_proj_fwd"] = ("mfma", qkv_u, 4.0 * Mdu)
+            w["addattn_fwd"] = ("mfma", add_u, Mdu + Mqu)
+            w["dctx_bwd"] = ("mfma", add_u, Mqu + Mdu)
+            w["attn_fwd"] = ("hbm", att_u, 4 * Mdu)
+            w["attn_bwd"] = ("hbm", 2.5 * att_u, 8 * Mdu)
+            w["addattn_bwd_rows"] = ("hbm", 0.0, Mdu + Mqu)
     else:
         M = float(Mn + Mu)
         Md, Mq = 4.0 * M * d, 4.0 * M * q
@@ -116,29 +127,53 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(shape, sample_users=64, steps=3):
-    """The oracle's reference-shaped train step (per-slot loop, dropout on, dense per-slot
-    embedding grads, torch Adam) on the host cores: bounded sample of the same workload."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(shape, budget_s=60.0):
+    """The oracle's reference-shaped train step (the op sequence of nrms_v0.py:255-260 + train_eval.py:111-127: per-slot
+    encoder loop, dropout on, dense per-slot embedding grads, torch Adam) on this box's host cores, as BASELINE.md
+    section 3 plans it: B = 32 (BASELINE config 0's batch) and the largest B of 512 / 256 / 128 / 64 whose 3 warm-up + 5
+    timed steps fit `budget_s`, estimated from the B = 32 rate."""
     from oracle import nrms_oracle as orc
     threads = host_threads()
     torch.set_num_threads(threads)
     params = synth.make_params(shape, seed=0)
-    trainer = orc.ReferenceShapedTrainer(params, shape.num_attention_heads, p_drop=0.2, lr=1e-3)
-    batch = synth.make_batch(shape, seed=1, batch_size=sample_users)
-    t0 = time.perf_counter()
-    trainer.step(batch)                      # warm-up
-    warm = time.perf_counter() - t0
-    log("cpu baseline: warm-up step %.1f s on %d threads" % (warm, threads))
-    if warm * steps > 40.0:                  # keep the default run within a few minutes
-        steps = max(1, int(40.0 / warm))
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        trainer.step(batch)
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": sample_users / dt, "unit": "users/s", "cores": threads, "kind": "port",
-            "sample": "%d timed train steps of %d users (1 warm-up), same H/C/L/d/V, dropout 0.2, "
-                      "per-slot encoder loop + torch Adam, fp32, torch %s CPU" % (steps, sample_users, torch.__version__),
-            "ms_per_step": dt * 1e3}
+
+    def run(users, warm, steps):
+        trainer = orc.ReferenceShapedTrainer(params, shape.num_attention_heads, p_drop=0.2, lr=1e-3)
+        batch = synth.make_batch(shape, seed=1, batch_size=users)
+        for _ in range(warm):
+            trainer.step(batch)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(batch)
+        return (time.perf_counter() - t0) / steps
+
+    dt32 = run(32, 3, 5)
+    log("cpu baseline: B=32 %.2f s/step on %d threads" % (dt32, threads))
+    big = 64
+    for cand in (512, 256, 128):
+        if dt32 * cand / 32.0 * 8 <= budget_s:          # steps get cheaper per user as B grows: a safe over-estimate
+            big = cand
+            break
+    dtb = run(big, 3, 5)
+    log("cpu baseline: B=%d %.2f s/step" % (big, dtb))
+    best = max((32 / dt32, 32, dt32), (big / dtb, big, dtb))
+    return {"value": best[0], "unit": "users/s", "cores": threads, "kind": "port", "cpu": cpu_model_name(),
+            "sample": "3 warm-up + 5 timed train steps at B=32 and at B=%d (the largest of 512/256/128/64 fitting %.0f s), same "
+                      "H/C/L/d/V, dropout 0.2, per-slot encoder loop + torch Adam, fp32, torch %s CPU; value = the better of "
+                      "the two (B=%d)" % (big, budget_s, torch.__version__, best[1]),
+            "by_batch": {"32": {"users_per_s": 32 / dt32, "ms_per_step": dt32 * 1e3},
+                         str(big): {"users_per_s": big / dtb, "ms_per_step": dtb * 1e3}},
+            "ms_per_step": best[2] * 1e3}
 
 
 def timed(fn, n, sync=True):
@@ -257,12 +292,28 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the secondary legs")
     ap.add_argument("--dense-padding", action="store_true",
                     help="diagnostics: process padding tokens densely (as if embedding row 0 were not zero)")
-    ap.add_argument("--cpu-sample-users", type=int, default=64)
+    ap.add_argument("--cpu-budget-s", type=float, default=60.0, help="wall-clock budget of the larger CPU-baseline batch")
+    ap.add_argument("--grad-sync", default="allreduce", choices=["allreduce", "sharded"],
+                    help="N > 1: one all-reduce of the flat gradient + full Adam on every rank (default), or reduce-scatter -> "
+                         "Adam on the owned 1/N of the parameters -> all-gather (parallel.ShardedGradSync)")
+    ap.add_argument("--grad-compress", default=None, choices=["bf16"],
+                    help="--grad-sync sharded only: the table gradient travels as bf16 (opt-in; parity delta reported)")
+    ap.add_argument("--fp16-user-encoder", action="store_true",
+                    help="precision fp16: run the user encoder (3 %% of the flops) on the fused fp16 kernels too instead of "
+                         "bf16x3 -- faster, but the scores then sit AT the 1e-4 bar on 512-user batches")
     ap.add_argument("--precision", default="fp16", choices=["fp32", "bf16x3", "bf16", "fp16"],
                     help="fp16 (default): fused one-wave-per-title kernels, scores 4.4e-5 from the reference (bar 1e-4); "
                          "bf16x3: split-bf16 projections (5e-7); fp32 = exact f32 MFMA; bf16 misses the bar (3e-4)")
     args = ap.parse_args()
 
+    # N > 1: have RCCL write its topology / algorithm choices (rings, trees, channels, transports) to a per-rank file so
+    # the first multi-GPU record says what it ran on (parsed into data_parallel.rccl_info below)
+    nccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "NCCL_DEBUG" not in os.environ:
+        nccl_log = "/tmp/nrms_rccl_%s_rank%s.log" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("RANK", "0"))
+        os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,ENV,TUNING"
+        os.environ["NCCL_DEBUG_FILE"] = nccl_log
     rank, local_rank, world = parallel.init_process_group(os.environ.get("NRMS_DIST_BACKEND"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -280,6 +331,7 @@ def main():
     cfg.dropout = 0.2
     cfg.learning_rate = 1e-3
     cfg.precision = args.precision
+    cfg.fp16_user_encoder = bool(args.fp16_user_encoder)
     cfg.skip_padding_tokens = not args.dense_padding
     cfg.word_embed_size = shape.word_embed_size
     params = synth.make_params(shape, seed=0)
@@ -291,7 +343,12 @@ def main():
     parallel.broadcast_parameters(model._flat)
     batch_np = synth.make_batch(shape, seed=1 + rank, batch_size=B)      # each rank: its own users
     batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
-    reduce = parallel.GradAllReduce() if world > 1 else None
+    reduce = None
+    if world > 1:
+        if args.grad_sync == "sharded":
+            reduce = parallel.ShardedGradSync(model._flat.numel(), shape.n_words * shape.word_embed_size, compress=args.grad_compress)
+        else:
+            reduce = parallel.GradAllReduce()
 
     def step():
         return model.train_step(batch, world_size=world, all_reduce=reduce)
@@ -316,6 +373,7 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     dt = parallel.max_over_ranks(dt, dev)
     loss = float(loss_sum) / B
     log("timed region: %d steps in %.3f s" % (args.steps, dt))
@@ -344,17 +402,43 @@ def main():
         dist.broadcast(ref, src=0)
         diff = torch.tensor([float((model._flat - ref).abs().max())], device=dev)
         dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, dt_local / args.steps * 1e3)
         g = torch.zeros_like(model._flat)
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        reduce(g)
+        ar = parallel.GradAllReduce()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ar(g)
         torch.cuda.synchronize()
         parallel.barrier()
         evs[0].record()
         for _ in range(5):
-            reduce(g)
+            ar(g)
         evs[1].record()
         torch.cuda.synchronize()
         ar_ms = evs[0].elapsed_time(evs[1]) / 5
+        # the two halves of the same exchange, as the sharded path issues them
+        sh = parallel.ShardedGradSync(model._flat.numel(), shape.n_words * shape.word_embed_size)
+        for hnd in (sh.start(g, 0), sh.start(g, 1)):
+            hnd.wait()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        evs[2].record()
+        for _ in range(5):
+            for hnd in (sh.start(g, 0), sh.start(g, 1)):
+                hnd.wait()
+        evs[3].record()
+        torch.cuda.synchronize()
+        rs_ms = evs[2].elapsed_time(evs[3]) / 5
+        scratch = model._flat.clone()
+        sh.gather(scratch)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        evs[2].record()
+        for _ in range(5):
+            sh.gather(scratch)
+        evs[3].record()
+        torch.cuda.synchronize()
+        ag_ms = evs[2].elapsed_time(evs[3]) / 5
         os.environ["NRMS_NO_OVERLAP"] = "1"
         for _ in range(2):
             step()
@@ -362,7 +446,15 @@ def main():
         t_no = parallel.max_over_ranks(timed(step, max(3, args.steps // 2)), dev) / max(3, args.steps // 2)
         del os.environ["NRMS_NO_OVERLAP"]
         parallel.barrier()
-        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+        rccl_info = None
+        if nccl_log and os.path.exists(nccl_log):
+            import re
+            keep = re.compile(r"(nranks|Channel|Ring|Tree|channels|Algo|Proto|XGMI|xgmi|P2P|via|NCCL_|RCCL|Using network|Init COMPLETE|comm 0x)")
+            lines = [ln.strip() for ln in open(nccl_log, errors="replace") if keep.search(ln)]
+            rccl_info = {"log_lines": len(lines), "head": lines[:40], "tail": lines[-12:]}
+        dp = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "grad_sync": args.grad_sync,
+              "grad_compress": args.grad_compress, "per_rank_ms_per_step": per_rank,
+              "reduce_scatter_ms": rs_ms, "all_gather_ms": ag_ms, "rccl_info": rccl_info,
               "allreduce_ms": ar_ms, "allreduce_bytes": int(model._flat.numel() * 4),
               "allreduce_algbw_GBps": model._flat.numel() * 4 / ar_ms / 1e6,
               "ms_per_step_without_overlap": t_no * 1e3, "overlap_ms": t_no * 1e3 - dt / args.steps * 1e3,
@@ -378,9 +470,12 @@ def main():
                                  batch_np["candidate_titles"].reshape(-1, shape.n_words_title)])
         allpad_frac = 1.0 - float((titles != 0).any(axis=1).mean())
         fp16_news = args.precision == "fp16"
-        work = kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news)
+        work = kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news, bool(args.fp16_user_encoder))
         # which arithmetic each timer's kernels run in (fp16 mode: the user encoder's kernels are bf16x3)
         kprec = {k: args.precision for k in work}
+        if fp16_news and not args.fp16_user_encoder:
+            for k in ("qkv_proj_fwd", "addattn_fwd", "dctx_bwd", "attn_fwd", "attn_bwd", "addattn_bwd_rows"):
+                kprec[k] = "bf16x3"
         kernels = {}
         for name, (bound, fl, by) in work.items():
             ms, n = eng.timing_read(name)
@@ -457,7 +552,7 @@ def main():
         if dp is not None:
             out["data_parallel"] = dp
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(shape, sample_users=args.cpu_sample_users)
+            out["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_budget_s)
     # secondary (N = 1, outside the timed region of `value`): the other modes on the same batch
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         modes = {}

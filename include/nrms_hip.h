@@ -95,9 +95,10 @@ typedef struct nrms_encoder_desc {
                               bit 1: additive-attention mask -> -1e9 (nrms_v1.py:100-101); 0 = nrms_v0 */
     int32_t  flags;        /* NRMS_FLAG_*; 0 = none */
     uint64_t seed;         /* counter-based RNG key for the dropout masks (per step) */
-    float    loss_scale;   /* NRMS_PRECISION_FP16 backward only: the fp16 gradient tensors are carried multiplied by this
-                              power of two and the results divided by it (<= 0: 65536).  Pick ~128 x the global batch:
-                              d(scores) is O(1/batch) and fp16 runs out of range below 6e-5 */
+    float    loss_scale;   /* NRMS_PRECISION_FP16 backward only: the fp16 gradient tensors are carried multiplied by a
+                              power of two and the results divided by it.  <= 0 (recommended): chosen on the device per
+                              call as the power of two that puts max |dout| into [64, 128), so no loss reduction, batch
+                              size or world size can overflow or flush the fp16 tensors; > 0: used as given */
     float    p_drop_attn;  /* dropout on the attention PROBABILITIES (nrms_naml.py:36-39, dropout site 2; 0 in nrms_v0 /
                               nrms_v1); not combinable with NRMS_PRECISION_FP16.  With NRMS_FLAG_PAD_ROW_ZERO an
                               all-padding sequence keeps a closed form: context of query i = b_v x (kept keys of i) /

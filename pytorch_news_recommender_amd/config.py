@@ -47,8 +47,11 @@ class Config(object):
         self.require_improvement = 10000
         self.warm_up_steps = 500
         self.warm_up = False
-        # HIP path only: "fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections) or "bf16"
+        # HIP path only: "fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections), "bf16", or "fp16" (fused
+        # one-wavefront-per-title fp16 news encoder; the user encoder -- 3 % of the flops -- stays in bf16x3 unless
+        # fp16_user_encoder is set, which keeps the scores inside the 1e-4 bar with margin)
         self.precision = "fp32"
+        self.fp16_user_encoder = False
         # HIP path only: when embedding row 0 (padding_idx) is all zeros, skip the padding tokens in the
         # Q|K|V projection and its weight gradient (identical results; include/nrms_hip.h NRMS_FLAG_PAD_ROW_ZERO)
         self.skip_padding_tokens = True

@@ -228,7 +228,7 @@ static Fwd16Scratch fwd16_scratch(const nrms_encoder_desc* d) {
     f.cscr = f.n_live + (gather ? 256 : 0);
     f.order = f.cscr + (gather ? align_up(compact_scratch_ints((long)M) * sizeof(int), 256) : 0);
     f.order_cnt = f.order + (gather ? align_up((size_t)2 * d->n_seq * sizeof(int), 256) : 0);
-    f.total = f.order_cnt + (gather ? 256 : 0);
+    f.total = f.order_cnt + (gather ? align_up(title_order_cnt_ints(d->n_seq) * sizeof(int), 256) : 0);
     return f;
 }
 
@@ -291,7 +291,7 @@ static Bwd16Layout bwd16_layout(const nrms_encoder_desc* d) {
     L.n_live = take(gather ? 256 : 0);
     L.cscr = take(gather ? compact_scratch_ints((long)M) * sizeof(int) : 0);
     L.order = take(gather ? (size_t)2 * d->n_seq * sizeof(int) : 0);
-    L.order_cnt = take(gather ? 256 : 0);
+    L.order_cnt = take(gather ? title_order_cnt_ints(d->n_seq) * sizeof(int) : 0);
     L.dxc = take(gather ? M * d->d_model * sizeof(float) : 0);
     L.sscr = take(gather ? scatter_grouped_scratch_ints((long)M, d->vocab) * sizeof(int) : 0);
     L.total = off;
@@ -319,7 +319,7 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     f.workspace = base + L.fused;
     f.w_qkv = w->w_qkv; f.b_qkv = w->b_qkv; f.w_add = w->w_add; f.q_vec = w->q_vec;
     f.x16 = acts->x; f.ctx16 = acts->ctx; f.t16 = acts->t; f.w = acts->w; f.dout = dout;
-    f.loss_scale = desc->loss_scale > 0.f ? desc->loss_scale : 65536.f;
+    f.loss_scale = desc->loss_scale;           // <= 0: device-side, from max |dout|
     f.drop = make_dropout(desc->seed, desc->p_drop_ctx);
     f.dw_qkv = grads->w_qkv; f.db_qkv = grads->b_qkv; f.dw_add = grads->w_add; f.db_add = grads->b_add; f.dq_vec = grads->q_vec;
     int rc;
@@ -471,28 +471,57 @@ extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc
     return bwd_layout(desc).total;
 }
 
+// ---- helper streams (declared in common.h) -------------------------------------------------------------------------
+namespace nrms {
+struct SideEntry { int device; hipStream_t caller; SideSet* set; };
+static std::mutex g_side_mu;
+static std::vector<SideEntry> g_side_sets;
+
+SideSet* side_streams_for(hipStream_t caller) {
+    if (getenv("NRMS_NO_SIDE_STREAMS") != nullptr) return nullptr;        // read per call: a profiler pass serialises the step
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    for (const SideEntry& e : g_side_sets)
+        if (e.device == dev && e.caller == caller) return e.set;
+    if (g_side_sets.size() >= 32) return nullptr;
+    SideSet* ss = new SideSet();
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreateWithFlags(&ss->ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {                                     // remember the failure (a null set): do not retry on every call
+        for (int i = 0; i < 2; ++i) if (ss->s[i]) (void)hipStreamDestroy(ss->s[i]);
+        for (int i = 0; i < 8; ++i) if (ss->ev[i]) (void)hipEventDestroy(ss->ev[i]);
+        delete ss;
+        ss = nullptr;
+        (void)hipGetLastError();
+    }
+    g_side_sets.push_back(SideEntry{dev, caller, ss});
+    return ss;
+}
+
+int side_order(SideSet* ss, int e, hipStream_t from, hipStream_t to, const char* what) {
+    if (hipEventRecord(ss->ev[e], from) != hipSuccess || hipStreamWaitEvent(to, ss->ev[e], 0) != hipSuccess) {
+        set_error("%s: ordering the helper stream failed: %s", what, hipGetErrorString(hipGetLastError()));
+        return NRMS_ELAUNCH;
+    }
+    return NRMS_OK;
+}
+
+SideJoinGuard::~SideJoinGuard() {
+    if (!armed) return;
+    for (int i = 0; i < 2; ++i)                    // best effort on an error path: events 6 and 7 are reserved for this
+        if (hipEventRecord(ss->ev[6 + i], ss->s[i]) == hipSuccess) (void)hipStreamWaitEvent(caller, ss->ev[6 + i], 0);
+}
+}  // namespace nrms
+
 // step 5 of the backward (shared by nrms_encoder_bwd and nrms_encoder_bwd_wqkv)
 // One helper stream for the weight-gradient (TN) GEMMs of the fp32 / split-bf16 backward: d(W_add), d(W_O) and d(W_qkv)
 // feed nothing inside the call, so they run beside the main stream's chain (d(ctx) GEMM, attention backward -- a long
 // latency-bound kernel that leaves most of the matrix pipe idle --, dX GEMM, scatter).  In order among themselves (they
 // share the partial-slab workspace), forked from the main stream where their inputs are complete, joined at the end of
-// the call.  Created once per process; like the fp16 backward's helper streams (fused16_bwd.hip), one such backward may be
-// in flight per process.  NRMS_NO_SIDE_STREAMS (read per call) serialises everything onto the caller's stream.
-struct GemmSideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // 0..2 forks, 3 d(W_O) done, 4 join
-    bool ok = false, tried = false;
-    void init() {
-        if (tried) return;
-        tried = true;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
-        for (int i = 0; i < 5; ++i)
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return;
-        ok = true;
-    }
-};
-static GemmSideStream g_gemm_side;
-
+// the call (on every exit path: SideJoinGuard).  The streams belong to the caller's stream (side_streams_for): backwards
+// on different streams or devices of one process do not share them.
 static int bwd_wqkv(const nrms_encoder_desc* desc, const float* xin, const float* dqkv, const int* n_live,
                     const nrms_encoder_grads* grads, float* tn_partial, hipStream_t s) {
     const int d = desc->d_model, M = desc->n_seq * desc->seq_len;
@@ -567,11 +596,12 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     float* dq_partial = (float*)(base + L.dq_partial);
     void* wplanes = (void*)(base + L.wplanes);
 
-    g_gemm_side.init();
-    const bool side = g_gemm_side.ok && getenv("NRMS_NO_SIDE_STREAMS") == nullptr;
-    hipStream_t s2 = side ? g_gemm_side.s : s;
-    auto fork = [&](int i) {                      // the helper stream continues from here on the main stream
-        if (side) { (void)hipEventRecord(g_gemm_side.ev[i], s); (void)hipStreamWaitEvent(s2, g_gemm_side.ev[i], 0); }
+    SideSet* ss = side_streams_for(s);
+    const bool side = ss != nullptr;
+    hipStream_t s2 = side ? ss->s[0] : s;
+    SideJoinGuard join_guard(ss, s);
+    auto fork = [&](int i) -> int {               // the helper stream continues from here on the main stream
+        return side ? side_order(ss, i, s, s2, "encoder_bwd") : NRMS_OK;
     };
 
     // 1. pooling rows: ds, d(q_vec)
@@ -583,7 +613,8 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
                                      pmask, s);
     if (rc) return rc;
     // 3. d(w_add), d(b_add) = dZ^T [ctx | 1]: needs ds only -- on the helper stream, beside everything below
-    fork(0);
+    rc = fork(0);
+    if (rc) return rc;
     {
         TNArgs t{};
         t.M = M; t.N = q; t.K = d; t.amode = A_DZ;
@@ -609,14 +640,18 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     const float* dattn_in = dctx;
     if (wo) {
         // 3b. output projection: d(W_O), d(b_O) = dC^T [attn | 1] (helper stream: reads d(ctx));  d(attn) = dC W_O
-        fork(1);
+        rc = fork(1);
+        if (rc) return rc;
         TNArgs t{};
         t.M = M; t.N = d; t.K = d; t.amode = A_PLAIN;
         t.A = dctx; t.lda = d; t.B = acts->attn; t.ldb = d;
         t.dW = grads->w_o; t.dbias = grads->b_o; t.partial = tn_partial;
         rc = tn_gemm(desc, t, s2, "dwo_bwd");
         if (rc) return rc;
-        if (side) (void)hipEventRecord(g_gemm_side.ev[3], s2);          // d(ctx) may be overwritten after this (step 6)
+        if (side && hipEventRecord(ss->ev[3], s2) != hipSuccess) {      // d(ctx) may be overwritten after this (step 6)
+            set_error("encoder_bwd: hipEventRecord failed");
+            return NRMS_ELAUNCH;
+        }
         rc = launch_transpose(w->w_o, wo_t, d, d, s);
         if (rc) return rc;
         NTArgs g{};
@@ -652,7 +687,8 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     // 5. d(w_qkv), d(b_qkv) = dQKV^T [X | 1]   (X = the forward's gathered+dropped embeddings) -- or later,
     //    by nrms_encoder_bwd_wqkv (NRMS_FLAG_DEFER_WQKV)
     if ((desc->flags & NRMS_FLAG_DEFER_WQKV) == 0) {
-        fork(2);                                   // after the attention backward AND its padding-row sums into d(b_qkv)
+        rc = fork(2);                              // after the attention backward AND its padding-row sums into d(b_qkv)
+        if (rc) return rc;
         rc = bwd_wqkv(desc, gather ? acts->x : x, dqkv, n_live, grads, tn_partial, s2);
         if (rc) return rc;
     }
@@ -666,7 +702,10 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         g.A = dqkv; g.lda = 3 * d; g.W = wqkv_t;
         g.C = gather ? dctx : dx; g.ldc = d;
         if (gather) { g.a_rows = compact ? nullptr : live; g.m_dev = n_live; }
-        if (side && wo && gather) (void)hipStreamWaitEvent(s, g_gemm_side.ev[3], 0);     // dX lands in the d(ctx) buffer d(W_O) reads
+        if (side && wo && gather && hipStreamWaitEvent(s, ss->ev[3], 0) != hipSuccess) {   // dX lands in the d(ctx) buffer d(W_O) reads
+            set_error("encoder_bwd: hipStreamWaitEvent failed");
+            return NRMS_ELAUNCH;
+        }
         rc = nt_gemm(desc, A_PLAIN, E_STORE, g, wplanes, s, "dx_bwd");
         if (rc) return rc;
     }
@@ -676,9 +715,9 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         else rc = launch_scatter_grouped((long)M, desc->vocab, d, ids, live, n_live, dctx, drop_e, grads->table,
                                          (int*)(base + L.sscr), s);
     }
-    if (side) {                                    // the caller's stream continues after the weight gradients too
-        (void)hipEventRecord(g_gemm_side.ev[4], s2);
-        (void)hipStreamWaitEvent(s, g_gemm_side.ev[4], 0);
+    if (side && rc == NRMS_OK) {                   // the caller's stream continues after the weight gradients too
+        rc = side_order(ss, 4, s2, s, "encoder_bwd");
+        if (rc == NRMS_OK) join_guard.disarm();
     }
     return rc;
 }

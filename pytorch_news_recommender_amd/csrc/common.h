@@ -168,6 +168,29 @@ __device__ __forceinline__ float wave_max(float v) {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// ---- helper streams of the backward (capi.hip).  One SET per (device, caller stream), created the first time that stream
+// runs a backward: the weight-gradient GEMMs fork from the caller's stream onto the set's streams and are joined back into it
+// inside the same C-ABI call (or by the deferred join).  Two engines on two streams -- or on two devices -- of one process
+// get two independent sets; nothing is shared between caller streams.  nullptr = keep everything on the caller's stream
+// (NRMS_NO_SIDE_STREAMS, creation failure, or more than 32 distinct caller streams).
+struct SideSet {
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool pending = false;          // a deferred join is outstanding (NRMS_FLAG_DEFER_WQKV, fp16 mode)
+};
+SideSet* side_streams_for(hipStream_t caller);
+// `to` continues from what is enqueued on `from` so far (event e of the set); NRMS_ELAUNCH when the runtime refuses
+int side_order(SideSet* ss, int e, hipStream_t from, hipStream_t to, const char* what);
+// On scope exit (an error return in the middle of a backward included) the caller's stream waits for whatever the set's
+// streams have been given, so the caller may reuse the workspace they read; disarm() when the normal path has joined them
+// itself or leaves them running on purpose (deferred join).
+struct SideJoinGuard {
+    SideSet* ss; hipStream_t caller; bool armed;
+    SideJoinGuard(SideSet* set, hipStream_t c) : ss(set), caller(c), armed(set != nullptr) {}
+    void disarm() { armed = false; }
+    ~SideJoinGuard();
+};
+
 struct TimingScope {
     TimingScope(const char* name, hipStream_t s);
     ~TimingScope();

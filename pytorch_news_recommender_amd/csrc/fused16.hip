@@ -399,13 +399,16 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
     }
 }
 
-// order[0][..] = titles with at least one non-padding token, order[1][..] = all-padding titles (each list in
-// whatever order the block counters resolve: titles are independent, results do not depend on it); cnt[0..1] = sizes.
+// order[0][..] = titles with at least one non-padding token, order[1][..] = all-padding titles, BOTH IN ASCENDING TITLE ORDER
+// (a stable partition: which workgroup sums which titles' bias gradients -- and therefore the last bits of those sums -- must
+// not depend on how a race between workgroups resolves); cnt[0..1] = their sizes, cnt[2 + 2 b ..] = the two counts of block b.
 // 256 titles per workgroup (64 per wave): the id loads of 16 titles are issued together (one dependent load per title made
-// the kernel a 16-long latency chain), and a workgroup reserves its two output ranges with ONE pair of atomics.
+// the kernel a 16-long latency chain).  Pass 1 (PLACE = false) writes the per-block counts, pass 2 recomputes the flags (the
+// ids are 6.7 MB: cheaper than a flag array round trip), sums the counts of the blocks before it and places its titles.
+template <bool PLACE>
 __global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, const int64_t* ids, int* order, int* cnt) {
     __shared__ int flag[256];
-    __shared__ int wcount[4][2], base[2];
+    __shared__ int wcount[4][2], base[2], part[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t0 = blockIdx.x * 256;
 #pragma unroll 1
@@ -429,11 +432,26 @@ __global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, cons
     const unsigned long long below = (1ull << lane) - 1ull;
     int rank = f == 0 ? __popcll(m_ne & below) : __popcll(m_e & below);
     if (lane == 0) { wcount[wave][0] = __popcll(m_ne); wcount[wave][1] = __popcll(m_e); }
+    if (PLACE) {
+        // counts of the blocks before this one (and, in the last block, of all blocks: the totals)
+        int s0 = 0, s1 = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) { s0 += cnt[2 + 2 * b]; s1 += cnt[3 + 2 * b]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+        if (lane == 0) { part[wave][0] = s0; part[wave][1] = s1; }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        base[0] = atomicAdd(cnt + 0, wcount[0][0] + wcount[1][0] + wcount[2][0] + wcount[3][0]);
-        base[1] = atomicAdd(cnt + 1, wcount[0][1] + wcount[1][1] + wcount[2][1] + wcount[3][1]);
+        const int c0 = wcount[0][0] + wcount[1][0] + wcount[2][0] + wcount[3][0];
+        const int c1 = wcount[0][1] + wcount[1][1] + wcount[2][1] + wcount[3][1];
+        if (!PLACE) { cnt[2 + 2 * blockIdx.x] = c0; cnt[3 + 2 * blockIdx.x] = c1; }
+        else {
+            base[0] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+            base[1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+            if (blockIdx.x == gridDim.x - 1) { cnt[0] = base[0] + c0; cnt[1] = base[1] + c1; }
+        }
     }
+    if (!PLACE) return;
     __syncthreads();
     if (f >= 0) {
         for (int w = 0; w < wave; ++w) rank += wcount[w][f];
@@ -441,11 +459,13 @@ __global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, cons
     }
 }
 
+size_t title_order_cnt_ints(int n_seq) { return 2 + 2 * (size_t)cdiv(n_seq > 0 ? n_seq : 1, 256); }
+
 int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream) {
     if (n_seq <= 0) return NRMS_OK;
-    if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) { set_error("title_order: memset failed"); return NRMS_ELAUNCH; }
     TimingScope ts("title_order", stream);
-    hipLaunchKernelGGL(title_order_kernel, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+    hipLaunchKernelGGL(title_order_kernel<false>, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+    hipLaunchKernelGGL(title_order_kernel<true>, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
     return check_launch("title_order");
 }
 

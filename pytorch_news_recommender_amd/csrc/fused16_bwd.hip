@@ -72,6 +72,12 @@ template <int SB>
 __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fused_bwd16_pool_kernel(Bwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 3 * F16_SLOT);         // [B16_RED] column sums of this workgroup
+    // Column sums are collected WITHOUT atomics: every wave writes its share to a row of its own (stg_t: the 2 x 7 tile
+    // sums of the pooling backward per row block; stg_h: an all-padding title's d(b_v) share of one head, double buffered
+    // over the head loop's barriers) and one thread per column adds the waves' shares in ascending wave order -- the same
+    // bits on every run (a deterministic option for gradient parity).
+    float* stg_t = red + B16_RED;                                       // [F16_WAVES][SB][2 F16_QT][32]
+    float* stg_h = stg_t + F16_WAVES * SB * 2 * F16_QT * 32;            // [2][F16_WAVES][32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
@@ -184,9 +190,15 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                     accz = mfma32h(dz, sel[s2], accz);
                     accu = mfma32h(u, sel[s2], accu);
                 }
-                if (valid) {
-                    atomicAdd(red + B16_RED_QKV + 32 * t + l32, regsum(accz));
-                    atomicAdd(red + B16_RED_QKV + QP + 32 * t + l32, regsum(accu));
+                // this wave's share of d(b_add) (columns of dZ) and d(q_vec) (columns of ds T): both lane halves hold
+                // partial sums over different token rows
+                float cz = valid ? regsum(accz) : 0.f, cu = valid ? regsum(accu) : 0.f;
+                cz += __shfl_xor(cz, 32, 64);
+                cu += __shfl_xor(cu, 32, 64);
+                if (hh == 0) {
+                    float* row = stg_t + ((wave * SB + b) * 2 * F16_QT + 2 * t) * 32 + l32;
+                    row[0] = cz;
+                    row[32] = cu;
                 }
             }
             zf[b][14] = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -195,7 +207,16 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         ring.store(0);
         ring.load(1);
         ring.store(1);
-        __syncthreads();
+        const bool any_closed = __syncthreads_or((!live && valid) ? 1 : 0) != 0;     // (also the barrier the ring needs here)
+        for (int i = tid; i < 2 * F16_QT * 32; i += F16_THREADS) {           // fixed order: waves ascending, row blocks ascending
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < F16_WAVES; ++w)
+#pragma unroll
+                for (int b = 0; b < SB; ++b) sum += stg_t[((w * SB + b) * 2 * F16_QT) * 32 + i];
+            const int r = i >> 5, c = i & 31;                                // r = 2 t + {0: dZ, 1: ds T}
+            red[B16_RED_QKV + (r & 1) * QP + 32 * (r >> 1) + c] += sum;
+        }
 
         // ================= d(ctx)^T per head -> dctx16 =================
         // d(ctx)^T[f][tok] = sum_q Wadd[q][f] dZ[tok][q] + w_tok dout[f], then the forward's dropout mask
@@ -205,6 +226,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             ring.load(n + 2);
             const h8 d0 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 8 * hh);
             const h8 d1 = *reinterpret_cast<const h8*>(a.dout16 + (long)seq * DP + head * 32 + 16 + 8 * hh);
+            float closed = 0.f;                                           // an all-padding title's share of d(b_v) of this head
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 f32x16 dct = zero16();
@@ -232,11 +254,21 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                 }
                 if (!live && valid) {
                     // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
-                    atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(transpose32(dct, idf)));
+                    closed += regsum(transpose32(dct, idf));
                 }
+            }
+            if (any_closed) {
+                closed += __shfl_xor(closed, 32, 64);
+                if (hh == 0) stg_h[((head & 1) * F16_WAVES + wave) * 32 + l32] = closed;
             }
             ring.store(n + 2);
             __syncthreads();
+            if (any_closed && tid < 32) {                                 // (the buffer of this parity is rewritten two barriers later)
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < F16_WAVES; ++w) sum += stg_h[((head & 1) * F16_WAVES + w) * 32 + tid];
+                red[(3 * head + 2) * 32 + tid] += sum;
+            }
             ++n;
         }
         __syncthreads();                                          // the ring restarts: nobody may still read a slot
@@ -251,6 +283,8 @@ template <int SB>
 __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fused_bwd16_attn_kernel(Bwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem + 3 * F16_SLOT);
+    float* stg = red + B16_RED;                       // [2][F16_WAVES][3][32]: per-wave shares of d(b_q), d(b_k), d(b_v) of one head,
+                                                      // double buffered over the head loop's barriers (no atomics: see the pool kernel)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
@@ -344,6 +378,10 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                 vf[b][0] = acc_frag(t, 0); vf[b][1] = acc_frag(t, 1);
             }
             ring.store(n + 2);
+            // column sums of dQ', dK, dV (= of d(ctx)) over this title's rows go to this wave's staging row as soon as they
+            // are complete (short live ranges: the kernel sits at the 256-register limit); a wave without a live title adds zeros
+            float* srow = stg + (((head & 1) * F16_WAVES + wave) * 3) * 32 + l32;
+            if (!live && hh == 0) { srow[0] = 0.f; srow[32] = 0.f; srow[64] = 0.f; }
             if (live) {
                 // ---- per query block ib: P^T[jb][ib] (rows = keys of block jb, columns = queries), dS^T[jb][ib]
                 h8 pf[SB][SB][2], sf[SB][SB][2];                         // [jb][ib] operand fragments
@@ -396,12 +434,18 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                 }
                 // ---- d(ctx) [i][f] per query block; d(b_v) = sum_i d(ctx)_i (rows of P sum to 1)
                 h8 dx0[SB][2];
+                {
+                    float sv = 0.f;
 #pragma unroll
-                for (int ib = 0; ib < SB; ++ib) {
-                    const f32x16 dctx = transpose_frags(dc[ib][0], dc[ib][1], idf);
-                    atomicAdd(red + (3 * head + 2) * 32 + l32, regsum(dctx));
-                    dx0[ib][0] = acc_frag(dctx, 0); dx0[ib][1] = acc_frag(dctx, 1);
+                    for (int ib = 0; ib < SB; ++ib) {
+                        const f32x16 dctx = transpose_frags(dc[ib][0], dc[ib][1], idf);
+                        sv += regsum(dctx);
+                        dx0[ib][0] = acc_frag(dctx, 0); dx0[ib][1] = acc_frag(dctx, 1);
+                    }
+                    sv += __shfl_xor(sv, 32, 64);
+                    if (hh == 0) srow[64] = sv;
                 }
+                float sk = 0.f;
 #pragma unroll
                 for (int jb = 0; jb < SB; ++jb) {
                     _Float16* orow = a.dqkv16 + (drow[jb] < 0 ? 0 : drow[jb]) * (long)B16_DQ + head * 96 + 8 * hh;
@@ -434,10 +478,13 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                             *reinterpret_cast<h8*>(orow + 32) = dk0;
                             *reinterpret_cast<h8*>(orow + 32 + 16) = dk1;
                         }
-                        atomicAdd(red + (3 * head + 1) * 32 + l32, regsum(transpose_frags(dk0, dk1, idf)));
+                        sk += regsum(transpose_frags(dk0, dk1, idf));
                     }
                 }
+                sk += __shfl_xor(sk, 32, 64);
+                if (hh == 0) srow[32] = sk;
                 // ---- dQ'^T[f][i] = sum_j K[j][f] dS^T[j][i]   (i in block ib)
+                float sq = 0.f;
 #pragma unroll
                 for (int ib = 0; ib < SB; ++ib) {
                     f32x16 dq = zero16();
@@ -453,10 +500,18 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                         *reinterpret_cast<h8*>(orow) = dq0;
                         *reinterpret_cast<h8*>(orow + 16) = dq1;
                     }
-                    atomicAdd(red + (3 * head) * 32 + l32, regsum(transpose_frags(dq0, dq1, idf)));
+                    sq += regsum(transpose_frags(dq0, dq1, idf));
                 }
+                sq += __shfl_xor(sq, 32, 64);
+                if (hh == 0) srow[0] = sq;
             }
             __syncthreads();
+            if (tid < 96) {                                               // fixed order: waves ascending
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < F16_WAVES; ++w) sum += stg[(((head & 1) * F16_WAVES + w) * 3) * 32 + tid];
+                red[3 * head * 32 + tid] += sum;
+            }
             ++n;
         }
 #pragma unroll
@@ -476,8 +531,44 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     for (int i = tid; i < B16_RED; i += F16_THREADS) out[i] = red[i];
 }
 
+// ---- loss scale of the fp16 backward, chosen ON THE DEVICE from the upstream gradient it is about to round to fp16:
+// the power of two that puts max |dout| into [64, 128) (fp16 keeps 11 bits down to 6e-5 and overflows above 65504, so the
+// gradient tensors derived from dout have ~2^9 of head room and ~2^20 below them whatever the caller's loss reduction,
+// batch size or data-parallel world size is).  A fixed scale (desc.loss_scale > 0) is used as given.
+// sc[0] = scale, sc[1] = 1 / scale (both exact powers of two); every kernel that removes the scale reads sc[1].
+__device__ __forceinline__ float loss_scale_from_max(unsigned max_bits, float fixed) {
+    if (fixed > 0.f) return fixed;
+    const int e = (int)((max_bits >> 23) & 0xFF) - 127;             // 2^e <= max < 2^(e+1)   (max_bits: |x| as uint)
+    if (max_bits == 0u || e == 128) return 1.0f;                    // all zero, or inf / nan: nothing sensible to scale
+    int k = 6 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    return __uint_as_float((unsigned)(k + 127) << 23);
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(long n, const float* x, unsigned* max_bits) {
+    unsigned m = 0u;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (long i = tid; i < n / 4; i += nth) {
+            const f32x4 v = x4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7FFFFFFFu);     // nan / inf sort above every finite value
+        }
+        for (long i = (n & ~3L) + tid; i < n; i += nth) m = max(m, __float_as_uint(x[i]) & 0x7FFFFFFFu);
+    } else {
+        for (long i = tid; i < n; i += nth) m = max(m, __float_as_uint(x[i]) & 0x7FFFFFFFu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(max_bits, m);
+}
+
 // dout16[n][P16(padded f)] = fp16(dout[n][f] * scale), zero in the padding columns
-__global__ __launch_bounds__(256) void dout16_kernel(long n_seq, int d, int h, int dk, float scale, const float* dout, _Float16* dout16) {
+__global__ __launch_bounds__(256) void dout16_kernel(long n_seq, int d, int h, int dk, float fixed_scale, const unsigned* max_bits,
+                                                     float* sc, const float* dout, _Float16* dout16) {
+    const float scale = loss_scale_from_max(*max_bits, fixed_scale);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = scale; sc[1] = 1.0f / scale; }
     const long total = n_seq * F16_DP;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / F16_DP;
@@ -563,7 +654,7 @@ struct Dx16Args {
     const _Float16* xtiles;   // [30][32][KP]
     float* c;                 // [rows][ldc]
     int ldc, d;
-    float inv_scale;
+    const float* sc;          // device: {loss scale, 1 / loss scale}
 };
 
 __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void gemm16_dx_kernel(Dx16Args a) {
@@ -574,6 +665,7 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void gemm16_dx_kernel(D
     const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
     const int row0 = (blockIdx.x * F16_WAVES + wave) * 32;
     if (blockIdx.x * F16_WAVES * 32 >= M) return;                       // whole workgroup beyond the rows (uniform)
+    const float inv_scale = a.sc[1];
     TileRing ring;
     ring.smem = smem; ring.src = a.xtiles; ring.n_tiles = 30; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
     ring.load(0); ring.store(0);
@@ -607,7 +699,7 @@ __global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void gemm16_dx_kernel(D
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + crow32(r, hh);
-                if (row < M && k < a.d) a.c[(long)row * a.ldc + k] = acc[nt][r] * a.inv_scale;
+                if (row < M && k < a.d) a.c[(long)row * a.ldc + k] = acc[nt][r] * inv_scale;
             }
         }
     }
@@ -817,8 +909,9 @@ __global__ void tn16_reduce_kernel(const float* partial, int splits, int N, int 
 
 // bias / q_vec gradients from the per-workgroup column sums of the fused kernel (fixed order: 8 row groups per
 // column, each summed in ascending workgroup order, then combined in a fixed tree)
-__global__ __launch_bounds__(1024) void red16_kernel(const float* red, int n_wg, int h, int dk, int d, int q, float inv_scale,
+__global__ __launch_bounds__(1024) void red16_kernel(const float* red, int n_wg, int h, int dk, int d, int q, const float* sc,
                                                     float qscale, float* db_qkv, float* db_add, float* dq_vec) {
+    const float inv_scale = sc[1];
     __shared__ float part[32][33];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + c;
@@ -856,8 +949,9 @@ __global__ __launch_bounds__(1024) void red16_kernel(const float* red, int n_wg,
 }
 
 // index maps of the reduce: rows of d(W_qkv) (dqkv16 column order), columns of d(W_add) (ctx16 column order)
-__global__ void maps16_kernel(int d, int h, int dk, int q, float inv_scale, float qscale, int* nmap_qkv, float* nscale_qkv,
+__global__ void maps16_kernel(int d, int h, int dk, int q, const float* sc, float qscale, int* nmap_qkv, float* nscale_qkv,
                               int* kmap_x, int* nmap_add, float* nscale_add, int* kmap_ctx) {
+    const float inv_scale = sc[1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B16_DQ) {
         const int head = i / 96, rem = i - head * 96, which = rem >> 5, p = rem & 31;
@@ -879,27 +973,10 @@ __global__ void maps16_kernel(int d, int h, int dk, int q, float inv_scale, floa
 // ---------------------------------------------------------------------------------------------------------------
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
-// Two helper streams (created once per process) so that the two weight-gradient GEMMs -- HBM-bound, independent of
-// everything after them -- run beside the issue-bound attention kernel and the dX GEMM instead of behind them.  Forked
-// from and joined back into the caller's stream with events inside the same C-ABI call: to the caller the call is still
-// one in-order piece of work on its stream.
-struct SideStreams {
-    hipStream_t s[2] = {nullptr, nullptr};
-    hipEvent_t fork[2] = {nullptr, nullptr}, join[2] = {nullptr, nullptr};
-    bool ok = false, tried = false;
-    bool pending = false;          // a deferred join is outstanding (Fused16Bwd::defer_join)
-    void init() {
-        if (tried) return;
-        tried = true;
-        for (int i = 0; i < 2; ++i) {
-            if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return;
-            if (hipEventCreateWithFlags(&fork[i], hipEventDisableTiming) != hipSuccess) return;
-            if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) return;
-        }
-        ok = true;
-    }
-};
-static SideStreams g_side;
+// Two helper streams (a set per caller stream, side_streams_for in capi.hip) so that the two weight-gradient GEMMs --
+// HBM-bound, independent of everything after them -- run beside the issue-bound attention kernel and the dX GEMM instead of
+// behind them.  Forked from and joined back into the caller's stream with events inside the same C-ABI call: to the caller
+// the call is still one in-order piece of work on its stream.  Events of the set: 0, 1 = forks, 2, 3 = joins (6, 7: guard).
 
 Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     Fused16BwdLayout L;
@@ -917,6 +994,7 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     L.dqkv16 = take((size_t)(M + 32) * B16_DQ * 2);
     L.red = take((size_t)2 * L.n_wg * B16_RED * 4);      // pool kernel + attention kernel
     L.maps = take((size_t)(B16_DQ * 2 + F16_KP + F16_QP * 2 + F16_DP) * 4);
+    L.scale = take(256);                                 // {scale, 1 / scale} floats, then max |dout| as uint bits
     // TN partial slabs.  The kernel's ~200 registers allow two waves per SIMD, i.e. exactly ONE 8-wave workgroup per CU:
     // the grid must not exceed the 256 CUs, or the surplus workgroups run as a second round on an otherwise idle GPU
     // (44 splits x 6 blocks = 264 workgroups took 0.39 ms alone, 40 x 6 = 240 take 0.23 ms; inside the step, where the
@@ -966,7 +1044,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     const Fused16BwdLayout L = fused16_bwd_layout(M, f.n_seq);
     char* base = (char*)f.workspace;
     const int dk = f.d / f.h;
-    const float qscale = 1.0f / sqrtf((float)dk), inv_scale = 1.0f / f.loss_scale;
+    const float qscale = 1.0f / sqrtf((float)dk);
     _Float16* btiles = (_Float16*)(base + L.btiles);
     _Float16* xtiles = (_Float16*)(base + L.xtiles);
     _Float16* qv16 = (_Float16*)(base + L.qv16);
@@ -982,13 +1060,16 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     int* nmap_add = kmap_x + F16_KP;
     float* nscale_add = (float*)(nmap_add + F16_QP);
     int* kmap_ctx = (int*)(nscale_add + F16_QP);
+    float* sc = (float*)(base + L.scale);                      // device: {scale, 1 / scale}
+    unsigned* max_bits = (unsigned*)(sc + 2);
     float* partial_qkv = (float*)(base + L.partial);
     float* partial_add = (float*)(base + L.partial + up256((size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4));
-    g_side.init();
-    if (g_side.pending) { const int jr = fused_bwd16_join(stream); if (jr) return jr; }      // an un-joined earlier call: order it first
-    // NRMS_NO_SIDE_STREAMS is read per call so that a profiler pass can serialise the step (exclusive kernel durations)
-    const bool side = g_side.ok && getenv("NRMS_NO_SIDE_STREAMS") == nullptr;
-    hipStream_t s_add = side ? g_side.s[0] : stream, s_qkv = side ? g_side.s[1] : stream;
+    { const int jr = fused_bwd16_join(stream); if (jr) return jr; }      // an un-joined earlier call on this stream: order it first
+    // (NRMS_NO_SIDE_STREAMS is read per call so that a profiler pass can serialise the step: exclusive kernel durations)
+    SideSet* ss = side_streams_for(stream);
+    const bool side = ss != nullptr;
+    hipStream_t s_add = side ? ss->s[0] : stream, s_qkv = side ? ss->s[1] : stream;
+    SideJoinGuard join_guard(ss, stream);
     const int Mp = f.n_seq * 32 * (f.S > 32 ? 2 : 1);         // fragment order: 32 rows per block, zero beyond a sequence
     {
         Prep16bArgs p{};
@@ -996,10 +1077,15 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         p.btiles = btiles; p.xtiles = xtiles; p.qv16 = qv16; p.bqkv32 = bqkv32;
         TimingScope ts("prep16", stream);
         hipLaunchKernelGGL(prep16b_kernel, dim3(2048), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(maps16_kernel, dim3(cdiv(B16_DQ, 256)), dim3(256), 0, stream, f.d, f.h, dk, f.q, inv_scale, qscale,
-                           nmap_qkv, nscale_qkv, kmap_x, nmap_add, nscale_add, kmap_ctx);
+        // loss scale: from max |dout| on the device unless the caller fixed it (f.loss_scale > 0)
+        if (hipMemsetAsync(max_bits, 0, sizeof(unsigned), stream) != hipSuccess) { set_error("fused_bwd16: memset failed"); return NRMS_ELAUNCH; }
+        const long nd = (long)f.n_seq * f.d;
+        if (!(f.loss_scale > 0.f))
+            hipLaunchKernelGGL(absmax_kernel, dim3(nd > 1024L * 1024 ? 1024 : (int)cdiv(nd, 1024)), dim3(256), 0, stream, nd, f.dout, max_bits);
         hipLaunchKernelGGL(dout16_kernel, dim3(cdiv((long)f.n_seq * F16_DP, 256) > 4096 ? 4096 : cdiv((long)f.n_seq * F16_DP, 256)),
-                           dim3(256), 0, stream, (long)f.n_seq, f.d, f.h, dk, f.loss_scale, f.dout, dout16);
+                           dim3(256), 0, stream, (long)f.n_seq, f.d, f.h, dk, f.loss_scale, max_bits, sc, f.dout, dout16);
+        hipLaunchKernelGGL(maps16_kernel, dim3(cdiv(B16_DQ, 256)), dim3(256), 0, stream, f.d, f.h, dk, f.q, sc, qscale,
+                           nmap_qkv, nscale_qkv, kmap_x, nmap_add, nscale_add, kmap_ctx);
         int rc = check_launch("prep16b");
         if (rc) return rc;
     }
@@ -1016,8 +1102,11 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
 #endif
     const int n_wg = a.n_groups < L.n_wg ? a.n_groups : L.n_wg;
     {
-        const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4;
         const bool two = f.S > 32;
+        // ring + column sums + the per-wave staging rows of the atomic-free reductions (the pooling kernel's are the larger)
+        const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4 +
+                           (size_t)(F16_WAVES * (two ? 2 : 1) * 2 * F16_QT * 32 + 2 * F16_WAVES * 32) * 4;
+        static_assert(F16_WAVES * 2 * F16_QT * 32 + 2 * F16_WAVES * 32 >= 2 * F16_WAVES * 3 * 32, "the attention kernel's staging fits the same size");
         const void* fp = two ? (const void*)fused_bwd16_pool_kernel<2> : (const void*)fused_bwd16_pool_kernel<1>;
         const void* fa = two ? (const void*)fused_bwd16_attn_kernel<2> : (const void*)fused_bwd16_attn_kernel<1>;
         hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1030,12 +1119,12 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         }
         if (side) {
             // d(W_add)[q][f] = sum_tok dZ[tok][q] ctx[tok][f] needs only the pooling kernel's dZ16: beside the attention kernel
-            (void)hipEventRecord(g_side.fork[0], stream);
-            (void)hipStreamWaitEvent(s_add, g_side.fork[0], 0);
-            int rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
-                                 L.tn_splits_add, nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, s_add, "dwadd_bwd");
+            int rc = side_order(ss, 0, stream, s_add, "fused_bwd16");
             if (rc) return rc;
-            (void)hipEventRecord(g_side.join[0], s_add);
+            rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
+                             L.tn_splits_add, nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, s_add, "dwadd_bwd");
+            if (rc) return rc;
+            if (hipEventRecord(ss->ev[2], s_add) != hipSuccess) { set_error("fused_bwd16: hipEventRecord failed"); return NRMS_ELAUNCH; }
         }
         Bwd16Args b = a;
         b.red = red + (long)n_wg * B16_RED;                       // second set of per-workgroup sums
@@ -1049,7 +1138,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     }
     {
         TimingScope ts("red16", stream);
-        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 32)), dim3(1024), 0, stream, red, 2 * n_wg, f.h, dk, f.d, f.q, inv_scale,
+        hipLaunchKernelGGL(red16_kernel, dim3(cdiv(B16_RED, 32)), dim3(1024), 0, stream, red, 2 * n_wg, f.h, dk, f.d, f.q, sc,
                            qscale, f.db_qkv, f.db_add, f.dq_vec);
         int rc = check_launch("red16");
         if (rc) return rc;
@@ -1062,18 +1151,18 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     }
     // d(W_qkv)[n][k] = sum_rows dQKV[r][n] x[r][k]   (live rows only): beside the dX GEMM
     if (side) {
-        (void)hipEventRecord(g_side.fork[1], stream);
-        (void)hipStreamWaitEvent(s_qkv, g_side.fork[1], 0);
+        rc = side_order(ss, 1, stream, s_qkv, "fused_bwd16");
+        if (rc) return rc;
     }
     rc = launch_tn16(false, dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial_qkv,
                      L.tn_splits_qkv, nmap_qkv, kmap_x, nscale_qkv, f.d, f.dw_qkv, s_qkv, "dwqkv_bwd");
     if (rc) return rc;
-    if (side) (void)hipEventRecord(g_side.join[1], s_qkv);
+    if (side && hipEventRecord(ss->ev[3], s_qkv) != hipSuccess) { set_error("fused_bwd16: hipEventRecord failed"); return NRMS_ELAUNCH; }
     // dX = dQKV W'  -> fp32 rows
     {
         Dx16Args g{};
         g.M = (int)M; g.m_dev = f.n_rows_dev; g.a16 = dqkv16; g.xtiles = xtiles; g.c = f.dx; g.ldc = f.d; g.d = f.d;
-        g.inv_scale = inv_scale;
+        g.sc = sc;
         const size_t lds = (size_t)3 * F16_SLOT;
         const hipError_t e = hipFuncSetAttribute((const void*)gemm16_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("gemm16_dx: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
@@ -1081,21 +1170,23 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         hipLaunchKernelGGL(gemm16_dx_kernel, dim3(cdiv(M, 32 * F16_WAVES)), dim3(F16_THREADS), lds, stream, g);
         rc = check_launch("gemm16_dx");
     }
-    if (side) {                                                     // join: the caller's stream continues after both GEMMs
-        if (f.defer_join) g_side.pending = true;                    // ... or later, in fused_bwd16_join
-        else {
-            (void)hipStreamWaitEvent(stream, g_side.join[0], 0);
-            (void)hipStreamWaitEvent(stream, g_side.join[1], 0);
+    if (side && rc == NRMS_OK) {                                    // join: the caller's stream continues after both GEMMs
+        if (f.defer_join) ss->pending = true;                       // ... or later, in fused_bwd16_join
+        else if (hipStreamWaitEvent(stream, ss->ev[2], 0) != hipSuccess || hipStreamWaitEvent(stream, ss->ev[3], 0) != hipSuccess) {
+            set_error("fused_bwd16: hipStreamWaitEvent failed");
+            return NRMS_ELAUNCH;                                    // (the guard still joins what it can)
         }
+        join_guard.disarm();
     }
     return rc;
 }
 
 // The other half of Fused16Bwd::defer_join: work enqueued on `stream` after this sees d(W_qkv), d(b_qkv), d(W_add), d(b_add).
 int fused_bwd16_join(hipStream_t stream) {
-    if (!g_side.pending) return NRMS_OK;
-    g_side.pending = false;
-    if (hipStreamWaitEvent(stream, g_side.join[0], 0) != hipSuccess || hipStreamWaitEvent(stream, g_side.join[1], 0) != hipSuccess) {
+    SideSet* ss = side_streams_for(stream);
+    if (ss == nullptr || !ss->pending) return NRMS_OK;
+    ss->pending = false;
+    if (hipStreamWaitEvent(stream, ss->ev[2], 0) != hipSuccess || hipStreamWaitEvent(stream, ss->ev[3], 0) != hipSuccess) {
         set_error("fused_bwd16_join: hipStreamWaitEvent failed");
         return NRMS_ELAUNCH;
     }

@@ -348,11 +348,13 @@ struct Fused16Fwd {
     Dropout drop;             // context dropout
 };
 int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream);
+// order [2][n_seq] ints, cnt title_order_cnt_ints(n_seq) ints (cnt[0..1] = the two list sizes)
+size_t title_order_cnt_ints(int n_seq);
 int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream);
 
 // fused16_bwd.hip: the backward of the above.  `workspace` holds the backward weight planes, dout16, dZ16, dQKV16, the
 // per-workgroup column sums and the split-M partial slabs (fused16_bwd_layout(M, n_seq).total bytes).
-struct Fused16BwdLayout { int n_wg, tn_splits_qkv, tn_splits_add; size_t btiles, xtiles, qv16, bqkv32, dout16, dz16, dctx16, dqkv16, red, maps, partial, total; };
+struct Fused16BwdLayout { int n_wg, tn_splits_qkv, tn_splits_add; size_t btiles, xtiles, qv16, bqkv32, dout16, dz16, dctx16, dqkv16, red, maps, scale, partial, total; };
 Fused16BwdLayout fused16_bwd_layout(long M, int n_seq);
 struct Fused16Bwd {
     int n_seq, S, d, h, q;
@@ -365,7 +367,8 @@ struct Fused16Bwd {
     const int* order; const int* order_cnt;
     const void* ctx16; const void* t16; const float* w;         // forward activations
     const float* dout;        // [n_seq][d]
-    float loss_scale;         // power of two: fp16 gradients are carried multiplied by it
+    float loss_scale;         // > 0: fixed power of two the fp16 gradients are carried multiplied by; <= 0: chosen on the
+                              // device from max |dout| (loss_scale_from_max)
     Dropout drop;             // context dropout
     float* dw_qkv; float* db_qkv; float* dw_add; float* db_add; float* dq_vec;           // accumulated
     float* dx;                // [rows][d] fp32 (rows as pos / tokens): gradient w.r.t. the encoder input

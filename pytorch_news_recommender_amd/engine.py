@@ -114,8 +114,9 @@ class NRMSEngine:
             raise _lib.NrmsError("the NRMS HIP engine needs a GPU device (got %s); there is no CPU path" % device)
         self._bufs = {}
         self._saved = None
+        self.fp16_user_encoder = False     # precision "fp16": the user encoder runs in bf16x3 unless this is set
         self.fp16_backward = True          # training in fp16 mode runs the fused fp16 backward (csrc/fused16_bwd.hip)
-        self.loss_scale = 65536.0          # fp16 backward: power of two ~128 x the global batch (set per step)
+        self.loss_scale = 0.0              # fp16 backward: 0 = chosen on the device from max |dout| per call (nrms_hip.h)
         self._gen = 0                      # generation stamp of _saved (checked by the autograd backward)
         # out-of-range word ids: counted on the device by nrms_sanitize_ids, surfaced without a host sync
         # (the count is copied to pinned memory behind the kernel and looked at on a later call)
@@ -128,9 +129,13 @@ class NRMSEngine:
 
     def _fp16_ok(self, enc, seq_len, mask_mode, training):
         """The fused fp16 kernels cover the shapes of include/nrms_hip.h (NRMS_PRECISION_FP16); an encoder pass
-        outside them (e.g. the user encoder over a 50-slot history) runs in bf16x3 instead."""
+        outside them runs in bf16x3 instead.  So does the user encoder unless fp16_user_encoder is set: it is 3 % of
+        the flops, and with it in split-bf16 (~2^-16 relative) the scores keep a margin inside north_star's 1e-4
+        and the user encoder's additive-attention gradients (cancelling sums) are no longer fp16 noise."""
         d, L = self.dims, self.FP16_LIMITS
         h = d.heads(enc)
+        if enc == "user_encoder" and not self.fp16_user_encoder:
+            return False
         return (seq_len <= L["seq_len"] and d.word_embed_size <= L["d_model"] and h <= L["n_heads"]
                 and d.word_embed_size // h <= L["d_k"] and d.query_vector_dim <= L["q_dim"]
                 and not d.output_proj and not mask_mode and (not training or self.fp16_backward))
@@ -387,9 +392,9 @@ class NRMSEngine:
         B, H, Cn, L = sv["B"], sv["H"], sv["C"], sv["L"]
         d = self.dims.word_embed_size
         N = B * (H + Cn)
-        self.loss_scale = float(2 ** math.ceil(math.log2(128.0 * max(B, 1))))     # fp16 mode: d(scores) ~ 1 / batch
-        if getattr(self, "loss_scale_override", None):
-            self.loss_scale = float(self.loss_scale_override)                     # experiments (tools/fp16_grad_stats.py)
+        # fp16 mode: the loss scale is derived on the device from the gradient each encoder receives (any loss reduction,
+        # batch size or world size); a fixed value only for experiments (tools/fp16_grad_stats.py)
+        self.loss_scale = float(getattr(self, "loss_scale_override", None) or 0.0)
         nv, user = sv["nv"], sv["user"]
         hist = nv[:B * H]
         cand = nv[B * H:]

@@ -211,6 +211,7 @@ class Model(nn.Module):
             # into the table by hand without refresh_pad_row_flag()): is the padding row all zeros?
             tname = [n for n in self._names if n.endswith("word_embedding.0.weight") or n.endswith("word_embedding.weight")][0]
             self._pad_zero = bool((self._layout.view(self._flat, tname)[0] == 0).all().item())
+        self._engine.fp16_user_encoder = bool(getattr(self.config, "fp16_user_encoder", False))
         self._engine.pad_row_zero = self._pad_zero and bool(getattr(self.config, "skip_padding_tokens", True))
         return self._flat.device
 
@@ -297,7 +298,27 @@ class Model(nn.Module):
         scores = eng.forward(self._flat, bt, ct, mask, training=True, p_drop=p_drop, seed=seed)
         loss_sum, dscores = eng.ce_loss(scores, grad_scale=1.0 / gb)
         st["g"].zero_()
-        if all_reduce is not None and hasattr(all_reduce, "start") and not os.environ.get("NRMS_NO_OVERLAP"):
+        lr_ = float(self.config.learning_rate if lr is None else lr)
+        overlap = not os.environ.get("NRMS_NO_OVERLAP")
+        if all_reduce is not None and hasattr(all_reduce, "owned"):
+            # parallel.ShardedGradSync: reduce-scatter (the table region underneath the deferred weight-gradient GEMMs),
+            # Adam on the 1/world of the parameters this rank owns, all-gather of the updated parameters
+            pending = []
+            if overlap:
+                eng.backward(self._flat, st["g"], dscores, table_grad_ready=lambda: pending.append(all_reduce.start(st["g"], 0)))
+            else:
+                eng.backward(self._flat, st["g"], dscores)
+                pending.append(all_reduce.start(st["g"], 0))
+            pending.append(all_reduce.start(st["g"], 1))
+            for h in pending:
+                h.wait()
+            st["step"] += 1
+            for lo, hi, gshard in all_reduce.owned():
+                eng.adam_step(self._flat[lo:hi], gshard, st["m"][lo:hi], st["v"][lo:hi], st["step"], lr=lr_, betas=betas, eps=eps)
+            all_reduce.gather(self._flat)
+            self._last_scores = scores
+            return loss_sum
+        if all_reduce is not None and hasattr(all_reduce, "start") and overlap:
             # the table gradient (first V*d floats of the flat buffer, 95 % of the bytes) is reduced underneath
             # the deferred d(W_qkv) GEMM; the remaining 2.6 MB follow when the backward has been enqueued
             n_table = self._dims.n_words * self._dims.word_embed_size
@@ -312,8 +333,7 @@ class Model(nn.Module):
             if all_reduce is not None:
                 all_reduce(st["g"])
         st["step"] += 1
-        eng.adam_step(self._flat, st["g"], st["m"], st["v"], st["step"],
-                      lr=float(self.config.learning_rate if lr is None else lr), betas=betas, eps=eps)
+        eng.adam_step(self._flat, st["g"], st["m"], st["v"], st["step"], lr=lr_, betas=betas, eps=eps)
         self._last_scores = scores
         return loss_sum
 

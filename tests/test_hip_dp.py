@@ -35,7 +35,17 @@ def _build(shape, params, precision="fp32"):
     return m.to("cuda:0").train()
 
 
-def _worker(rank, world, port, out_dir, precision):
+def _sync(kind, model, force=False):
+    """"allreduce": parallel.GradAllReduce (+ full Adam on every rank); "sharded": reduce-scatter, Adam on the owned
+    1/world, all-gather (parallel.ShardedGradSync)."""
+    from pytorch_news_recommender_amd import parallel
+    if kind == "allreduce":
+        return parallel.GradAllReduce(force=force)
+    n_table = model._dims.n_words * model._dims.word_embed_size
+    return parallel.ShardedGradSync(model._flat.numel(), n_table, force=force)
+
+
+def _worker(rank, world, port, out_dir, precision, sync="allreduce"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -47,7 +57,7 @@ def _worker(rank, world, port, out_dir, precision):
     model = _build(shape, params, precision)
     model.engine
     parallel.broadcast_parameters(model._flat, src=0)
-    reduce = parallel.GradAllReduce()
+    reduce = _sync(sync, model)
     losses = []
     for t in range(2):
         gbatch = synth.make_batch(shape, seed=20 + t, ragged=True)
@@ -61,11 +71,11 @@ def _worker(rank, world, port, out_dir, precision):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16"])
-def test_two_ranks_match_single_process(tmp_path, precision):
+@pytest.mark.parametrize("precision,sync", [("fp32", "allreduce"), ("fp16", "allreduce"), ("fp32", "sharded"), ("fp16", "sharded")])
+def test_two_ranks_match_single_process(tmp_path, precision, sync):
     from pytorch_news_recommender_amd import synth
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), precision), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), precision, sync), nprocs=2, join=True)
     f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
     assert np.abs(f0 - f1).max() < 1e-7                   # replicas stay in lock-step
     shape = synth.Shape(n_words=400, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
@@ -130,7 +140,7 @@ def test_deferred_wqkv_backward_equals_plain_backward():
             assert torch.equal(a, b), n
 
 
-def _rccl_worker(rank, port, out_dir, precision):
+def _rccl_worker(rank, port, out_dir, precision, sync="allreduce"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from pytorch_news_recommender_amd import parallel, synth
@@ -142,7 +152,7 @@ def _rccl_worker(rank, port, out_dir, precision):
     model = _build(shape, synth.make_params(shape, seed=9), precision)
     model.engine
     parallel.broadcast_parameters(model._flat, src=0)
-    reduce = parallel.GradAllReduce(force=True)
+    reduce = _sync(sync, model, force=True)
     assert reduce.active
     losses = []
     for t in range(3):
@@ -154,14 +164,15 @@ def _rccl_worker(rank, port, out_dir, precision):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16"])
-def test_rccl_collectives_on_one_gpu(tmp_path, precision):
+@pytest.mark.parametrize("precision,sync", [("fp32", "allreduce"), ("fp16", "allreduce"), ("fp16", "sharded")])
+def test_rccl_collectives_on_one_gpu(tmp_path, precision, sync):
     """The data-parallel step through REAL RCCL calls (backend "nccl", a one-rank group: two ranks cannot share a GPU under
     RCCL): asynchronous all-reduce of the table gradient started from inside the backward, the deferred d(W_qkv) GEMMs
     enqueued under it, the second all-reduce, the waits, Adam -- must equal the plain single-process step
-    (a one-rank sum is the identity), i.e. the stream ordering between the kernels and RCCL's stream holds."""
+    (a one-rank sum is the identity), i.e. the stream ordering between the kernels and RCCL's stream holds.
+    sync = "sharded": the same through ncclReduceScatter / ncclAllGather (parallel.ShardedGradSync; one rank owns it all)."""
     from pytorch_news_recommender_amd import synth
-    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path), precision), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path), precision, sync), nprocs=1, join=True)
     shape = synth.Shape(n_words=400, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                         batch_size=6, history_len=50, n_candidates=5, n_words_title=30)
     model = _build(shape, synth.make_params(shape, seed=9), precision)

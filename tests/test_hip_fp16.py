@@ -1,6 +1,10 @@
 """precision = "fp16": the fused one-wavefront-per-sequence kernels (csrc/fused16.hip) against the reference
 fixtures and the oracle.  fp16 operands carry 11 significant bits, so the bar here is north_star's own
-(scores within 1e-4 of the reference), not the 1e-5 of the fp32 / bf16x3 modes; the measured errors are printed."""
+(scores within 1e-4 of the reference), not the 1e-5 of the fp32 / bf16x3 modes; the measured errors are printed.
+
+The mode's default keeps the user encoder (3 % of the flops) in bf16x3; `fp16_user` = True puts it on the fused fp16
+kernels as well (config.fp16_user_encoder) -- that variant is tested against a 1.5e-4 bar (it sits AT 1e-4 on large
+batches, which is why it is not the default)."""
 import os
 
 import numpy as np
@@ -13,6 +17,13 @@ from tests.test_hip_parity import make_model, tbatch
 pytestmark = pytest.mark.gpu
 
 SCORE_TOL = 1e-4          # north_star: click scores within 1e-4 of the reference
+USER16 = [False, True]    # config.fp16_user_encoder
+
+
+def score_bar(o_scores, fp16_user=False):
+    """1e-4 absolute for scores of the reference's own scale (|score| <= 0.1 at initialisation, where north_star states its
+    bar); proportionally more where a synthetic shape produces larger scores (fp16 error is relative)."""
+    return (1.5e-4 if fp16_user else SCORE_TOL) * max(1.0, float(np.abs(o_scores).max()) / 0.1)
 VEC_TOL = 1.5e-3          # news / user vectors (norm ~ 1..10): 2^-11 relative per rounding
 
 
@@ -22,12 +33,13 @@ def _padded_to_model_cols(keep_padded, n_heads, dk):
     return k.reshape(keep_padded.shape[0], n_heads * dk)
 
 
-def test_fp16_scores_within_bar_of_reference_fixture(golden_dir):
+@pytest.mark.parametrize("fp16_user", USER16)
+def test_fp16_scores_within_bar_of_reference_fixture(golden_dir, fp16_user):
     g = np.load(os.path.join(golden_dir, "g2_mind.npz"), allow_pickle=False)
     shape = synth.G2_MIND
     params = synth.make_params(shape, seed=21)
     batch = synth.make_batch(shape, seed=22, ragged=True)
-    model = make_model(shape, params, precision="fp16").eval()
+    model = make_model(shape, params, precision="fp16", fp16_user=fp16_user).eval()
     B, H, L = batch["browsed_titles"].shape
     with torch.no_grad():
         for dedup in (True, False):
@@ -42,8 +54,9 @@ def test_fp16_scores_within_bar_of_reference_fixture(golden_dir):
     assert verr < VEC_TOL
 
 
+@pytest.mark.parametrize("fp16_user", USER16)
 @pytest.mark.parametrize("case", ["g1_odd", "tiny", "bench_small", "all_padding", "nonzero_pad_row"])
-def test_fp16_forward_shapes_against_oracle(case):
+def test_fp16_forward_shapes_against_oracle(case, fp16_user):
     """Both encoders through the fused kernel (histories of at most 32 slots) on awkward shapes: d_k = 6 with 10
     heads (KP = 64, DP = 320, QP = 32), minimum sizes, all-padding titles (closed form), an empty-history user,
     masked candidates, a table whose padding row is not zero (dense path)."""
@@ -71,19 +84,19 @@ def test_fp16_forward_shapes_against_oracle(case):
     if case == "all_padding":
         batch["browsed_titles"][:] = 0
         batch["candidate_titles"][:] = 0
-    model = make_model(shape, params, precision="fp16").eval()
+    model = make_model(shape, params, precision="fp16", fp16_user=fp16_user).eval()
     model.dedup_inference = False
     with torch.no_grad():
         s = model(tbatch(batch)).cpu().numpy()
-    assert model.engine.pad_row_zero is pad_zero
+    assert model.engine.pad_row_zero is pad_zero and model.engine.fp16_user_encoder is fp16_user
     p = orc.to_torch(params)
     with torch.no_grad():
         o_scores, aux = orc.forward(p, batch, shape.num_attention_heads)
     o_scores = o_scores.numpy()
     valid = batch["candidate_mask"] == 1
     err = float(np.abs(s - o_scores)[valid].max())
-    print("fp16 %s: max |score - oracle| = %.3e (score scale %.3f)" % (case, err, float(np.abs(o_scores[valid]).max())))
-    assert err < 3e-4 * max(1.0, float(np.abs(o_scores[valid]).max()) / 0.1)
+    print("fp16 %s (user fp16=%s): max |score - oracle| = %.3e (score scale %.3f)" % (case, fp16_user, err, float(np.abs(o_scores[valid]).max())))
+    assert err < score_bar(o_scores[valid], fp16_user)
     assert (s[~valid] == np.float32(-1e9)).all()
     # the encoders on their own
     B, H, L = batch["browsed_titles"].shape
@@ -120,7 +133,7 @@ def test_fp16_train_mode_forward_replays_its_dropout_masks():
         o_scores, _ = orc.forward(pt, batch, h, p_drop=0.2, keep={"embed": ke, "ctx": kc})
     err = float(np.abs(s - o_scores.numpy()).max())
     print("fp16 dropout replay: max |score - oracle| = %.3e" % err)
-    assert err < 3e-4
+    assert err < score_bar(o_scores.numpy())
 
 
 def test_fp16_mode_rejects_shapes_outside_the_fused_kernels():
@@ -180,8 +193,13 @@ def test_fp16_gradients_against_reference_fixture(golden_dir):
     assert not grads[emb][0].any()
 
 
-@pytest.mark.parametrize("case", ["g1_odd", "bench_small", "all_padding", "nonzero_pad_row", "dropout"])
-def test_fp16_forward_backward_against_oracle(case):
+@pytest.mark.parametrize("fp16_user", USER16)
+@pytest.mark.parametrize("case", ["g1_odd", "bench_small", "all_padding", "nonzero_pad_row", "dropout", "dropout_bench"])
+def test_fp16_forward_backward_against_oracle(case, fp16_user):
+    """`dropout_bench`: the benchmarked geometry -- d = 300 (KP = DP = 320), 10 heads x 30 (the 16-bit-field mask over
+    10 x 32 padded columns), q = 200 (QP = 224), 30-word titles (SB = 1 kernels), 50-slot histories (the SB = 2 user-encoder
+    kernels when fp16_user), dropout 0.2 on both sites, padding-skipping compact path -- replayed through the oracle with
+    the kernels' own keep masks (nrms_v0.py:137,171-173 semantics): scores and all 19 gradients."""
     from oracle import nrms_oracle as orc
     from tests.test_hip_parity import fwd_bwd
     kw = dict(seed=102, ragged=True, min_title=1, empty_history_user=True, all_pad_title=True, mask_some_candidates=True)
@@ -198,17 +216,22 @@ def test_fp16_forward_backward_against_oracle(case):
         shape = synth.Shape(n_words=300, word_embed_size=120, num_attention_heads=6, query_vector_dim=64, batch_size=12,
                             history_len=20, n_candidates=4, n_words_title=17)
         pad_zero = False
-    else:
+    elif case == "dropout":
         shape = synth.Shape(n_words=500, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
                             batch_size=6, history_len=9, n_candidates=4, n_words_title=12)
+        p_drop = 0.2
+    else:
+        shape = synth.Shape(n_words=2000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                            batch_size=6, history_len=50, n_candidates=5, n_words_title=30)
         p_drop = 0.2
     params = synth.make_params(shape, seed=101, pad_row_zero=pad_zero)
     batch = synth.make_batch(shape, **kw)
     if case == "all_padding":
         batch["browsed_titles"][:] = 0
         batch["candidate_titles"][:] = 0
-    model = make_model(shape, params, dropout=p_drop, precision="fp16").train()
+    model = make_model(shape, params, dropout=p_drop, precision="fp16", fp16_user=fp16_user).train()
     scores, loss, grads = fwd_bwd(model, batch)
+    assert model.engine.pad_row_zero is pad_zero
     keep = None
     if p_drop > 0:
         sv = model.engine._saved
@@ -220,12 +243,41 @@ def test_fp16_forward_backward_against_oracle(case):
     o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads, p_drop=p_drop, keep=keep)
     valid = batch["candidate_mask"] == 1
     err = float(np.abs(scores - o_scores)[valid].max())
-    print("fp16 train %s: max |score - oracle| = %.3e, |loss diff| %.2e" % (case, err, abs(loss - o_loss)))
-    assert err < 3e-4 * max(1.0, float(np.abs(o_scores[valid]).max()) / 0.1)
+    print("fp16 train %s (user fp16=%s): max |score - oracle| = %.3e, |loss diff| %.2e" % (case, fp16_user, err, abs(loss - o_loss)))
+    assert err < score_bar(o_scores[valid], fp16_user)
     # all_padding: every title is the same vector, the true bias gradients are differences of equal terms (~1e-8)
     # while each term is ~0.1: what is left is the fp16 rounding of the terms, ~1e-4 absolute
     _grad_report(grads, o_grads, synth.param_names(), case, abs_floor=2e-4 if case == "all_padding" else GRAD_ABS)
     assert not grads["news_encoder.word_embedding.0.weight"][0].any()
+
+
+def test_fp16_sum_reduced_loss_through_autograd():
+    """A loss the fixed 128 x batch scale of round 2 could not carry: CrossEntropyLoss(reduction="sum") at 512 users makes
+    |d(scores)| O(1) instead of O(1/512) -- x 65536 that overflowed fp16 and sent NaNs through Adam.  The loss scale is
+    now derived on the device from max |dout| of each backward call, so any reduction / batch / world size works: the
+    gradients must be finite and equal batch x the oracle's mean-loss gradients."""
+    from oracle import nrms_oracle as orc
+    # (a vocabulary large enough that no word occurs more than 64 times in the step: the grouped scatter sums longer buckets
+    #  in an order that is reproducible only chunk by chunk, csrc/embed.hip)
+    shape = synth.Shape(n_words=30000, word_embed_size=60, num_attention_heads=6, query_vector_dim=32,
+                        batch_size=512, history_len=9, n_candidates=4, n_words_title=12)
+    params = synth.make_params(shape, seed=7)
+    batch = synth.make_batch(shape, seed=8, ragged=True, min_title=1, mask_some_candidates=True)
+    res = {}
+    for red in ("sum", "mean"):
+        model = make_model(shape, params, precision="fp16", fp16_user=True).train()
+        model.zero_grad()
+        scores = model(tbatch(batch))
+        y = torch.zeros(len(scores), dtype=torch.long, device=scores.device)
+        torch.nn.CrossEntropyLoss(reduction=red)(scores, y).backward()
+        res[red] = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
+        assert all(np.isfinite(g).all() for g in res[red].values()), red
+    _, _, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads)
+    B = shape.batch_size
+    _grad_report(res["mean"], o_grads, synth.param_names(), "mean")
+    _grad_report({n: g / B for n, g in res["sum"].items()}, o_grads, synth.param_names(), "sum/B")
+    for n in synth.param_names():          # a power-of-two change of scale: the two runs carry the same fp16 values
+        np.testing.assert_array_equal(res["sum"][n], res["mean"][n] * np.float32(B), err_msg=n)
 
 
 def test_fp16_fused_train_steps_track_the_reference(golden_dir):

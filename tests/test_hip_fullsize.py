@@ -138,24 +138,141 @@ def test_padding_token_skip_equals_dense_path_at_full_size(full):
 
 
 def noise_only(name):
-    """Tensors whose fp16-mode gradient at these (freshly initialised) weights is rounding noise, DESIGN section 2: W_K.bias
-    is analytically zero, the additive biases are cancelling sums, and the user encoder's additive attention sees nearly
-    uniform pooling weights (its gradients are 1e-13: below what an fp16 forward leaves of them)."""
+    """Tensors whose gradient at these (freshly initialised) weights is decided by the last bits of the forward in EVERY
+    mode, DESIGN section 1: W_K.bias is analytically zero (softmax is invariant to a per-query constant), the additive
+    biases are cancelling sums (sum_s ds_s = 0), and the user encoder's additive attention sees nearly uniform pooling
+    weights, so ds = w (dw - sum w dw) cancels to 1e-4 of its terms (gradients of 1e-13 ... 1e-10 next to 1e-4 for the
+    projections).  Their conditioning, not the arithmetic of the user encoder, is the limit: with the user encoder in
+    bf16x3 (2^-16 per product) the fp16 news vectors it is FED (5e-4 relative) still move them by O(1), and so does a
+    5e-4 relative perturbation of the news vectors in the exact fp32 mode -- test_conditioning_of_the_exempted_gradients
+    measures exactly that, and test_fp16_gradients_after_training_steps checks them once training has made them real."""
     return (name.endswith("W_K.bias") or name.endswith("additive_attention.linear.bias")
             or name.startswith("user_encoder.additive_attention."))
+
+
+def test_conditioning_of_the_exempted_gradients(full):
+    """Why three user-encoder tensors are exempt from the fp16 gradient bar AT INITIALISATION: in the library's exact fp32
+    mode, perturb the user encoder's input (the news vectors) by 3e-4 relative -- what an fp16 news encoder does to them --
+    and its additive-attention gradients move by tens of percent, while the projection gradients move by ~1e-3.  The
+    limit is the conditioning of those sums at near-uniform pooling weights, not the arithmetic that evaluates them."""
+    import ctypes as C
+    from pytorch_news_recommender_amd import _lib
+    from tests.test_hip_parity import make_model
+    shape, _, batch, tb = full
+    model = make_model(shape, synth.make_params(shape, seed=0))
+    eng, flat, lay = model.engine, model._flat, model._layout
+    B, H, Cn, L, d = shape.batch_size, shape.history_len, shape.n_candidates, shape.n_words_title, shape.word_embed_size
+    ids = torch.cat([tb["browsed_titles"].reshape(B * H, L), tb["candidate_titles"].reshape(B * Cn, L)])
+    nv = eng.encode_titles(flat, ids, chunk_titles=1 << 20)
+    hist, cand = nv[:B * H].view(B, H, d).clone(), nv[B * H:].view(B, Cn, d).contiguous()
+    mask = tb["candidate_mask"].contiguous()
+
+    def user_grads(h_in):
+        user = eng.encode_users(flat, h_in, save=True)
+        scores = eng.click_scores(cand, user, mask)
+        _, ds = eng.ce_loss(scores, grad_scale=1.0 / B)
+        dcand, duser = torch.empty_like(cand), torch.empty(B, d, device=flat.device)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(eng.lib.nrms_click_score_bwd(B, Cn, d, _lib.ptr(cand), _lib.ptr(user), _lib.ptr(mask), _lib.ptr(ds), _lib.ptr(dcand),
+                                                _lib.ptr(duser), stream), "click_score_bwd")
+        g = torch.zeros_like(flat)
+        eng.encode_users_backward(flat, g, h_in, duser)
+        return g
+
+    g0 = user_grads(hist)
+    noise = torch.randn(hist.shape, generator=torch.Generator().manual_seed(11)).cuda()
+    g1 = user_grads((hist * (1.0 + 3e-4 * noise)).contiguous())
+    moved = {}
+    for name in lay.names:
+        if not name.startswith("user_encoder."):
+            continue
+        a, b = lay.view(g1, name).double(), lay.view(g0, name).double()
+        moved[name] = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+        print("   fp32 mode, input perturbed 3e-4: %-62s scale %.2e  moves by %.1e of scale" % (name, float(b.abs().max()), moved[name]))
+    for name, m in moved.items():
+        if name.startswith("user_encoder.additive_attention."):
+            assert m > 2e-2, (name, m)                    # ill-conditioned: no 5e-4-accurate forward can pin them
+        elif not name.endswith("W_K.bias"):
+            assert m < 4e-3, (name, m)                    # well-conditioned: these ARE held to the bar below
+
+
+def test_fp16_gradients_after_training_steps(full):
+    """Once training has moved the weights off the symmetric initialisation the exempted tensors are real numbers and are
+    held to the bar: 150 fp32 train steps on a fixed batch, then the CE gradients of a FRESH batch in the fp16 mode against
+    the exact fp32 mode -- all 19 tensors but the analytically zero W_K.bias, the user encoder's additive attention
+    included (measured: 9e-4 / 3e-3 / 1e-3 of their scale; with the user encoder in fp16 too they sit at 4e-3 / 1e-2 / 3e-3,
+    one more reason it runs in bf16x3)."""
+    from tests.test_hip_parity import make_model
+    shape, _, batch, tb = full
+    model = make_model(shape, synth.make_params(shape, seed=0))
+    model.config.learning_rate = 1e-3
+    for _ in range(150):
+        model.train_step(tb)
+    fresh = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(shape, seed=2).items()}
+    lay, flat = model._layout, model._flat
+    g = {}
+    try:
+        for prec in ("fp32", "fp16"):
+            model.config.precision = prec
+            eng = model.engine
+            _, dce = eng.ce_loss(_scores(model, fresh), grad_scale=1.0 / shape.batch_size)
+            g[prec] = torch.zeros_like(flat)
+            eng.backward(flat, g[prec], dce)
+    finally:
+        model.config.precision = "fp32"
+    for name in lay.names:
+        a, b = lay.view(g["fp16"], name).double(), lay.view(g["fp32"], name).double()
+        rel = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+        print("   trained 150 steps, fp16 vs fp32 grad %-62s scale %.2e  max err %.1e of scale" % (name, float(b.abs().max()), rel))
+        if name.endswith("W_K.bias"):
+            continue
+        # (the additive biases stay cancelling sums: twice the bar)
+        assert rel < (8e-3 if name.endswith("additive_attention.linear.bias") else 4e-3), (name, rel)
+
+
+def _fp16_vs_fp32(shape, tb, seed):
+    from tests.test_hip_parity import make_model
+    model = make_model(shape, synth.make_params(shape, seed=seed))
+    ref = _scores(model, tb, training=False).clone()
+    model.config.precision = "fp16"
+    assert model.engine.precision == "fp16" and not model.engine.fp16_user_encoder
+    s = _scores(model, tb, training=False)
+    valid = tb["candidate_mask"] == 1
+    e = (s - ref)[valid].abs().double()
+    return float((e * e).mean().sqrt()), float(torch.quantile(e, 0.999)), float(e.max()), float((ref[valid].double() ** 2).mean().sqrt())
+
+
+def test_fp16_scores_inside_the_bar_with_margin_on_three_seeds(full):
+    """north_star: click scores within 1e-4 of the reference.  The benchmarked mode (fp16 news encoder, bf16x3 user
+    encoder) against the library's exact fp32 mode -- itself within 1.5e-7 of the reference on fixture g2 -- over the 2 555
+    valid scores of a 512-user batch, three weight / batch seeds: the MAXIMUM must stay under 1e-4."""
+    shape, _, _, _ = full
+    worst = 0.0
+    for seed in (0, 7, 13):
+        batch = synth.make_batch(shape, seed=1 + seed, mask_some_candidates=True)
+        tb = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+        rms, p999, err, scale = _fp16_vs_fp32(shape, tb, seed)
+        print("full size fp16 vs fp32, seed %d: score rms %.3f  err rms %.2e  99.9 %% %.2e  max %.2e" % (seed, scale, rms, p999, err))
+        worst = max(worst, err)
+        assert 1e-7 < rms < 3e-5 and err < 1e-4
+    print("full size fp16 vs fp32: worst max over three seeds %.2e" % worst)
 
 
 def test_fp16_mode_properties_at_full_size(full):
     """The benchmarked mode at the benchmarked size: run-to-run determinism, user-permutation equivariance (a user's
     scores do not depend on its batch position: bit-exact), distance to the exact fp32 scores inside north_star's bar,
-    the backward linear in d(scores) (a factor 2 is exact in fp16 too), padding-row and untouched-row gradients zero,
-    and the compact path against the dense path."""
+    every gradient tensor against the fp32 mode's, the backward linear in d(scores) (a factor 2 is exact in fp16 too),
+    padding-row and untouched-row gradients zero, and the compact path against the dense path."""
     from tests.test_hip_parity import make_model
     shape, _, batch, tb = full
     model = make_model(shape, synth.make_params(shape, seed=0))      # fresh weights (the shared fixture has been trained on)
     eng, flat, lay = model.engine, model._flat, model._layout
     ref = _scores(model, tb, training=False).clone()
     valid = tb["candidate_mask"] == 1
+    # CE-shaped upstream gradient (what training feeds the backward), fp32 reference gradients
+    _, dce = eng.ce_loss(_scores(model, tb), grad_scale=1.0 / shape.batch_size)
+    g32 = torch.zeros_like(flat)
+    eng.backward(flat, g32, dce)
     try:
         model.config.precision = "fp16"
         eng = model.engine
@@ -166,9 +283,21 @@ def test_fp16_mode_properties_at_full_size(full):
         rms, p999, err = float((e * e).mean().sqrt()), float(torch.quantile(e, 0.999)), float(e.max())
         print("full size fp16 vs fp32 over %d scores of rms %.3f: rms %.2e, 99.9 %% %.2e, max %.2e" % (
             e.numel(), float((ref[valid].double() ** 2).mean().sqrt()), rms, p999, err))
-        # north_star's 1e-4 is asserted against the REFERENCE on fixture g2 (20 scores, max 4.4e-5); over 2 555 scores the
-        # same error distribution (rms 2.8e-5 = 5e-4 of the score scale: one fp16 rounding) has its maximum AT the bar
-        assert 1e-7 < rms < 4e-5 and p999 < 1e-4 and err < 1.5e-4
+        assert 1e-7 < rms < 3e-5 and err < 1e-4                      # north_star's bar, on every one of the 2 555 scores
+        # gradients of the CE loss against the fp32 mode, tensor by tensor, relative to each tensor's scale
+        g16 = torch.zeros_like(flat)
+        _scores(model, tb)
+        eng.backward(flat, g16, dce)
+        for name in lay.names:
+            a, b = lay.view(g16, name).double(), lay.view(g32, name).double()
+            scale = float(b.abs().max())
+            rel = float((a - b).abs().max()) / (scale + 1e-300)
+            rrms = float(((a - b) ** 2).mean().sqrt() / ((b ** 2).mean().sqrt() + 1e-300))
+            print("   fp16 vs fp32 grad %-62s scale %.2e  max err %.1e of scale  rel rms %.1e" % (name, scale, rel, rrms))
+            if noise_only(name):
+                continue
+            # the user encoder's tensors (bf16x3 kernels fed by fp16 news vectors) and the news encoder's (fp16 kernels)
+            assert rel < 4e-3, (name, rel)
         perm = torch.from_numpy(np.random.default_rng(4).permutation(shape.batch_size)).cuda()
         assert torch.equal(_scores(model, {k: v[perm] for k, v in tb.items()}), s1[perm])
         d1 = (torch.randn(s1.shape, generator=torch.Generator().manual_seed(5)) * 1e-3).cuda()
@@ -182,9 +311,9 @@ def test_fp16_mode_properties_at_full_size(full):
             if noise_only(name):
                 continue
             a, b = lay.view(grads[0], name), lay.view(grads[1], name)
-            # (a factor 2 is exact in fp16 except for values in the subnormal range -- the tokens with tiny pooling weights --
-            # which keep fewer bits than their doubles: the bound is the mode's gradient tolerance, GRAD_REL of test_hip_fp16)
-            assert float((2 * a - b).abs().max()) <= 4e-3 * float(a.abs().max()) + 1e-12, name
+            # the loss scale follows max |dout| (a power of two): doubling d(scores) halves it, every fp16 value is the same
+            # and the result is exactly twice the first one
+            assert torch.equal(2 * a, b), name
         emb = lay.view(grads[0], "news_encoder.word_embedding.0.weight")
         ids = torch.cat([tb["browsed_titles"].reshape(-1), tb["candidate_titles"].reshape(-1)])
         untouched = torch.ones(shape.n_words, dtype=torch.bool, device="cuda")

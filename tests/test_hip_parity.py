@@ -37,7 +37,7 @@ def assert_grad_close(got, ref, mode, name):
         name, mode, float(diff.max()), worst, float(np.abs(ref).max()))
 
 
-def make_model(shape, params, dropout=0.0, device="cuda", precision="fp32"):
+def make_model(shape, params, dropout=0.0, device="cuda", precision="fp32", fp16_user=False):
     from pytorch_news_recommender_amd.config import Config
     from pytorch_news_recommender_amd.model.nrms_hip import Model
     cfg = Config("nrms_hip")
@@ -47,6 +47,7 @@ def make_model(shape, params, dropout=0.0, device="cuda", precision="fp32"):
     cfg.query_vector_dim = shape.query_vector_dim
     cfg.dropout = dropout
     cfg.precision = precision
+    cfg.fp16_user_encoder = fp16_user          # precision "fp16" only: the user encoder in fp16 too (default: bf16x3)
     m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
     return m.to(device)
