@@ -575,6 +575,7 @@ def main():
             # the drop-in loop of train_eval.py:111-127: model(batch) -> CE -> loss.backward() -> torch.optim.Adam.step
             opt = torch.optim.Adam(model.parameters(), lr=1e-3)
             crit = torch.nn.CrossEntropyLoss()
+            model.reuse_grad_buffer = True           # as train_eval.train(use_autograd=True) sets it
 
             def ref_loop():
                 outp = model(batch)

@@ -592,7 +592,9 @@ struct Prep16bArgs {
     const float* q_vec;   // [q]
     float* bqkv32;        // [3h][32] (Q part pre-scaled)
     _Float16* btiles;     // [4h][32][KP]
-    _Float16* xtiles;     // dX GEMM: [2 halves][3 chunks][5][32 rows = input feature][KP cols = dqkv16 column within the chunk]
+    _Float16* xtiles;     // dX GEMM (gemm16_dx_kernel): [DX_SLABS][4 k-steps][10 n-tiles][lane half][32 n][8 k]: the operand
+                          // fragments of W' (rows = dqkv16 columns, 64 per slab; columns = input features) in the order a
+                          // wave reads them -- one contiguous KiB per (k-step, n-tile), filled by LDS-DMA
     _Float16* qv16;       // [QP]
 };
 
@@ -618,16 +620,15 @@ __global__ __launch_bounds__(256) void prep16b_kernel(Prep16bArgs a) {
             a.btiles[i] = (_Float16)v;
         } else if (i < n1 + n2) {
             const long j = i - n1;
-            const int c = (int)(j % KP);                        // column inside the 320-wide contraction chunk
-            const long r = j / KP;
-            const int krow = (int)(r & 31);
-            int tile = (int)(r >> 5);                           // ((half * 3) + chunk) * 5 + nt
-            const int nt = tile % 5; tile /= 5;
-            const int chunk = tile % 3, half = tile / 3;
-            const int k = (half * 5 + nt) * 32 + krow;          // input feature (output column of dX)
-            const int m = chunk * KP + c;                       // dqkv16 column
+            // position j = ((((slab * 4 + s) * 10 + t) * 2 + hh) * 32 + l) * 8 + e  ->  W'[m][n], m = 64 slab + 16 s + 8 hh + e, n = 32 t + l
+            const int e = (int)(j & 7), l = (int)((j >> 3) & 31), hh2 = (int)((j >> 8) & 1);
+            long r = j >> 9;
+            const int t = (int)(r % 10); r /= 10;
+            const int s4 = (int)(r & 3), slab = (int)(r >> 2);
+            const int m = 64 * slab + 16 * s4 + 8 * hh2 + e;     // dqkv16 column
+            const int k = 32 * t + l;                            // input feature (output column of dX)
             const int head = m / 96, rem = m - head * 96, which = rem >> 5, p = rem & 31;
-            const int s = p >> 4, t = p & 15, hh = t >> 3, jj = t & 7;
+            const int s = p >> 4, tt = p & 15, hh = tt >> 3, jj = tt & 7;
             const int f = 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);       // feature held at memory position p (acc_frag order)
             float v = 0.f;
             if (head < a.h && f < a.dk && k < a.d)
@@ -646,62 +647,121 @@ __global__ __launch_bounds__(256) void prep16b_kernel(Prep16bArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // dX[r][k] = inv_scale * sum_m dqkv16[r][m] W'[m][k]  for rows r < *n_rows (compact live rows) -- fp32 [rows][ldc].
-// One wave per 32 rows; two passes of 5 output tiles (80 accumulator registers) over 3 contraction chunks of 320.
+// A plain LDS-staged GEMM, sized by what bounds it: 0.56 GB of dQKV16 in + 0.35 GB of dX out against 180 GFLOP, i.e. HBM
+// (0.18 ms at 5 TB/s) well before the matrix pipe (0.08 ms).  256 rows x all 320 columns per workgroup, 8 waves as
+// 4 (rows) x 2 (columns): a wave owns 64 x 160 = 2 x 5 accumulator tiles, so one 64-deep slab costs it 40 MFMAs for 28 LDS
+// fragment reads.  Both operands reach LDS by LDS-DMA (no staging registers, no ds_write pass, no ordinary load in the loop --
+// hipcc drains the DMA queue in front of the first use of any ordinary load):
+//   A slab [256 rows][64 k] row-major, 128 B per row, filled in whole 128-B lines (8 rows per DMA instruction); the 16-byte
+//     pieces of a row are XOR-swizzled by (row >> 1) & 7 -- on the SOURCE address, the LDS image of a DMA is lane-linear -- so
+//     that the 16 lanes of a ds_read_b128 group (16 different rows, same logical piece) hit 16 different 16-byte slots;
+//   B slab: W' fragments in read order (prep16b), 1 contiguous KiB per (k-step, n-tile).
+// Two slots: slab i + 1 travels while slab i is consumed (32 KB of dQKV16 in flight per CU: what keeps HBM streaming).
+// The weight fragment is the MFMA's A operand and the data rows its B operand: the accumulator then holds four CONSECUTIVE
+// output columns of one row per register quad, stored as 16 bytes (a quarter of the store instructions of the row-in-registers
+// form).  (Round 2's kernel -- one wave per 32 rows, weights through a register-staged ring, A fragments straight from
+// global -- ran at 0.37 ms: every tile step exposed a global-load latency.)
+constexpr int DX_BM = 256, DX_BK = 64, DX_THREADS = 512;
+constexpr int DX_SLABS = B16_DQ / DX_BK;                    // 15
+constexpr int DX_A_BYTES = DX_BM * DX_BK * 2;               // 32 KB
+constexpr int DX_B_BYTES = DX_BK * F16_KP * 2;              // 40 KB
+constexpr int DX_SLOT = DX_A_BYTES + DX_B_BYTES;
+static_assert(B16_DQ % DX_BK == 0 && F16_KP == 320, "15 slabs of 64; 10 column tiles of 32");
 struct Dx16Args {
     int M;                    // upper bound of the rows (sizes the grid)
     const int* m_dev;         // rows actually present (device), or null
     const _Float16* a16;      // [rows][B16_DQ]
-    const _Float16* xtiles;   // [30][32][KP]
+    const _Float16* xtiles;   // [DX_SLABS][4][10][2][32][8]
     float* c;                 // [rows][ldc]
     int ldc, d;
     const float* sc;          // device: {loss scale, 1 / loss scale}
 };
 
-__global__ __launch_bounds__(F16_THREADS, 8 / F16_WAVES) void gemm16_dx_kernel(Dx16Args a) {
+__global__ __launch_bounds__(DX_THREADS, 2) void gemm16_dx_kernel(Dx16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
     const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
-    const int row0 = (blockIdx.x * F16_WAVES + wave) * 32;
-    if (blockIdx.x * F16_WAVES * 32 >= M) return;                       // whole workgroup beyond the rows (uniform)
+    const int row0 = blockIdx.x * DX_BM;
+    if (row0 >= M) return;                                              // whole workgroup beyond the rows (uniform)
     const float inv_scale = a.sc[1];
-    TileRing ring;
-    ring.smem = smem; ring.src = a.xtiles; ring.n_tiles = 30; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
-    ring.load(0); ring.store(0);
-    ring.load(1); ring.store(1);
-    const int arow = min(row0 + l32, M - 1);                           // clamped: rows past the end are computed, not stored
-    const _Float16* ar = a.a16 + (long)arow * B16_DQ + 8 * hh;
-    __syncthreads();
-    int n = 0;
+    // ---- this lane's share of the DMA fills.  A: piece p = wave + 8 i (i < 4) holds rows 8 p .. 8 p + 7; lane -> row 8 p + (lane >> 3),
+    // physical 16-byte slot lane & 7, which receives the logical piece (lane & 7) ^ ((row >> 1) & 7).  Rows past the end are clamped
+    // (computed, never stored).  B: piece q = wave + 8 i (i < 5), lane-linear.
+    const char* asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * (wave + 8 * i) + (lane >> 3);
+        const int piece = (lane & 7) ^ ((r >> 1) & 7);
+        asrc[i] = reinterpret_cast<const char*>(a.a16 + (long)min(row0 + r, M - 1) * B16_DQ) + piece * 16;
+    }
+    const char* bsrc = reinterpret_cast<const char*>(a.xtiles) + wave * 1024 + lane * 16;
+    auto issue = [&](int slab, int slot) {
+        char* la = smem + slot * DX_SLOT + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + slab * (DX_BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(la + i * 8192), 16, 0, 0);
+        char* lb = smem + slot * DX_SLOT + DX_A_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + (long)slab * DX_B_BYTES + i * 8192),
+                                             (__attribute__((address_space(3))) void*)(lb + i * 8192), 16, 0, 0);
+    };
+    // fragment addresses inside a slot: rows wm * 64 + 32 i + l32 of A; tiles wn * 5 + j of B
+    int aoff[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + 32 * i + l32;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) aoff[i][s] = r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
+    }
+    const int boff = DX_A_BYTES + (wn * 5 * 64 + lane) * 16;            // + (s * 10 + j) * 1024
+
+    f32x16 acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = zero16();
+    issue(0, 0);
+    __asm__ volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        f32x16 acc[5];
+    for (int slab = 0; slab < DX_SLABS; ++slab) {
+        if (slab + 1 < DX_SLABS) issue(slab + 1, (slab + 1) & 1);
+        const char* st = smem + (slab & 1) * DX_SLOT;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i] = zero16();
-#pragma unroll 1
-        for (int chunk = 0; chunk < 3; ++chunk) {
-            h8 af[F16_KS];
+        for (int s = 0; s < 4; ++s) {
+            const h8 a0 = *reinterpret_cast<const h8*>(st + aoff[0][s]);
+            const h8 a1 = *reinterpret_cast<const h8*>(st + aoff[1][s]);
 #pragma unroll
-            for (int s = 0; s < F16_KS; ++s) af[s] = *reinterpret_cast<const h8*>(ar + chunk * F16_KP + 16 * s);
-#pragma unroll
-            for (int nt = 0; nt < 5; ++nt) {
-                ring.load(n + 2);
-                tile_mma<false>(acc[nt], ring, n, af);                 // D[row][k] : rows in registers, k on lanes
-                ring.store(n + 2);
-                __syncthreads();
-                ++n;
+            for (int j = 0; j < 5; ++j) {
+                const h8 b = *reinterpret_cast<const h8*>(st + boff + (s * 10 + j) * 1024);
+                acc[0][j] = mfma32h(b, a0, acc[0][j]);               // D[n][row]: columns in registers, rows on lanes
+                acc[1][j] = mfma32h(b, a1, acc[1][j]);
             }
         }
+        // slab + 1 has landed (this wave's share: the counter; everybody's: the barrier) and nobody still reads this slot
+        __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) {
-            const int k = (half * 5 + nt) * 32 + l32;
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + wm * 64 + 32 * i + l32;
+        if (row >= M) continue;
+        float* crow = a.c + (long)row * a.ldc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + crow32(r, hh);
-                if (row < M && k < a.d) a.c[(long)row * a.ldc + k] = acc[nt][r] * inv_scale;
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int k = (wn * 5 + j) * 32 + 8 * g + 4 * hh;      // registers 4 g .. 4 g + 3 = columns k .. k + 3
+                if (k < a.d) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * inv_scale;
+                    *reinterpret_cast<f32x4*>(crow + k) = v;
+                }
             }
-        }
     }
 }
 
@@ -985,7 +1045,7 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
     L.n_wg = 512;
     L.btiles = take((size_t)40 * 32 * F16_KP * 2);
-    L.xtiles = take((size_t)30 * 32 * F16_KP * 2);
+    L.xtiles = take((size_t)DX_SLABS * DX_B_BYTES);          // = 30 * 32 * KP * 2: the dX weight slabs
     L.qv16 = take((size_t)F16_QP * 2);
     L.bqkv32 = take((size_t)30 * 32 * 4);
     L.dout16 = take((size_t)n_seq * F16_DP * 2);
@@ -1163,11 +1223,12 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         Dx16Args g{};
         g.M = (int)M; g.m_dev = f.n_rows_dev; g.a16 = dqkv16; g.xtiles = xtiles; g.c = f.dx; g.ldc = f.d; g.d = f.d;
         g.sc = sc;
-        const size_t lds = (size_t)3 * F16_SLOT;
+        if ((f.d & 3) != 0 || ((uintptr_t)f.dx & 15) != 0) { set_error("gemm16_dx: dx must be 16-byte aligned, d %% 4 == 0"); return NRMS_EINVAL; }
+        const size_t lds = (size_t)2 * DX_SLOT;
         const hipError_t e = hipFuncSetAttribute((const void*)gemm16_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("gemm16_dx: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
         TimingScope ts("dx_bwd", stream);
-        hipLaunchKernelGGL(gemm16_dx_kernel, dim3(cdiv(M, 32 * F16_WAVES)), dim3(F16_THREADS), lds, stream, g);
+        hipLaunchKernelGGL(gemm16_dx_kernel, dim3(cdiv(M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
         rc = check_launch("gemm16_dx");
     }
     if (side && rc == NRMS_OK) {                                    // join: the caller's stream continues after both GEMMs

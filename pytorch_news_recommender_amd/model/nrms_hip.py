@@ -99,15 +99,16 @@ class _NRMSFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dscores):
         model = ctx.model
-        # ONE persistent flat gradient buffer (57.6 MB at V = 45 800) in the reference's loop, where
-        # model.zero_grad() has set every .grad to None (train_eval.py:115): autograd then adopts the returned views
-        # as .grad, and the next backward may reuse the buffer.  When gradients are being accumulated (.grad still
-        # set, possibly aliasing the buffer) a fresh buffer is used so that nothing autograd holds is overwritten.
-        accumulating = any(p.grad is not None for p in model.parameters())
-        gflat = None if accumulating else model._autograd_grad
+        # Default: a fresh flat gradient buffer per backward -- autograd adopts the returned views as .grad, and a tensor
+        # the caller kept from an earlier step (a saved p.grad, a hook's argument) must keep its values, as torch guarantees.
+        # model.reuse_grad_buffer = True (set by train_eval.train for the reference's loop, which zeroes the gradients
+        # before every backward, train_eval.py:115, and keeps nothing) opts into ONE persistent 57.6 MB buffer instead;
+        # even then a fresh buffer is used while gradients are being accumulated (.grad still set).
+        reuse = bool(getattr(model, "reuse_grad_buffer", False)) and not any(p.grad is not None for p in model.parameters())
+        gflat = model._autograd_grad if reuse else None
         if gflat is None or gflat.shape != model._flat.shape or gflat.device != model._flat.device:
             gflat = torch.empty_like(model._flat)
-            if not accumulating:
+            if reuse:
                 model._autograd_grad = gflat
         gflat.zero_()
         model._engine.backward(model._flat, gflat, dscores, gen=ctx.gen)
@@ -138,6 +139,7 @@ class Model(nn.Module):
         self._opt = None
         self._calls = 0
         self._autograd_grad = None
+        self.reuse_grad_buffer = False      # autograd path: see _NRMSFunction.backward
         self._flatten(table.device)
         # a load through ANY parent (the dispatch wrapper of model/__init__.py included) may change the embedding
         # table: nn.Module.load_state_dict recurses via _load_from_state_dict and never calls a child's

@@ -73,11 +73,12 @@ class _NamlFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dscores):
         model = ctx.model
-        accumulating = any(p.grad is not None for p in model.parameters())
-        gflat = None if accumulating else model._autograd_grad
+        # fresh buffer per backward unless the caller opted into reuse (model.reuse_grad_buffer: nrms_hip._NRMSFunction)
+        reuse = bool(getattr(model, "reuse_grad_buffer", False)) and not any(p.grad is not None for p in model.parameters())
+        gflat = model._autograd_grad if reuse else None
         if gflat is None or gflat.shape != model._flat.shape or gflat.device != model._flat.device:
             gflat = torch.empty_like(model._flat)
-            if not accumulating:
+            if reuse:
                 model._autograd_grad = gflat
         gflat.zero_()
         model._engine.backward(model._flat, gflat, dscores, gen=ctx.gen)

@@ -116,6 +116,10 @@ def train(config, model, train_iter, dev_iter=None, dev_labels=None, use_autogra
     if use_autograd:
         optimizer = torch.optim.Adam(model.parameters(), lr=config.learning_rate)
         criterion = nn.CrossEntropyLoss()
+        # this loop zeroes the gradients before every backward and keeps no reference to an old .grad: the backward may
+        # hand autograd views of ONE persistent flat buffer instead of 57.6 MB of fresh memory per step (opt-in contract,
+        # model/nrms_hip.py _NRMSFunction.backward)
+        net.reuse_grad_buffer = True
     total_batch, AUC_best, STEP_SIZE = 0, 0.56, 100          # train_eval.py:59,61
     hist = dict(losses=[], aucs=[], ckpts=[], warmup_losses=[])
     window = []
@@ -164,7 +168,10 @@ def train(config, model, train_iter, dev_iter=None, dev_labels=None, use_autogra
                 window.append(loss_sum / B)
             if total_batch % STEP_SIZE == 0:                 # one host sync per 100 iterations, not two per step
                 vals = [float(v) for v in window]
-                net.engine.check_ids()                       # out-of-range word ids of the last 100 steps surface here
+                # out-of-range word ids surface here: after the very first batch (total_batch == 0: a vocabulary / table
+                # mismatch is caught before a second update is applied, where nn.Embedding would have raised) and then
+                # every 100 steps
+                net.engine.check_ids()
                 hist['losses'].extend(vals)
                 window = []
                 if verbose:
@@ -231,7 +238,13 @@ def test(config, model, data_iter, test_list_nums=None, ckpt_file=None, out_file
     net = _inner(model)
     if ckpt_file is None and pick_best:
         ckpt_file = best_checkpoint(config)
+        if ckpt_file is None:
+            # the reference fails here too (it loads './save_model/' + None, train_eval.py:309): scoring whatever weights
+            # the model happens to hold and writing a submission from them would be a silent wrong answer
+            raise FileNotFoundError("test(pick_best=True): no checkpoint of model %r with a dev AUC above 0.5 in %r"
+                                    % (config.model_name, config.save_path))
     if ckpt_file is not None:
+        print('loading checkpoint:', os.path.join(config.save_path, ckpt_file))
         model.load_state_dict(torch.load(os.path.join(config.save_path, ckpt_file), weights_only=True))
     if test_list_nums is None:
         from .data_handler import get_Test_List

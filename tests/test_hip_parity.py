@@ -488,3 +488,64 @@ def test_second_training_forward_invalidates_the_first_backward():
     with pytest.raises(NrmsError, match="replaced"):
         s1.sum().backward()
     s2.sum().backward()                                           # the latest forward still backpropagates
+
+
+def test_a_retained_grad_tensor_keeps_its_values():
+    """torch guarantees that a tensor the caller kept from an earlier backward (a saved p.grad, a hook's argument) is not
+    overwritten by a later one.  The autograd path therefore hands out a fresh flat gradient buffer per backward unless
+    the caller opted into reuse (model.reuse_grad_buffer, set by train_eval.train for the reference's loop)."""
+    shape = synth.G1_ODD
+    params = synth.make_params(shape, seed=11)
+    model = make_model(shape, params).train()
+    name = "news_encoder.multihead_self_attention.W_V.weight"
+    p = dict(model.named_parameters())[name]
+    _, _, g1 = fwd_bwd(model, synth.make_batch(shape, seed=12, ragged=True))
+    kept = p.grad                                   # no clone: the very tensor autograd installed
+    model.zero_grad(set_to_none=True)
+    _, _, g2 = fwd_bwd(model, synth.make_batch(shape, seed=13, ragged=True))
+    assert not np.array_equal(g1[name], g2[name])
+    np.testing.assert_array_equal(kept.cpu().numpy(), g1[name])
+    # opt-in reuse: the same storage serves every backward (what the reference-shaped training loop wants)
+    model.reuse_grad_buffer = True
+    model.zero_grad(set_to_none=True)
+    fwd_bwd(model, synth.make_batch(shape, seed=12, ragged=True))
+    ptr = p.grad.data_ptr()
+    model.zero_grad(set_to_none=True)
+    fwd_bwd(model, synth.make_batch(shape, seed=13, ragged=True))
+    assert p.grad.data_ptr() == ptr
+
+
+def test_two_engines_on_two_streams_in_one_process():
+    """Helper streams are per caller stream (capi.hip side_streams_for): two models trained from two host threads on two HIP
+    streams of one process, their backwards in flight at the same time, give exactly the gradients each gives alone."""
+    import threading
+    shape = synth.Shape(n_words=3000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=16, history_len=50, n_candidates=5, n_words_title=30)
+    jobs = []
+    for i, prec in enumerate(("fp16", "bf16x3")):
+        params = synth.make_params(shape, seed=70 + i)
+        batch = synth.make_batch(shape, seed=80 + i, ragged=True, min_title=1)
+        model = make_model(shape, params, precision=prec).train()
+        alone = fwd_bwd(model, batch)
+        jobs.append(dict(model=model, batch=batch, alone=alone, stream=torch.cuda.Stream(), out=None, err=None))
+    torch.cuda.synchronize()
+
+    def run(job):
+        try:
+            with torch.cuda.stream(job["stream"]):
+                for _ in range(4):                  # several steps each, so that the two threads really overlap
+                    job["out"] = fwd_bwd(job["model"], job["batch"])
+            job["stream"].synchronize()
+        except Exception as e:                      # surfaced below
+            job["err"] = e
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for j in jobs:
+        assert j["err"] is None, j["err"]
+        np.testing.assert_array_equal(j["out"][0], j["alone"][0])
+        for n in j["alone"][2]:
+            np.testing.assert_array_equal(j["out"][2][n], j["alone"][2][n], err_msg=n)

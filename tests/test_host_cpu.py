@@ -485,3 +485,18 @@ def test_device_feed_yields_the_batches_of_the_reference_shaped_loader():
     b0 = next(iter(DeviceFeed(cfg2, samples, type=0, id2title_dict=corpus.id2title_dict, id2abst_dict=corpus.id2abst_dict,
                               batch_size=8, device="cpu")))
     assert int(b0["browsed_categ_ids"].max()) >= 1 and b0["browsed_absts"].shape == (8, cfg2.history_len, cfg2.n_words_abst)
+
+
+def test_test_with_pick_best_raises_when_there_is_no_checkpoint(tmp_path):
+    """train_eval.test(pick_best=True) with nothing to load must fail loudly (the reference fails on './save_model/' + None,
+    train_eval.py:309) instead of scoring whatever weights the model holds and writing a submission file."""
+    from pytorch_news_recommender_amd import train_eval
+    from pytorch_news_recommender_amd.config import Config
+    cfg = Config("nrms_hip")
+    cfg.save_path = str(tmp_path / "save_model") + "/"
+    with pytest.raises(FileNotFoundError, match="no checkpoint"):
+        train_eval.test(cfg, model=None, data_iter=[], pick_best=True)
+    os.makedirs(cfg.save_path)
+    open(os.path.join(cfg.save_path, "T01-01_00.00_nrms_hip_epoch5_iter_10_auc_0.412.ckpt"), "w").close()   # below 0.5: not a candidate
+    with pytest.raises(FileNotFoundError, match="no checkpoint"):
+        train_eval.test(cfg, model=None, data_iter=[], pick_best=True)
