@@ -227,7 +227,7 @@ static Fwd16Scratch fwd16_scratch(const nrms_encoder_desc* d) {
     f.n_live = f.pos + (gather ? align_up(M * sizeof(int), 256) : 0);
     f.cscr = f.n_live + (gather ? 256 : 0);
     f.order = f.cscr + (gather ? align_up(compact_scratch_ints((long)M) * sizeof(int), 256) : 0);
-    f.order_cnt = f.order + (gather ? align_up((size_t)2 * d->n_seq * sizeof(int), 256) : 0);
+    f.order_cnt = f.order + (gather ? align_up((size_t)3 * d->n_seq * sizeof(int), 256) : 0);
     f.total = f.order_cnt + (gather ? align_up(title_order_cnt_ints(d->n_seq) * sizeof(int), 256) : 0);
     return f;
 }
@@ -262,7 +262,7 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
             f.ids = ids;
             int* order = (int*)(base + fs.order);
             int* order_cnt = (int*)(base + fs.order_cnt);
-            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s);
+            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s, 3);
             if (rc) return rc;
             f.order = order; f.order_cnt = order_cnt;
         } else {

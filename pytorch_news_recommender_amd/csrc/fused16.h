@@ -136,6 +136,21 @@ struct TileRingDMA {
         if (g == 1) { load_piece(n, 2); load_piece(n, 3); }
         if (g == 2) load_piece(n, 4);
     }
+    // The same with the LDS slot chosen by the STEP and the source by the TILE: a kernel whose tile sequence revisits tiles
+    // (fused_fwd16p: the additive tiles once per title of the wave) walks steps 0, 1, 2, ... and names the tile of each.
+    __device__ __forceinline__ void load_at(int step, int tile) {
+        const char* g = reinterpret_cast<const char*>(src) + (long)tile * F16_SLOT_DMA + wave * 1024 + lane * 16;
+        char* l = smem + (step % SLOTS) * F16_SLOT_DMA + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + i * (F16_WAVES * 1024)),
+                                             (__attribute__((address_space(3))) void*)(l + i * (F16_WAVES * 1024)), 16, 0, 0);
+    }
+    __device__ __forceinline__ void load_piece_at(int step, int tile, int i) {
+        const char* g = reinterpret_cast<const char*>(src) + (long)tile * F16_SLOT_DMA + wave * 1024 + lane * 16 + i * (F16_WAVES * 1024);
+        char* l = smem + (step % SLOTS) * F16_SLOT_DMA + wave * 1024 + i * (F16_WAVES * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    }
     __device__ __forceinline__ void store(int) {}
     // end of the step that consumed tile n: tile n + 1 is complete in LDS for every wave after this.  `younger` = vector
     // memory instructions this wave issued in this step AFTER the five pieces of tile n + 2 (stores of the step's results):

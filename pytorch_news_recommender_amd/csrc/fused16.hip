@@ -345,6 +345,285 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? F16_FWD_WGS : 1) void fused_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The news encoder's forward on the padding-skipping path (NRMS_FLAG_PAD_ROW_ZERO: pos / ids / a 3-class order list):
+// the same products as fused_fwd16_kernel<., 1>, with the 32-row tile of the ATTENTION stage used twice as well.
+//
+// A padding token's Q | K | V row is the bias, the same for every padding token of a title, so in the attention stage the
+// L - n padding tokens of a title with n real tokens collapse exactly: as keys into ONE key whose logit gains log(L - n),
+// as queries into one row whose context they all share.  A "short" title (its n <= 15 real tokens a prefix) therefore needs
+// n + 1 <= 16 rows, and TWO short titles share one tile: rows 0..15 title A, rows 16..31 title B, with the cross-title entries
+// of S^T masked.  Per pair the 30 head tiles cost what they cost one title before (66 MFMAs per head, one softmax); a MIND
+// title is ~11 words, the bench's are 5..19: three quarters of the titles pair up.  The additive stage is per token -- the
+// context dropout draws a different mask for each of the L tokens, padding or not -- so each title expands back to its L rows
+// (lane t of title p pulls column 16 p + min(t, n_p) of the context with ds_bpermute), goes through the dropout, the ctx16
+// store and the seven additive tiles exactly as before; a pair walks the additive tiles twice.
+//   workgroups [0, g_pair): 8 short titles (2 per wave) | [g_pair, +g_long): 4 long titles | then 4 all-padding titles
+// The softmax mask is an additive per-register bias (0 / log multiplicity / -3e38) prepared once per title: one add per
+// element instead of the compare + select pair of the general kernel.
+template <bool TRAIN>
+__global__ __launch_bounds__(F16_THREADS, F16_FWD_WGS) void fused_fwd16p_kernel(Fwd16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int S = a.S;
+    constexpr int KP = F16_KP, DP = F16_DP;
+    const int n_head_tiles = 3 * a.h;
+    constexpr float NEG = -3.0e38f;
+
+    // ---- which titles this wave owns
+    const int n_long = a.order_cnt[0], n_e = a.order_cnt[1], n_short = a.order_cnt[2];
+    const int g_pair = (n_short + 2 * F16_WAVES - 1) / (2 * F16_WAVES);
+    const int g_long = (n_long + F16_WAVES - 1) / F16_WAVES, g_e = (n_e + F16_WAVES - 1) / F16_WAVES;
+    const int blk = blockIdx.x;
+    if (blk >= g_pair + g_long + g_e) return;                       // surplus workgroup (the grid is an upper bound)
+    const bool pair = blk < g_pair, skip_heads = blk >= g_pair + g_long;      // uniform over the workgroup
+    const int NT = pair ? 2 : 1;                                    // titles per wave
+    int seq[2] = {0, 0};
+    bool val[2] = {false, false};
+    if (pair) {
+        const int p0 = 2 * (blk * F16_WAVES + wave);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { val[i] = p0 + i < n_short; seq[i] = val[i] ? a.order[2 * (long)a.n_seq + p0 + i] : 0; }
+    } else if (!skip_heads) {
+        const int sl = (blk - g_pair) * F16_WAVES + wave;
+        val[0] = sl < n_long; seq[0] = val[0] ? a.order[sl] : 0;
+    } else {
+        const int sl = (blk - g_pair - g_long) * F16_WAVES + wave;
+        val[0] = sl < n_e; seq[0] = val[0] ? a.order[(long)a.n_seq + sl] : 0;
+    }
+    long tok0[2];
+    int nlive[2];                                                   // real tokens of a short title (a prefix by classification)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        tok0[i] = (long)seq[i] * S;
+        nlive[i] = 0;
+        if (pair && val[i]) nlive[i] = __popcll(__ballot(lane < S && a.ids[tok0[i] + lane] != 0));
+    }
+
+    // ---- the tile's rows: (title, token) of row l32, its x16 row, and the softmax bias of the key rows this lane holds
+    const int myp = pair ? (l32 >> 4) : 0, myr = pair ? (l32 & 15) : l32;
+    const int myn = myp ? nlive[1] : nlive[0];
+    const bool myval = myp ? val[1] : val[0];
+    long xrow = -1;                                                 // -1: a row of zeros (rows the tile does not use)
+    if (!skip_heads && myval) {
+        const long t0 = myp ? tok0[1] : tok0[0];
+        if (pair) {
+            if (myr < myn) xrow = a.pos[t0 + myr];                  // a real token (pos >= 0 by classification)
+            else if (myr == myn && myn < S) xrow = *a.n_rows;       // the title's padding tokens, all in this one row
+        } else if (myr < S) {
+            xrow = a.pos[t0 + myr];
+            if (xrow < 0) xrow = *a.n_rows;                         // a padding token inside a long title: x16's padding row
+        }
+    }
+    f32x16 kbias;                                                   // per key row j = crow32(r, hh), for this lane's query column l32
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = crow32(r, hh);
+        float bsv;
+        if (pair) {
+            const int jr = j & 15;
+            const float lm = __logf((float)max(S - myn, 1));
+            bsv = (j >> 4) != myp ? NEG : (jr < myn ? 0.f : ((jr == myn && myn < S) ? lm : NEG));
+        } else {
+            bsv = j < S ? 0.f : NEG;
+        }
+        kbias[r] = bsv;
+    }
+    // expansion: token l32 of title i reads the context column of its row (all padding tokens: the shared row)
+    int src_lane[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) src_lane[i] = 4 * (16 * i + min(l32, nlive[i]) + 32 * hh);
+    bool tok_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) tok_ok[i] = val[i] && l32 < S;
+
+    // ---- tile steps: the 3 h head tiles (not for all-padding titles), then the 7 additive tiles once per title
+    const int n_head_steps = skip_heads ? 0 : n_head_tiles;
+    const int n_steps = n_head_steps + F16_QT * NT;
+    auto tile_at = [&](int step) { return step < n_head_steps ? step : n_head_tiles + (step - n_head_steps) % F16_QT; };
+    using Ring = TileRingDMA<F16_FWD_SLOTS>;
+    constexpr int AH = Ring::AHEAD;
+    Ring ring;
+    ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_steps; ring.wave = wave; ring.lane = lane; ring.l32 = l32; ring.hh = hh;
+#pragma unroll
+    for (int i = 0; i < AH; ++i) ring.load_at(i, tile_at(i));       // (n_steps >= 7 > AH)
+
+    h8 xf[F16_KS];
+    {
+        const _Float16* xr = a.x16 + (xrow < 0 ? 0 : xrow) * KP + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < F16_KS; ++s) xf[s] = *reinterpret_cast<const h8*>(xr + 16 * s);
+        if (xrow < 0) {
+#pragma unroll
+            for (int s = 0; s < F16_KS; ++s) xf[s] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): see fused_fwd16_kernel
+    __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const bool any_live = val[0] || val[1];                         // this wave has work in the head tiles
+    int n = 0;
+#pragma unroll 1
+    for (int head = 0; head < a.h; ++head) {
+        f32x16 ct;                                                  // ctx^T[f][tile column] of this head
+        if (!skip_heads) {
+            f32x16 qt = zero16(), kt = zero16(), vv = zero16();
+            auto pre = [&](int g) { if (n + AH < n_steps) ring.load_piece_at(n + AH, tile_at(n + AH), g); };
+            if (!any_live && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
+            if (any_live) tile_mma<true>(qt, ring, n, xf, pre);
+            ring.step_barrier(n);
+            ++n;
+            if (!any_live && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
+            if (any_live) tile_mma<true>(kt, ring, n, xf, pre);
+            ring.step_barrier(n);
+            ++n;
+            if (!any_live && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
+            if (any_live) tile_mma<false>(vv, ring, n, xf, pre);
+            if (any_live) {
+                // S^T[j][i] (rows j = keys in registers, columns i = queries), masked / weighted by the additive bias
+                f32x16 st = mfma32h(acc_frag(kt, 0), acc_frag(qt, 0), zero16());
+                st = mfma32h(acc_frag(kt, 1), acc_frag(qt, 1), st);
+                float m = NEG;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] += kbias[r]; m = fmaxf(m, st[r]); }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] - m); sum += st[r]; }
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] *= inv;
+                ct = mfma32h(acc_frag(vv, 0), acc_frag(st, 0), zero16());
+                ct = mfma32h(acc_frag(vv, 1), acc_frag(st, 1), ct);
+            } else {
+                ct = zero16();
+            }
+        } else {
+            ct = rows_of(a.bqkv32 + (3 * head + 2) * 32, hh);       // all-padding title: ctx = b_v
+        }
+        // ---- per title: its L rows of the context, dropout, ctx16
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i < NT) {
+                f32x16 cx = ct;
+                if (pair) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        cx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane[i], __float_as_int(ct[r])));
+                }
+                if (a.drop.thresh != 0u) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const uint64_t e0 = (uint64_t)(tok0[i] + l32) * (uint64_t)DP + (uint64_t)(head * 32 + 16 * c + 8 * hh);
+                        float sc[8];
+                        dropout_scale8(a.drop.seed, 1u, e0 >> 3, a.drop.thresh16, a.drop.inv_keep, sc);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cx[8 * c + e] *= sc[e];
+                    }
+                }
+                if (val[i]) {                                       // rows beyond the sequence are stored too: zeros
+                    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    _Float16* dst = a.ctx16 + frag_off((long)seq[i], F16_CS, 2 * head, l32, hh);
+                    *reinterpret_cast<h8*>(dst) = tok_ok[i] ? acc_frag(cx, 0) : z;
+                    *reinterpret_cast<h8*>(dst + 512) = tok_ok[i] ? acc_frag(cx, 1) : z;
+                }
+            }
+        }
+        if (!skip_heads) {
+            ring.step_barrier(n);
+            ++n;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i < NT && val[i]) {                                     // heads the model does not have: zero columns
+            for (int head = a.h; head < F16_CS / 2; ++head) {
+                _Float16* dst = a.ctx16 + frag_off((long)seq[i], F16_CS, 2 * head, l32, hh);
+                *reinterpret_cast<h8*>(dst) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<h8*>(dst + 512) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    }
+
+    // ---- additive attention + pooling, one title after the other (see fused_fwd16_kernel for the commentary)
+#pragma unroll 1
+    for (int i = 0; i < NT; ++i) {
+        const bool valid = i ? val[1] : val[0];
+        const bool tok = i ? tok_ok[1] : tok_ok[0];
+        const int sq = i ? seq[1] : seq[0];
+        const long t0 = i ? tok0[1] : tok0[0];
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's ctx16 stores have landed
+        h8 cf[F16_CS];
+        {
+            const _Float16* src = a.ctx16 + frag_off((long)sq, F16_CS, 0, l32, hh);
+#pragma unroll
+            for (int s = 0; s < F16_CS; ++s) cf[s] = *reinterpret_cast<const h8*>(src + 512 * s);
+        }
+        float score = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < F16_QT; ++t) {
+            const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
+            __builtin_amdgcn_sched_barrier(0);
+            auto pre2 = [&](int g) { if (n + AH < n_steps) ring.load_piece_at(n + AH, tile_at(n + AH), g); };
+            if (!valid && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
+            f32x16 tt = zero16();
+            if (valid) tile_mma<true>(tt, ring, n, cf, pre2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 th;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ex = __builtin_amdgcn_exp2f(fmaf(tt[4 * g + e], 2.885390082f, ba[4 * g + e]));
+                    const float v = fmaf(-2.0f, __builtin_amdgcn_rcpf(ex + 1.0f), 1.0f);
+                    score += qq[4 * g + e] * v;
+                    th[e] = (_Float16)v;
+                }
+                if (TRAIN && valid) {
+                    if (!tok) th = h4{0, 0, 0, 0};
+                    *reinterpret_cast<h4*>(a.t16 + (((long)sq * (F16_QP / 16) + 2 * t + (g >> 1)) * 32 + l32) * 16 + 8 * (g & 1) + 4 * hh) = th;
+                }
+            }
+            ring.step_barrier(n);
+            ++n;
+        }
+        score += __shfl_xor(score, 32, 64);
+        score = l32 < S ? score : NEG;
+        float mx = score;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float wgt = l32 < S ? __expf(score - mx) : 0.f;
+        float es = wgt;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) es += __shfl_xor(es, o, 64);
+        wgt /= es;
+        if (TRAIN && a.w != nullptr && tok && hh == 0) a.w[t0 + l32] = wgt;
+        if (valid) {
+            h8 sel[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sel[s2][j] = (_Float16)(l32 == 16 * s2 + 8 * hh + j ? 1.0f : 0.0f);
+            float wrow[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wrow[r] = __shfl(wgt, crow32(r, hh), 64);
+#pragma unroll
+            for (int p = 0; p < F16_CS / 2; ++p) {
+                f32x16 dd = mfma32h(cf[2 * p], sel[0], zero16());
+                dd = mfma32h(cf[2 * p + 1], sel[1], dd);
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc += wrow[r] * dd[r];
+                acc += __shfl_xor(acc, 32, 64);
+                const int nn = l32, f = 16 * (nn >> 4) + 8 * ((nn & 7) >> 2) + 4 * ((nn >> 3) & 1) + (nn & 3);
+                if (hh == 0 && f < a.dk && p < a.h) a.out[(long)sq * a.d + p * a.dk + f] = acc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // weight planes of one encoder (a few hundred KB): one launch per call
 struct Prep16Args {
     int d, h, dk, q, KP, DP, QP;
@@ -399,16 +678,20 @@ __global__ __launch_bounds__(256) void prep16_kernel(Prep16Args a) {
     }
 }
 
-// order[0][..] = titles with at least one non-padding token, order[1][..] = all-padding titles, BOTH IN ASCENDING TITLE ORDER
-// (a stable partition: which workgroup sums which titles' bias gradients -- and therefore the last bits of those sums -- must
-// not depend on how a race between workgroups resolves); cnt[0..1] = their sizes, cnt[2 + 2 b ..] = the two counts of block b.
+// Title lists, each IN ASCENDING TITLE ORDER (a stable partition: which workgroup sums which titles' bias gradients -- and
+// therefore the last bits of those sums -- must not depend on how a race between workgroups resolves):
+//   NCLS = 2:  order[0][..] = titles with at least one non-padding token, order[1][..] = all-padding titles;
+//   NCLS = 3:  order[0][..] = "long" titles, order[1][..] = all-padding titles, order[2][..] = "short" titles: the non-padding
+//              tokens are a PREFIX of 1 .. 15 tokens, so that with one row for all its padding tokens the title fits 16 rows
+//              and two of them share one 32-row tile (fused_fwd16p_kernel).
+// cnt[0 .. NCLS) = the list sizes, cnt[NCLS + NCLS b + c] = the count of class c in block b (256 titles).
 // 256 titles per workgroup (64 per wave): the id loads of 16 titles are issued together (one dependent load per title made
 // the kernel a 16-long latency chain).  Pass 1 (PLACE = false) writes the per-block counts, pass 2 recomputes the flags (the
 // ids are 6.7 MB: cheaper than a flag array round trip), sums the counts of the blocks before it and places its titles.
-template <bool PLACE>
+template <int NCLS, bool PLACE>
 __global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, const int64_t* ids, int* order, int* cnt) {
     __shared__ int flag[256];
-    __shared__ int wcount[4][2], base[2], part[4][2];
+    __shared__ int wcount[4][NCLS], base[NCLS], part[4][NCLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t0 = blockIdx.x * 256;
 #pragma unroll 1
@@ -422,33 +705,48 @@ __global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, cons
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int t = t0 + wave * 64 + r * 16 + i;
-            const bool empty = __ballot(lane < S && v[i] != 0) == 0ull;
-            if (lane == 0) flag[wave * 64 + r * 16 + i] = t < n_seq ? (empty ? 1 : 0) : -1;
+            const unsigned long long livemask = __ballot(lane < S && v[i] != 0);
+            int cls = livemask == 0ull ? 1 : 0;
+            if (NCLS == 3 && livemask != 0ull) {
+                const int n = __popcll(livemask);
+                if (n <= 15 && livemask == (1ull << n) - 1ull) cls = 2;
+            }
+            if (lane == 0) flag[wave * 64 + r * 16 + i] = t < n_seq ? cls : -1;
         }
     }
     __syncthreads();
     const int f = flag[threadIdx.x];
-    const unsigned long long m_ne = __ballot(f == 0), m_e = __ballot(f == 1);
     const unsigned long long below = (1ull << lane) - 1ull;
-    int rank = f == 0 ? __popcll(m_ne & below) : __popcll(m_e & below);
-    if (lane == 0) { wcount[wave][0] = __popcll(m_ne); wcount[wave][1] = __popcll(m_e); }
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+        const unsigned long long m = __ballot(f == c);
+        if (f == c) rank = __popcll(m & below);
+        if (lane == 0) wcount[wave][c] = __popcll(m);
+    }
     if (PLACE) {
         // counts of the blocks before this one (and, in the last block, of all blocks: the totals)
-        int s0 = 0, s1 = 0;
-        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) { s0 += cnt[2 + 2 * b]; s1 += cnt[3 + 2 * b]; }
+        int s[NCLS];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
-        if (lane == 0) { part[wave][0] = s0; part[wave][1] = s1; }
+        for (int c = 0; c < NCLS; ++c) s[c] = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256)
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) s[c] += cnt[NCLS + NCLS * b + c];
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s[c] += __shfl_xor(s[c], o, 64);
+            if (lane == 0) part[wave][c] = s[c];
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int c0 = wcount[0][0] + wcount[1][0] + wcount[2][0] + wcount[3][0];
-        const int c1 = wcount[0][1] + wcount[1][1] + wcount[2][1] + wcount[3][1];
-        if (!PLACE) { cnt[2 + 2 * blockIdx.x] = c0; cnt[3 + 2 * blockIdx.x] = c1; }
+    if (threadIdx.x < NCLS) {
+        const int c = threadIdx.x;
+        const int mine = wcount[0][c] + wcount[1][c] + wcount[2][c] + wcount[3][c];
+        if (!PLACE) cnt[NCLS + NCLS * blockIdx.x + c] = mine;
         else {
-            base[0] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-            base[1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
-            if (blockIdx.x == gridDim.x - 1) { cnt[0] = base[0] + c0; cnt[1] = base[1] + c1; }
+            base[c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+            if (blockIdx.x == gridDim.x - 1) cnt[c] = base[c] + mine;
         }
     }
     if (!PLACE) return;
@@ -459,13 +757,20 @@ __global__ __launch_bounds__(256) void title_order_kernel(int n_seq, int S, cons
     }
 }
 
-size_t title_order_cnt_ints(int n_seq) { return 2 + 2 * (size_t)cdiv(n_seq > 0 ? n_seq : 1, 256); }
+size_t title_order_cnt_ints(int n_seq) { return 3 + 3 * (size_t)cdiv(n_seq > 0 ? n_seq : 1, 256); }
 
-int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream) {
+// n_classes = 2 (order [2][n_seq]) or 3 (order [3][n_seq])
+int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream, int n_classes) {
     if (n_seq <= 0) return NRMS_OK;
     TimingScope ts("title_order", stream);
-    hipLaunchKernelGGL(title_order_kernel<false>, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
-    hipLaunchKernelGGL(title_order_kernel<true>, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+    const dim3 grid(cdiv(n_seq, 256));
+    if (n_classes == 3) {
+        hipLaunchKernelGGL((title_order_kernel<3, false>), grid, dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+        hipLaunchKernelGGL((title_order_kernel<3, true>), grid, dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+    } else {
+        hipLaunchKernelGGL((title_order_kernel<2, false>), grid, dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+        hipLaunchKernelGGL((title_order_kernel<2, true>), grid, dim3(256), 0, stream, n_seq, S, ids, order, cnt);
+    }
     return check_launch("title_order");
 }
 
@@ -590,13 +895,20 @@ int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
 #ifdef NRMS_F16_EXPERIMENTS
     { const char* e = getenv("NRMS_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
-    const void* fn = two ? (train ? (const void*)fused_fwd16_kernel<true, 2> : (const void*)fused_fwd16_kernel<false, 2>)
+    // padding-skipping path with a 3-class order list: the kernel that pairs short titles (NRMS_NO_PAIRING: A/B switch, read per call)
+    const bool paired = !two && f.order != nullptr && f.pos != nullptr && f.ids != nullptr;
+    if (!paired) { a.order = nullptr; a.order_cnt = nullptr; }      // (the general kernel takes titles in index order)
+    const void* fn = paired ? (train ? (const void*)fused_fwd16p_kernel<true> : (const void*)fused_fwd16p_kernel<false>)
+                   : two ? (train ? (const void*)fused_fwd16_kernel<true, 2> : (const void*)fused_fwd16_kernel<false, 2>)
                          : (train ? (const void*)fused_fwd16_kernel<true, 1> : (const void*)fused_fwd16_kernel<false, 1>);
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("fused_fwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
     TimingScope ts(two ? "fused64_fwd16" : "fused_fwd16", stream);
-    const dim3 grid(cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 1 : 0));    // two lists: one more partial group
-    if (two) {
+    const dim3 grid(cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 3 : 0));    // three lists: up to three partial groups
+    if (paired) {
+        if (train) hipLaunchKernelGGL((fused_fwd16p_kernel<true>), grid, dim3(F16_THREADS), lds, stream, a);
+        else hipLaunchKernelGGL((fused_fwd16p_kernel<false>), grid, dim3(F16_THREADS), lds, stream, a);
+    } else if (two) {
         if (train) hipLaunchKernelGGL((fused_fwd16_kernel<true, 2>), grid, dim3(F16_THREADS), lds, stream, a);
         else hipLaunchKernelGGL((fused_fwd16_kernel<false, 2>), grid, dim3(F16_THREADS), lds, stream, a);
     } else {

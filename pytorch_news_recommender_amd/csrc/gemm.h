@@ -339,7 +339,7 @@ struct Fused16Fwd {
     const int* pos;           // token -> x16 row (-1: the padding token's row, index *n_rows) or null (row = token)
     const int* n_rows;        // device: number of compact rows (required with pos)
     const int64_t* ids;       // non-null: sequences whose ids are all 0 take the closed form (padding row is zero)
-    const int* order;         // optional [2][n_seq] from launch_title_order (+ order_cnt[2]): live titles, then all-padding ones
+    const int* order;         // optional [3][n_seq] from launch_title_order(n_classes = 3) (+ order_cnt): long, all-padding, short titles
     const int* order_cnt;
     void* ctx16;              // [n_seq*S][DP] fp16 (always written: the kernel reads it back)
     void* t16;                // [n_seq*S][QP] fp16 or null (inference)
@@ -348,9 +348,10 @@ struct Fused16Fwd {
     Dropout drop;             // context dropout
 };
 int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream);
-// order [2][n_seq] ints, cnt title_order_cnt_ints(n_seq) ints (cnt[0..1] = the two list sizes)
+// order [n_classes][n_seq] ints, cnt title_order_cnt_ints(n_seq) ints (cnt[0 .. n_classes) = the list sizes).  n_classes 2: titles
+// with a real token | all-padding titles; 3: long | all-padding | short-prefix titles (see fused16.hip)
 size_t title_order_cnt_ints(int n_seq);
-int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream);
+int launch_title_order(int n_seq, int S, const int64_t* ids, int* order, int* cnt, hipStream_t stream, int n_classes = 2);
 
 // fused16_bwd.hip: the backward of the above.  `workspace` holds the backward weight planes, dout16, dZ16, dQKV16, the
 // per-workgroup column sums and the split-M partial slabs (fused16_bwd_layout(M, n_seq).total bytes).
