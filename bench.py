@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the secondary legs")
     ap.add_argument("--dense-padding", action="store_true",
                     help="diagnostics: process padding tokens densely (as if embedding row 0 were not zero)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes when the committed traffic profile is stale")
     ap.add_argument("--cpu-budget-s", type=float, default=60.0, help="wall-clock budget of the larger CPU-baseline batch")
     ap.add_argument("--grad-sync", default="allreduce", choices=["allreduce", "sharded"],
                     help="N > 1: one all-reduce of the flat gradient + full Adam on every rank (default), or reduce-scatter -> "
@@ -497,14 +499,37 @@ def main():
         bound, fl, by = work[dom]
         peak = PEAKS[kprec[dom]] if bound == "mfma" else PEAK_HBM_GBPS
         achieved = (fl / 1e12 if bound == "mfma" else by / 1e9) / (dom_ms / args.steps * 1e-3)
-        # measured HBM bytes of that kernel's largest launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
-        # tools/profile_round.sh at this workload, committed under profiles/): null if not on file
-        traffic, tfile = None, os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % args.precision)
-        if B == 512 and os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile))["by_timer"].get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # measured HBM bytes per step of that kernel and of the whole step: rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE in separate
+        # passes (tools/hbm_traffic.py).  A committed profile is used only if it was measured on EXACTLY this kernel source
+        # (hash of csrc/ + include/); otherwise the two passes run now, as child processes, on the code that was just timed.
+        traffic, step_traffic, traffic_src = None, None, "unavailable"
+        if B == 512 and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hbm_traffic
+            sha = hbm_traffic.csrc_sha16()
+            tfile = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % args.precision)
+            prof = None
+            if os.path.exists(tfile) and not args.fp16_user_encoder:
+                try:
+                    cand = json.load(open(tfile))
+                    if cand.get("csrc_sha16") == sha:
+                        prof, traffic_src = cand, "profiles/%s (same kernel source: csrc sha %s)" % (os.path.basename(tfile), sha)
+                    else:
+                        traffic_src = "profiles/%s is stale (csrc sha %s != %s)" % (os.path.basename(tfile), cand.get("csrc_sha16"), sha)
+                except Exception as e:
+                    traffic_src = "unreadable profile: %r" % (e,)
+            if prof is None and not args.no_live_traffic:
+                try:
+                    log("measuring HBM traffic live (two rocprofv3 --pmc passes as child processes)")
+                    torch.cuda.synchronize()
+                    prof = hbm_traffic.collect(os.path.join("/tmp", "nrms_traffic_%d" % os.getpid()), steps=3, precision=args.precision,
+                                               extra=["--fp16-user-encoder"] if args.fp16_user_encoder else [])
+                    traffic_src = "measured in this run (tools/hbm_traffic.py, 3 steps per pass)"
+                except Exception as e:
+                    traffic_src += "; live measurement failed: %r" % (e,)
+            if prof is not None:
+                traffic = prof["by_timer"].get(dom, {}).get("hbm_bytes_per_step")
+                step_traffic = prof.get("step_bytes")
         total_users = B * world * args.steps
         users_per_s = total_users / dt
         per_gpu = users_per_s / world
@@ -526,8 +551,11 @@ def main():
             "loss": loss,
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_note": "HBM bytes of that kernel's largest launch, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, "
-                                         "profiles/r02_%s_hbm_traffic.json" % args.precision,
+                         "traffic_note": "HBM bytes per step of that kernel, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE (separate passes); "
+                                         "source: " + traffic_src,
+                         "step_traffic": step_traffic,
+                         "step_traffic_note": "HBM bytes of ALL kernels of one train step, same measurement; algorithmic: 4.87 MB/user x %d = "
+                                              "%.2f GB (SURVEY 8d)" % (B, 4.87e6 * B / 1e9),
                          "peak_note": ("HBM3E spec 8 TB/s (6.3 TB/s measured achievable)" if bound == "hbm" else
                                        {"fp32": "f32-input MFMA dense peak", "bf16": "bf16 MFMA dense peak", "fp16": "fp16 MFMA dense peak",
                                         "bf16x3": "bf16 dense peak / 3 (3 bf16 MFMAs per fp32-equivalent step by construction)"}[kprec[dom]]),
@@ -551,8 +579,6 @@ def main():
                                       "frac": kernels[k]["tflops"] / PEAKS[kprec[k]]}
         if dp is not None:
             out["data_parallel"] = dp
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_budget_s)
     # secondary (N = 1, outside the timed region of `value`): the other modes on the same batch
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         modes = {}
@@ -597,6 +623,11 @@ def main():
             out["eval_path"] = eval_path_leg(model, dev)
         except Exception as e:       # secondary leg only: never lose the headline line
             out["eval_path"] = {"error": repr(e)}
+    # the CPU baseline LAST: its OpenMP worker threads keep spinning for a while after each parallel region, which starves the
+    # host thread that launches the GPU legs above (the ~50-launch bf16x3 step measured 58 k instead of 72 k users/s behind it)
+    if world == 1 and not args.no_cpu_baseline and rank == 0:
+        torch.cuda.synchronize()
+        out["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_budget_s)
     if rank == 0:
         print(json.dumps(out), flush=True)
     parallel.barrier()

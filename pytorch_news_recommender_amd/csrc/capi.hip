@@ -290,7 +290,7 @@ static Bwd16Layout bwd16_layout(const nrms_encoder_desc* d) {
     L.pos = take(gather ? M * sizeof(int) : 0);
     L.n_live = take(gather ? 256 : 0);
     L.cscr = take(gather ? compact_scratch_ints((long)M) * sizeof(int) : 0);
-    L.order = take(gather ? (size_t)2 * d->n_seq * sizeof(int) : 0);
+    L.order = take(gather ? (size_t)3 * d->n_seq * sizeof(int) : 0);
     L.order_cnt = take(gather ? title_order_cnt_ints(d->n_seq) * sizeof(int) : 0);
     L.dxc = take(gather ? M * d->d_model * sizeof(float) : 0);
     L.sscr = take(gather ? scatter_grouped_scratch_ints((long)M, d->vocab) * sizeof(int) : 0);
@@ -333,7 +333,7 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
         if (skip_pad_rows(desc)) {
             int* order = (int*)(base + L.order);
             int* order_cnt = (int*)(base + L.order_cnt);
-            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s);
+            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s, 3);
             if (rc) return rc;
             f.pos = pos; f.n_rows_dev = n_live; f.ids = ids; f.order = order; f.order_cnt = order_cnt;
         }

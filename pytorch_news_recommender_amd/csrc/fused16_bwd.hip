@@ -29,8 +29,12 @@ struct Bwd16Args {
     const int* pos;             // token -> x16 / dqkv16 row, -1 = padding token; null: row = token
     const int* n_rows;          // device: number of compact rows (with pos); x16 row *n_rows is the padding token's row
     const int64_t* ids;         // non-null: all-padding titles take the closed form
-    const int* order;           // as in the forward
+    const int* order;           // [n_cls][n_seq] title lists of launch_title_order (null: titles in index order)
     const int* order_cnt;
+    int n_cls;                  // 2: titles with a real token | all-padding titles.  3: long | all-padding | short titles -- then
+                                // the pooling kernel hands the attention kernel the d(ctx) of a short title COMPRESSED to its
+                                // n + 1 tile rows (the padding tokens' rows summed into one) and the attention kernel puts
+                                // two short titles into one 32-row tile, as the forward does (fused16.hip, fused_fwd16p_kernel)
     const _Float16* btiles;     // [4h][32][KP]: the h tiles Wadd_h^T (32 features x QP), then per head W'_q | W_k | W_v
     const float* bqkv32;        // [3h][32]
     const _Float16* qv16;       // [QP]
@@ -96,24 +100,30 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             sel[s][j] = (_Float16)(l32 == 16 * s + 8 * hh + j ? 1.0f : 0.0f);
         }
 
-    int n_ne = a.n_seq, n_e = 0, g_ne = a.n_groups;
+    // title lists: [0] titles with a real token (n_cls 3: the long ones), [1] all-padding titles, [2] (n_cls 3) short titles
+    int n_ne = a.n_seq, n_e = 0, n_sh = 0, g_ne = a.n_groups, g_sh = 0;
     if (a.order != nullptr) {
         n_ne = a.order_cnt[0];
         n_e = a.order_cnt[1];
         g_ne = (n_ne + F16_WAVES - 1) / F16_WAVES;
+        if (a.n_cls == 3) { n_sh = a.order_cnt[2]; g_sh = (n_sh + F16_WAVES - 1) / F16_WAVES; }
     }
     TileRing ring;
     ring.smem = smem; ring.src = a.btiles; ring.n_tiles = a.h; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
 
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < a.n_groups; grp += gridDim.x) {
-        // ---- which sequence this wave owns in this group
+        // ---- which sequence this wave owns in this group (groups: long / short / all-padding titles, four per group)
         int slot_id = grp * F16_WAVES + wave;
         bool valid;
         int seq;
         if (grp < g_ne) { valid = slot_id < n_ne; seq = valid ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0; }
-        else {
+        else if (grp < g_ne + g_sh) {
             slot_id -= g_ne * F16_WAVES;
+            valid = slot_id < n_sh;
+            seq = valid ? a.order[2 * (long)a.n_seq + slot_id] : 0;
+        } else {
+            slot_id -= (g_ne + g_sh) * F16_WAVES;
             valid = slot_id < n_e;
             seq = valid ? a.order[a.n_seq + slot_id] : 0;
         }
@@ -124,6 +134,23 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             empty = __ballot(is_pad) == ~0ull;
         }
         const bool live = valid && !empty;
+        // a short title (n_cls 3, the third list): its n real tokens are a prefix, and the attention kernel processes it in n + 1
+        // tile rows -- one per real token, one for all its padding tokens.  Its d(ctx) leaves this kernel in that form: column
+        // c < n = token c, column n = the SUM over the padding tokens' rows (they share one context row in the forward, so their
+        // gradients add), by one product with the selector SelT[tok][col] = (min(tok, n) == col).
+        int nshort = -1;
+        h8 selT[2] = {h8{0, 0, 0, 0, 0, 0, 0, 0}, h8{0, 0, 0, 0, 0, 0, 0, 0}};
+        if (SB == 1 && a.n_cls == 3 && live && grp >= g_ne) {
+            nshort = __popcll(__ballot(lane < S && a.ids[tok0 + lane] != 0));
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int tok = crow32(8 * s + j, hh);                 // the k slot's token (the order of acc_frag)
+                    const int src = tok < nshort ? tok : (tok < S ? nshort : -1);
+                    selT[s][j] = (_Float16)(src == l32 ? 1.0f : 0.0f);
+                }
+        }
         // tile stream of this kernel: the h tiles Wadd_h^T (the first h tiles of btiles)
         ring.load(0);                                                   // lands while the pooling backward runs
 
@@ -249,8 +276,18 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                 if (live && !F16_DBG(a.dbg, 4)) {                     // (zero beyond the sequence: dZ and w are 0 there); the
                     // attention kernel reads the rows of titles with a real token only
                     _Float16* dcrow = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
-                    *reinterpret_cast<h8*>(dcrow) = acc_frag(dct, 0);
-                    *reinterpret_cast<h8*>(dcrow + 512) = acc_frag(dct, 1);
+                    if (SB == 1 && nshort >= 0) {
+                        const f32x16 xt = transpose32(dct, idf);                       // [tok][f]
+                        f32x16 dcp = mfma32h(acc_frag(xt, 0), selT[0], zero16());       // [f][col] = sum_tok xt[tok][f] SelT[tok][col]
+                        dcp = mfma32h(acc_frag(xt, 1), selT[1], dcp);
+                        if (l32 < 16) {                                                 // columns 0 .. n carry data, n + 1 .. 15 zeros
+                            *reinterpret_cast<h8*>(dcrow) = acc_frag(dcp, 0);
+                            *reinterpret_cast<h8*>(dcrow + 512) = acc_frag(dcp, 1);
+                        }
+                    } else {
+                        *reinterpret_cast<h8*>(dcrow) = acc_frag(dct, 0);
+                        *reinterpret_cast<h8*>(dcrow + 512) = acc_frag(dct, 1);
+                    }
                 }
                 if (!live && valid) {
                     // closed form (all-padding title): dS = 0, every dV row = mean of d(ctx) rows => d(b_v) += sum_tok d(ctx)
@@ -278,7 +315,13 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     for (int i = tid; i < B16_RED; i += F16_THREADS) out[i] = red[i];
 }
 
-// The attention part of the backward, on the sequences with a real token only (the first g_ne groups of the order list).
+// The attention part of the backward, on the sequences with a real token only.  With a 3-class title list (n_cls 3, SB = 1)
+// the groups are [pairs of short titles][long titles]: a pair shares one 32-row tile exactly as in the forward
+// (fused16.hip, fused_fwd16p_kernel) -- rows 16 p .. 16 p + n_p - 1 the real tokens of title p, row 16 p + n_p all its padding
+// tokens (as a key: logit + log multiplicity; as a query: the sum of their d(ctx) rows, which the pooling kernel has already
+// formed), cross-title entries of S^T masked by the additive bias -- so the recomputed Q | K | V tiles, the softmax and the
+// five gradient products serve two titles at once.  The shared row's dQ | dK | dV are the sums over the padding tokens: they
+// enter the bias gradients (column sums over the tile's rows) and are not stored (a padding token has no dX, no share of dW).
 template <int SB>
 __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fused_bwd16_attn_kernel(Bwd16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,33 +333,68 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     const int l32 = lane & 31, hh = lane >> 5;
     const int S = a.S;
     constexpr int KP = F16_KP, DP = F16_DP;
+    constexpr float NEG = -3.0e38f;
     for (int i = tid; i < B16_RED; i += F16_THREADS) red[i] = 0.f;
     h8 idf[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) idf[s][j] = (_Float16)(l32 == 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3) ? 1.0f : 0.0f);
-    int n_ne = a.n_seq, g_ne = a.n_groups;
+    int n_ne = a.n_seq, g_ne = a.n_groups, n_sh = 0, g_pair = 0;
     if (a.order != nullptr) {
         n_ne = a.order_cnt[0];
         g_ne = (n_ne + F16_WAVES - 1) / F16_WAVES;
+        if (SB == 1 && a.n_cls == 3) { n_sh = a.order_cnt[2]; g_pair = (n_sh + 2 * F16_WAVES - 1) / (2 * F16_WAVES); }
     }
     TileRing ring;
     ring.smem = smem; ring.src = a.btiles + (long)a.h * 32 * KP; ring.n_tiles = 3 * a.h; ring.tid = tid; ring.l32 = l32; ring.hh = hh; ring.dbg = 0;
     const h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     __syncthreads();
 #pragma unroll 1
-    for (int grp = blockIdx.x; grp < g_ne; grp += gridDim.x) {
-        const int slot_id = grp * F16_WAVES + wave;
-        const bool valid = slot_id < n_ne;
-        const int seq = valid ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0;
+    for (int grp = blockIdx.x; grp < g_pair + g_ne; grp += gridDim.x) {
+        const bool pair = SB == 1 && grp < g_pair;                      // uniform over the workgroup
+        // ---- the titles of this wave: two short ones (pair) or one
+        int seq2[2] = {0, 0};
+        bool val2[2] = {false, false};
+        int nl2[2] = {0, 0};                                            // real tokens of a short title
+        if (pair) {
+            const int p0 = 2 * (grp * F16_WAVES + wave);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                val2[i] = p0 + i < n_sh;
+                seq2[i] = val2[i] ? a.order[2 * (long)a.n_seq + p0 + i] : 0;
+                if (val2[i]) nl2[i] = __popcll(__ballot(lane < S && a.ids[(long)seq2[i] * S + lane] != 0));
+            }
+        } else {
+            const int slot_id = (grp - g_pair) * F16_WAVES + wave;
+            val2[0] = slot_id < n_ne;
+            seq2[0] = val2[0] ? (a.order != nullptr ? a.order[slot_id] : slot_id) : 0;
+        }
+        const bool valid = val2[0];
+        const int seq = seq2[0];
         const long tok0 = (long)seq * S;
         bool empty = false;
-        if (SB == 1 && a.ids != nullptr && valid) {
+        if (SB == 1 && !pair && a.ids != nullptr && valid) {
             const bool is_pad = lane < S ? a.ids[tok0 + lane] == 0 : true;
             empty = __ballot(is_pad) == ~0ull;
         }
-        const bool live = valid && !empty;
+        const bool live = pair ? (val2[0] || val2[1]) : (valid && !empty);
+        // this lane's tile row in pair mode: title myp, row myr of its 16
+        const int myp = pair ? (l32 >> 4) : 0, myr = pair ? (l32 & 15) : l32;
+        const int myn = myp ? nl2[1] : nl2[0];
+        const bool myval = myp ? val2[1] : val2[0];
+        const int myseq = myp ? seq2[1] : seq2[0];
+        f32x16 kbias;                                                   // SB = 1: additive softmax mask of the key rows this lane holds
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = crow32(r, hh);
+            float bsv = j < S ? 0.f : NEG;
+            if (pair) {
+                const int jr = j & 15;
+                bsv = (j >> 4) != myp ? NEG : (jr < myn ? 0.f : ((jr == myn && myn < S) ? __logf((float)max(S - myn, 1)) : NEG));
+            }
+            kbias[r] = bsv;
+        }
         ring.load(0); ring.store(0);
         ring.load(1); ring.store(1);
         int n = 0;
@@ -325,10 +403,17 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
         h8 xf[SB][F16_KS];
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
-            tok_ok[b] = valid && 32 * b + l32 < S;
-            drow[b] = tok_ok[b] && live ? (a.pos != nullptr ? (long)a.pos[tok0 + 32 * b + l32] : tok0 + 32 * b + l32) : -1;
-            // a padding token inside a live title reads the pad row (zeros + the ones column => Q|K|V = bias)
-            const long xrow = (tok_ok[b] && live && drow[b] < 0) ? (long)*a.n_rows : drow[b];
+            long xrow;
+            if (SB == 1 && pair) {
+                tok_ok[b] = myval && myr <= myn;
+                drow[b] = (myval && myr < myn) ? (long)a.pos[(long)myseq * S + myr] : -1;     // real tokens only
+                xrow = drow[b] >= 0 ? drow[b] : ((myval && myr == myn && myn < S) ? (long)*a.n_rows : -1);
+            } else {
+                tok_ok[b] = valid && 32 * b + l32 < S;
+                drow[b] = tok_ok[b] && live ? (a.pos != nullptr ? (long)a.pos[tok0 + 32 * b + l32] : tok0 + 32 * b + l32) : -1;
+                // a padding token inside a live title reads the pad row (zeros + the ones column => Q|K|V = bias)
+                xrow = (tok_ok[b] && live && drow[b] < 0) ? (long)*a.n_rows : drow[b];
+            }
             const _Float16* xr = a.x16 + (xrow < 0 ? 0 : xrow) * KP + 8 * hh;
 #pragma unroll
             for (int s = 0; s < F16_KS; ++s) xf[b][s] = *reinterpret_cast<const h8*>(xr + 16 * s);
@@ -344,9 +429,12 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
             h8 dc[SB][2];
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
-                const _Float16* dcsrc = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
+                // pair: column myr of title myp's COMPRESSED d(ctx) (fused_bwd16_pool_kernel); a missing second title: zeros
+                const _Float16* dcsrc = (SB == 1 && pair) ? a.dctx16 + frag_off((long)myseq, F16_CS, 2 * head, myr, hh)
+                                                          : a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
                 dc[b][0] = *reinterpret_cast<const h8*>(dcsrc);             // (zeros beyond the sequence)
                 dc[b][1] = *reinterpret_cast<const h8*>(dcsrc + 512);
+                if (SB == 1 && pair && !myval) { dc[b][0] = z8; dc[b][1] = z8; }
             }
             // ---- tiles W'_q, W_k, W_v: Q^T, K^T, V^T [f][tok], kept as operand fragments only (bias: the ones column)
             h8 qf[SB][2], kf[SB][2], vf[SB][2];
@@ -395,7 +483,8 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                         pt[jb] = mfma32h(kf[jb][1], qf[ib][1], pt[jb]);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            pt[jb][r] = 32 * jb + crow32(r, hh) < S ? pt[jb][r] : -3.0e38f;
+                            if (SB == 1) pt[jb][r] += kbias[r];           // rows beyond the sequence / the other title; padding multiplicity
+                            else pt[jb][r] = 32 * jb + crow32(r, hh) < S ? pt[jb][r] : NEG;
                             m = fmaxf(m, pt[jb][r]);
                         }
                     }
@@ -405,7 +494,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                     for (int jb = 0; jb < SB; ++jb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const float p = 32 * jb + crow32(r, hh) < S ? __expf(pt[jb][r] - m) : 0.f;
+                            const float p = (SB == 1 || 32 * jb + crow32(r, hh) < S) ? __expf(pt[jb][r] - m) : 0.f;
                             pt[jb][r] = p;
                             sum += p;
                         }
@@ -1151,7 +1240,8 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     }
     Bwd16Args a{};
     a.n_seq = f.n_seq; a.S = f.S; a.d = f.d; a.h = f.h; a.dk = dk; a.q = f.q;
-    a.n_groups = cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 1 : 0);
+    a.n_groups = cdiv(f.n_seq, F16_WAVES) + (f.order != nullptr ? 2 : 0);      // three lists: up to two more partial groups
+    a.n_cls = f.order != nullptr ? 3 : 2;                                       // (launch_title_order(..., 3) by the caller)
     a.x16 = (const _Float16*)f.x16; a.pos = f.pos; a.n_rows = f.n_rows_dev; a.ids = f.ids; a.order = f.order; a.order_cnt = f.order_cnt;
     a.btiles = btiles; a.bqkv32 = bqkv32; a.qv16 = qv16;
     a.ctx16 = (const _Float16*)f.ctx16; a.t16 = (const _Float16*)f.t16; a.w = f.w; a.dout16 = dout16;

@@ -365,7 +365,7 @@ struct Fused16Bwd {
     const int* pos;           // token -> row (x16 and dQKV16), -1 = padding token; null: row = token
     const int* n_rows_dev;    // number of rows (device) when pos != null, else null (= n_seq * S)
     const int64_t* ids;       // non-null: all-padding sequences take the closed form
-    const int* order; const int* order_cnt;
+    const int* order; const int* order_cnt;     // launch_title_order(n_classes = 3) lists, or null
     const void* ctx16; const void* t16; const float* w;         // forward activations
     const float* dout;        // [n_seq][d]
     float loss_scale;         // > 0: fixed power of two the fp16 gradients are carried multiplied by; <= 0: chosen on the

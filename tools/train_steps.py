@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Exactly N identical train steps of the bench configuration (bench.py's model, batch and step; nothing else runs), for
+profiler passes whose per-kernel totals are then divided by N.   python3 tools/train_steps.py --steps 4 [--precision fp16]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pytorch_news_recommender_amd import synth
+from pytorch_news_recommender_amd.config import Config
+from pytorch_news_recommender_amd.model.nrms_hip import Model
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=4)
+ap.add_argument("--users", type=int, default=512)
+ap.add_argument("--precision", default="fp16")
+ap.add_argument("--fp16-user-encoder", action="store_true")
+args = ap.parse_args()
+shape = synth.BENCH
+cfg = Config("nrms_hip")
+cfg.__nrms__()
+cfg.n_words_title, cfg.sample_size, cfg.batch_size = shape.n_words_title, shape.n_candidates - 1, args.users
+cfg.dropout, cfg.learning_rate, cfg.precision, cfg.fp16_user_encoder = 0.2, 1e-3, args.precision, args.fp16_user_encoder
+params = synth.make_params(shape, seed=0)
+model = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
+model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+model = model.to("cuda:0").train()
+batch = {k: torch.from_numpy(v).to("cuda:0") for k, v in synth.make_batch(shape, seed=1, batch_size=args.users).items()}
+for _ in range(args.steps):
+    model.train_step(batch)
+torch.cuda.synchronize()
