@@ -71,6 +71,11 @@ extern "C" {
  * library's helper streams when nrms_encoder_bwd returns; with this flag the call does not wait for them (dx and the table
  * gradient are complete in stream order, those four are NOT) and nrms_encoder_bwd_wqkv orders them into the stream. */
 #define NRMS_FLAG_DEFER_WQKV 2
+/* nrms_encoder_bwd, NRMS_PRECISION_FP16 news encoder: `acts.scratch` is still exactly what the nrms_encoder_fwd call of this
+ * step left in it (the caller has not passed that buffer to another forward in between).  The backward then reads the token
+ * and title lists the forward built there (live rows, row positions, the three title classes) instead of rebuilding them
+ * from the ids (five small launches).  Without the flag nothing in acts.scratch is read by the backward. */
+#define NRMS_FLAG_FWD_SCRATCH_KEPT 4
 
 /* One self-attention + additive-pooling encoder pass over n_seq sequences of seq_len rows.
  * vocab > 0  : news encoder -- input is `ids` [n_seq, seq_len] int64, rows gathered from

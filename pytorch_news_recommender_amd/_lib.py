@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("NRMS_HIP_LIB") or os.path.join(PKG, "libnrms_hip.so")
 
 NRMS_FLAG_PAD_ROW_ZERO = 1
 NRMS_FLAG_DEFER_WQKV = 2
+NRMS_FLAG_FWD_SCRATCH_KEPT = 4
 NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1
 NRMS_PRECISION_BF16 = 2

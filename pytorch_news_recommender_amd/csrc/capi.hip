@@ -2,6 +2,8 @@
 // sequences of one encoder forward / backward, error text and optional event timing.
 #include <stdarg.h>
 
+#include <algorithm>
+
 #include <mutex>
 #include <vector>
 
@@ -134,7 +136,7 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
                      "%s: precision fp16 supports neither the output projection, masks nor p_drop_attn (use bf16x3)", who);
     }
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
-    NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV)) == 0, "%s: unknown flags 0x%x", who, d->flags);
+    NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV | NRMS_FLAG_FWD_SCRATCH_KEPT)) == 0, "%s: unknown flags 0x%x", who, d->flags);
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
     return NRMS_OK;
 }
@@ -292,7 +294,7 @@ static Bwd16Layout bwd16_layout(const nrms_encoder_desc* d) {
     L.cscr = take(gather ? compact_scratch_ints((long)M) * sizeof(int) : 0);
     L.order = take(gather ? (size_t)3 * d->n_seq * sizeof(int) : 0);
     L.order_cnt = take(gather ? title_order_cnt_ints(d->n_seq) * sizeof(int) : 0);
-    L.dxc = take(gather ? M * d->d_model * sizeof(float) : 0);
+    L.dxc = take(gather ? M * std::max((size_t)d->d_model * sizeof(float), (size_t)NRMS_FP16_KP * 2) : 0);   // fp32 [M][d] or fp16 [M][320]
     L.sscr = take(gather ? scatter_grouped_scratch_ints((long)M, d->vocab) * sizeof(int) : 0);
     L.total = off;
     return L;
@@ -326,21 +328,36 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     int* live = (int*)(base + L.live);
     int* n_live = (int*)(base + L.n_live);
     if (gather) {
-        // the token lists of the forward live in ITS scratch, which later forward calls reuse: rebuild them
-        int* pos = (int*)(base + L.pos);
-        rc = launch_compact_live_rows(M, ids, live, pos, n_live, (int*)(base + L.cscr), s);
-        if (rc) return rc;
-        if (skip_pad_rows(desc)) {
-            int* order = (int*)(base + L.order);
-            int* order_cnt = (int*)(base + L.order_cnt);
-            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s, 3);
+        const bool kept = (desc->flags & NRMS_FLAG_FWD_SCRATCH_KEPT) != 0 && skip_pad_rows(desc) && acts->scratch != nullptr;
+        if (kept) {
+            // the lists of this step's forward, where encoder_fwd16 left them
+            const Fwd16Scratch fs = fwd16_scratch(desc);
+            char* fb = (char*)acts->scratch;
+            live = (int*)(fb + fs.live);
+            n_live = (int*)(fb + fs.n_live);
+            f.pos = (int*)(fb + fs.pos); f.n_rows_dev = n_live; f.ids = ids;
+            f.order = (int*)(fb + fs.order); f.order_cnt = (int*)(fb + fs.order_cnt);
+        } else {
+            // the forward's scratch may have been reused by later forward calls: rebuild the lists
+            int* pos = (int*)(base + L.pos);
+            rc = launch_compact_live_rows(M, ids, live, pos, n_live, (int*)(base + L.cscr), s);
             if (rc) return rc;
-            f.pos = pos; f.n_rows_dev = n_live; f.ids = ids; f.order = order; f.order_cnt = order_cnt;
+            if (skip_pad_rows(desc)) {
+                int* order = (int*)(base + L.order);
+                int* order_cnt = (int*)(base + L.order_cnt);
+                rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s, 3);
+                if (rc) return rc;
+                f.pos = pos; f.n_rows_dev = n_live; f.ids = ids; f.order = order; f.order_cnt = order_cnt;
+            }
         }
         f.dx = (float*)(base + L.dxc);
+        // compact path: dX travels to the grouped scatter as fp16 (still loss-scaled)
+        f.dx_fp16 = skip_pad_rows(desc);
     } else {
         f.dx = dx;
     }
+    const float* sc_dev = nullptr;
+    f.sc_out = &sc_dev;
     // NRMS_FLAG_DEFER_WQKV: the two weight-gradient GEMMs stay on their helper streams; dX and the table gradient below
     // are complete in stream order, nrms_encoder_bwd_wqkv joins the rest (a data-parallel caller starts the table
     // all-reduce in between)
@@ -350,7 +367,8 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     if (gather) {
         const Dropout drop_e = make_dropout(desc->seed, desc->p_drop_embed);
         if (skip_pad_rows(desc))
-            rc = launch_scatter_grouped(M, desc->vocab, d, ids, live, n_live, f.dx, drop_e, grads->table, (int*)(base + L.sscr), s);
+            rc = launch_scatter_grouped(M, desc->vocab, d, ids, live, n_live, f.dx, drop_e, grads->table, (int*)(base + L.sscr), s,
+                                        f.dx_fp16, NRMS_FP16_KP, sc_dev);
         else       // dense rows (one per token): the atomic scatter walks the live list over the dense rows
             rc = launch_scatter_dense_rows(M, d, ids, live, n_live, f.dx, drop_e, grads->table, s);
     }

@@ -293,9 +293,15 @@ __global__ __launch_bounds__(256) void tok_place_kernel(const int64_t* ids, cons
     }
 }
 
+// H16: dX rows are fp16 [rows][ldx] still multiplied by the fp16 backward's loss scale (half the bytes of the dX GEMM's
+// store and of this kernel's reads); the sum is taken in fp32 and divided by the scale (sc[1], device) once per table row.
+typedef _Float16 sg_h4 __attribute__((ext_vector_type(4)));
+template <bool H16>
 __global__ __launch_bounds__(256) void scatter_grouped_kernel(int V, int d4, const int* live, const int* offs,
-                                                              const int* total, const int* order, const float* dx,
-                                                              Dropout drop, float* dtable) {
+                                                              const int* total, const int* order, const void* dxv, int ldx,
+                                                              const float* sc, Dropout drop, float* dtable) {
+    const float* dx = reinterpret_cast<const float*>(dxv);
+    const _Float16* dx16 = reinterpret_cast<const _Float16*>(dxv);
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= V || v == 0) return;                                   // id 0 = padding: no gradient
@@ -313,7 +319,14 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(int V, int d4, con
         for (int j = 0; j < SL; ++j) {
             const int c4 = lane + 64 * j;
             if (c4 < d4) {
-                f32x4 g = *reinterpret_cast<const f32x4*>(dx + ((long)r * d4 + c4) * 4);
+                f32x4 g;
+                if (H16) {
+                    const sg_h4 gh = *reinterpret_cast<const sg_h4*>(dx16 + (long)r * ldx + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = (float)gh[e];
+                } else {
+                    g = *reinterpret_cast<const f32x4*>(dx + ((long)r * d4 + c4) * 4);
+                }
                 if (drop.thresh != 0u) g *= dropout_scale4(drop.seed, 0u, (uint64_t)(t * d4 + c4), drop.thresh, drop.inv_keep);
                 s[j] += g;
             }
@@ -337,15 +350,16 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(int V, int d4, con
 #pragma unroll
     for (int j = 0; j < SL; ++j) {
         const int c4 = lane + 64 * j;
-        if (c4 < d4) *reinterpret_cast<f32x4*>(dtable + ((long)v * d4 + c4) * 4) += s[j];
+        if (c4 < d4) *reinterpret_cast<f32x4*>(dtable + ((long)v * d4 + c4) * 4) += H16 ? s[j] * sc[1] : s[j];
     }
 }
 
 size_t scatter_grouped_scratch_ints(long M, int V) { return (size_t)2 * (V + 64) + (size_t)M + 64; }
 
 // scratch: scatter_grouped_scratch_ints(M, V) ints.  dx is compact (row r belongs to token live[r]).
-int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
-                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream) {
+int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const void* dx,
+                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream, bool dx_fp16, int ldx,
+                           const float* sc) {
     if (M <= 0) return NRMS_OK;
     int* cnt = scratch;                       // [V] counts -> exclusive offsets (in place)
     int* cursor = cnt + V + 64;               // [V]
@@ -366,8 +380,12 @@ int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* 
         hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(1024), 0, stream, V, nb, cnt, bsum, total);
     }
     hipLaunchKernelGGL(tok_place_kernel, dim3(blocks), dim3(256), 0, stream, ids, live, n_live, cnt, cursor, order);
-    hipLaunchKernelGGL(scatter_grouped_kernel, dim3(cdiv(V, 4)), dim3(256), 0, stream, V, d / 4, live, cnt, total, order, dx,
-                       drop, dtable);
+    if (dx_fp16)
+        hipLaunchKernelGGL(scatter_grouped_kernel<true>, dim3(cdiv(V, 4)), dim3(256), 0, stream, V, d / 4, live, cnt, total, order, dx,
+                           ldx, sc, drop, dtable);
+    else
+        hipLaunchKernelGGL(scatter_grouped_kernel<false>, dim3(cdiv(V, 4)), dim3(256), 0, stream, V, d / 4, live, cnt, total, order, dx,
+                           d, nullptr, drop, dtable);
     return check_launch("scatter_grouped");
 }
 

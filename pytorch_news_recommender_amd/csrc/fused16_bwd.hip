@@ -761,11 +761,12 @@ struct Dx16Args {
     const int* m_dev;         // rows actually present (device), or null
     const _Float16* a16;      // [rows][B16_DQ]
     const _Float16* xtiles;   // [DX_SLABS][4][10][2][32][8]
-    float* c;                 // [rows][ldc]
+    float* c;                 // [rows][ldc] fp32 (scale removed) -- or OUT16: fp16 [rows][F16_KP], still multiplied by the scale
     int ldc, d;
     const float* sc;          // device: {loss scale, 1 / loss scale}
 };
 
+template <bool OUT16>
 __global__ __launch_bounds__(DX_THREADS, 2) void gemm16_dx_kernel(Dx16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -839,12 +840,18 @@ __global__ __launch_bounds__(DX_THREADS, 2) void gemm16_dx_kernel(Dx16Args a) {
         const int row = row0 + wm * 64 + 32 * i + l32;
         if (row >= M) continue;
         float* crow = a.c + (long)row * a.ldc;
+        _Float16* crow16 = reinterpret_cast<_Float16*>(a.c) + (long)row * F16_KP;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int k = (wn * 5 + j) * 32 + 8 * g + 4 * hh;      // registers 4 g .. 4 g + 3 = columns k .. k + 3
-                if (k < a.d) {
+                if (OUT16) {                                           // all 320 columns (those beyond d are exact zeros)
+                    h4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (_Float16)acc[i][j][4 * g + e];
+                    *reinterpret_cast<h4*>(crow16 + k) = v;
+                } else if (k < a.d) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * inv_scale;
@@ -1210,6 +1217,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     float* nscale_add = (float*)(nmap_add + F16_QP);
     int* kmap_ctx = (int*)(nscale_add + F16_QP);
     float* sc = (float*)(base + L.scale);                      // device: {scale, 1 / scale}
+    if (f.sc_out != nullptr) *f.sc_out = sc;
     unsigned* max_bits = (unsigned*)(sc + 2);
     float* partial_qkv = (float*)(base + L.partial);
     float* partial_add = (float*)(base + L.partial + up256((size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4));
@@ -1315,10 +1323,12 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         g.sc = sc;
         if ((f.d & 3) != 0 || ((uintptr_t)f.dx & 15) != 0) { set_error("gemm16_dx: dx must be 16-byte aligned, d %% 4 == 0"); return NRMS_EINVAL; }
         const size_t lds = (size_t)2 * DX_SLOT;
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm16_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void* fn = f.dx_fp16 ? (const void*)gemm16_dx_kernel<true> : (const void*)gemm16_dx_kernel<false>;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("gemm16_dx: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
         TimingScope ts("dx_bwd", stream);
-        hipLaunchKernelGGL(gemm16_dx_kernel, dim3(cdiv(M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
+        if (f.dx_fp16) hipLaunchKernelGGL(gemm16_dx_kernel<true>, dim3(cdiv(M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
+        else hipLaunchKernelGGL(gemm16_dx_kernel<false>, dim3(cdiv(M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
         rc = check_launch("gemm16_dx");
     }
     if (side && rc == NRMS_OK) {                                    // join: the caller's stream continues after both GEMMs

@@ -372,7 +372,10 @@ struct Fused16Bwd {
                               // device from max |dout| (loss_scale_from_max)
     Dropout drop;             // context dropout
     float* dw_qkv; float* db_qkv; float* dw_add; float* db_add; float* dq_vec;           // accumulated
-    float* dx;                // [rows][d] fp32 (rows as pos / tokens): gradient w.r.t. the encoder input
+    float* dx;                // [rows][d] fp32 (rows as pos / tokens): gradient w.r.t. the encoder input -- or, with dx_fp16,
+                              // fp16 [rows][KP] STILL multiplied by the loss scale (the embedding scatter divides: *sc_out)
+    bool dx_fp16;
+    const float** sc_out;     // receives the device address of {scale, 1 / scale} (optional)
     bool defer_join;          // leave the two weight-gradient GEMMs running on their helper streams when the call returns
                               // (dx is complete in stream order); fused_bwd16_join() orders them before later work
 };
@@ -401,8 +404,10 @@ int launch_compact_live_rows(long M, const int64_t* ids, int* live, int* pos, in
                              hipStream_t stream);
 // grouped (atomic-free) scatter of a COMPACT dx; scratch: scatter_grouped_scratch_ints(M, V) ints
 size_t scatter_grouped_scratch_ints(long M, int V);
-int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
-                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream);
+// dx: fp32 [rows][d], or (dx_fp16) fp16 [rows][ldx] multiplied by the loss scale whose reciprocal is sc[1] (device)
+int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const void* dx,
+                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream, bool dx_fp16 = false, int ldx = 0,
+                           const float* sc = nullptr);
 // dx has one row per token; the live tokens' rows are scatter-added (float atomics)
 int launch_scatter_dense_rows(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
                               const Dropout& drop, float* dtable, hipStream_t stream);

@@ -196,7 +196,9 @@ class NRMSEngine:
             t = self._buf(tag + ".t16", Mp * QP, h) if need_bwd else None
             w = self._buf(tag + ".w", M) if need_bwd else None
             nbytes = int(self.lib.nrms_encoder_fwd_scratch_bytes(C.byref(desc)))
-            scratch = self._buf("fwd_scratch16", (nbytes + 3) // 4)
+            # one scratch per tag: a training forward's token / title lists stay untouched until its backward reads them
+            # (NRMS_FLAG_FWD_SCRATCH_KEPT), whatever inference or user-encoder passes run in between
+            scratch = self._buf(tag + ".scratch16", (nbytes + 3) // 4)
             dp = lambda z: None if z is None else z.data_ptr()
             return _lib.EncoderActs(x=dp(x), qkv=None, attn=None, ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
         x = self._buf(tag + ".x", M * d) if gather else None
@@ -413,6 +415,8 @@ class NRMSEngine:
                                    mask_mode=sv["user_mask_mode"])
         wn, gn = self._weights(flat, "news_encoder"), self._grads(gflat, "news_encoder")
         acts_n = self._acts("news", N * L, True, gather=True, desc=desc_n)
+        if desc_n.precision == _lib.NRMS_PRECISION_FP16:
+            desc_n.flags |= _lib.NRMS_FLAG_FWD_SCRATCH_KEPT     # acts_n.scratch is this step's forward scratch (its own buffer)
         if table_grad_ready is not None:
             desc_n.flags |= _lib.NRMS_FLAG_DEFER_WQKV
         rc = self.lib.nrms_encoder_bwd(C.byref(desc_n), C.byref(wn), _lib.ptr(sv["ids"]), None, None, C.byref(acts_n),

@@ -57,14 +57,17 @@ def _run(case, precision):
     model = make_model(shape, params, precision=precision, fp16_user=case["fp16_user"]).train()
     scores, loss, grads = fwd_bwd(model, batch)
     assert model.engine.pad_row_zero is case["pad_zero"]
-    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads)
+    o_scores, o_loss, o_grads, aux = orc.loss_and_grads(params, batch, shape.num_attention_heads)
     valid = batch["candidate_mask"] == 1
     assert (scores[~valid] == np.float32(-1e9)).all()
     if not valid.any():                                   # (one user whose only candidate is masked: nothing to compare)
         return
     err = float(np.abs(scores - o_scores)[valid].max())
     if precision == "fp16":
-        assert err < score_bar(o_scores[valid], case["fp16_user"]), (case, err)
+        # fp16 error is relative to what a score is made of: sum_f |cand_f user_f| (for MIND-shaped models about the score
+        # itself; for a one-token title or a 24-wide model the terms cancel and a score of 0.2 is built from terms of 1)
+        terms = float(np.abs(aux["cand"] * aux["user"][:, None, :]).sum(-1)[valid].max())
+        assert err < max(score_bar(o_scores[valid], case["fp16_user"]), 1e-3 * terms), (case, err, terms)
         # small models make many gradient tensors cancelling sums: an absolute floor of 1e-4 of the largest tensor's scale
         floor = 1e-4 * max(float(np.abs(v).max()) for v in o_grads.values()) + 2e-6
         _grad_report(grads, o_grads, synth.param_names(), "fuzz", abs_floor=floor)

@@ -213,7 +213,7 @@ def test_engine_scratch_bound_covers_library_sizes_and_flag_validation():
                 assert 0 < need <= 4 * bound_floats, (d, prec, vocab, flags, need, 4 * bound_floats)
                 assert lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(desc)) > 0
     bad = _lib.EncoderDesc(n_seq=1, seq_len=5, d_model=60, n_heads=6, q_dim=32, vocab=10, p_drop_embed=0.0,
-                           p_drop_ctx=0.0, precision=0, flags=4, seed=0)
+                           p_drop_ctx=0.0, precision=0, flags=64, seed=0)
     assert lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(bad)) == 0
     assert b"flags" in lib.nrms_last_error()
 
