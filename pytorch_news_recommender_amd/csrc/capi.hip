@@ -130,10 +130,19 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
                  "%s: unsupported precision %d", who, d->precision);
     if (d->precision == NRMS_PRECISION_FP16) {
         const char* why = nullptr;
-        NRMS_REQUIRE(fused16_supported(d->seq_len, d->d_model, d->n_heads, d->q_dim, &why),
-                     "%s: precision fp16 needs %s (use bf16x3 for this shape)", who, why);
-        NRMS_REQUIRE(d->use_output_proj == 0 && d->mask_mode == 0 && d->p_drop_attn == 0.f,
-                     "%s: precision fp16 supports neither the output projection, masks nor p_drop_attn (use bf16x3)", who);
+        if (d->use_output_proj) {
+            // wide heads + W_O (nrms_v1's news encoder): fused16_v1.hip, padding-skipping path only
+            NRMS_REQUIRE(fused16v1_supported(d->seq_len, d->d_model, d->n_heads, d->q_dim, &why),
+                         "%s: precision fp16 with the output projection needs %s (use bf16x3 for this shape)", who, why);
+            NRMS_REQUIRE(d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO) != 0 && d->p_drop_embed == 0.f,
+                         "%s: precision fp16 with the output projection covers the news encoder with NRMS_FLAG_PAD_ROW_ZERO "
+                         "and no embedding dropout (use bf16x3)", who);
+        } else {
+            NRMS_REQUIRE(fused16_supported(d->seq_len, d->d_model, d->n_heads, d->q_dim, &why),
+                         "%s: precision fp16 needs %s (use bf16x3 for this shape)", who, why);
+        }
+        NRMS_REQUIRE(d->mask_mode == 0 && d->p_drop_attn == 0.f,
+                     "%s: precision fp16 supports neither masks nor p_drop_attn (use bf16x3)", who);
     }
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
     NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV | NRMS_FLAG_FWD_SCRATCH_KEPT)) == 0, "%s: unknown flags 0x%x", who, d->flags);
@@ -224,7 +233,8 @@ static Fwd16Scratch fwd16_scratch(const nrms_encoder_desc* d) {
     const size_t M = (size_t)d->n_seq * d->seq_len;
     const bool gather = d->vocab > 0;
     f.planes = 0;
-    f.live = align_up(fused16_layout(d->d_model, d->n_heads, d->q_dim).total, 256);
+    f.live = align_up(d->use_output_proj ? fused16v1_planes_bytes(d->d_model, d->n_heads, d->q_dim)
+                                         : fused16_layout(d->d_model, d->n_heads, d->q_dim).total, 256);
     f.pos = f.live + (gather ? align_up(M * sizeof(int), 256) : 0);
     f.n_live = f.pos + (gather ? align_up(M * sizeof(int), 256) : 0);
     f.cscr = f.n_live + (gather ? 256 : 0);
@@ -243,7 +253,10 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     const Fwd16Scratch fs = fwd16_scratch(desc);
     const Fused16Layout L = fused16_layout(d, h, q);
     char* base = (char*)acts->scratch;
-    int rc = launch_prep16(d, h, q, w->w_qkv, w->b_qkv, w->w_add, w->b_add, w->q_vec, base + fs.planes, s);
+    const bool v1 = desc->use_output_proj != 0;
+    NRMS_REQUIRE(!v1 || (w->w_o && w->b_o && acts->attn), "encoder_fwd(fp16): use_output_proj needs w_o, b_o and acts.attn");
+    int rc = v1 ? launch_prep16v1(d, h, q, w->w_qkv, w->b_qkv, w->w_o, w->b_o, w->w_add, w->b_add, w->q_vec, base + fs.planes, s)
+                : launch_prep16(d, h, q, w->w_qkv, w->b_qkv, w->w_add, w->b_add, w->q_vec, base + fs.planes, s);
     if (rc) return rc;
     Fused16Fwd f{};
     f.n_seq = desc->n_seq; f.S = S; f.d = d; f.h = h; f.q = q;
@@ -275,7 +288,7 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
         rc = launch_cast16(M, d, L.KP, x, acts->x, s);
         if (rc) return rc;
     }
-    return launch_fused_fwd16(f, s);
+    return v1 ? launch_fused_fwd16v1(f, h, acts->attn, s) : launch_fused_fwd16(f, s);
 }
 
 // ---- fp16 backward workspace: fused16_bwd_layout | live | pos | n_live | compaction scratch | order | order_cnt |
@@ -304,6 +317,7 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
                          const nrms_encoder_acts* acts, const float* dout, const nrms_encoder_grads* grads, float* dx,
                          void* workspace, size_t workspace_bytes, hipStream_t s) {
     NRMS_REQUIRE(w && acts && dout && grads && workspace, "encoder_bwd(fp16): null argument");
+    NRMS_REQUIRE(desc->use_output_proj == 0, "encoder_bwd(fp16): the output projection has a fused fp16 forward only (train it in bf16x3)");
     NRMS_REQUIRE(acts->x && acts->ctx && acts->t && acts->w, "encoder_bwd(fp16): acts.x, ctx, t, w are required");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec, "encoder_bwd(fp16): null gradient buffer");
     const bool gather = desc->vocab > 0;

@@ -348,6 +348,13 @@ struct Fused16Fwd {
     Dropout drop;             // context dropout
 };
 int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream);
+// fused16_v1.hip: the same for heads wider than 32 with the output projection (nrms_v1's news encoder); attn16 =
+// [n_seq][20][32][16] fp16, the head concatenation in the operand order of the W_O tiles
+bool fused16v1_supported(int S, int d, int h, int q, const char** why);
+size_t fused16v1_planes_bytes(int d, int h, int q);
+int launch_prep16v1(int d, int h, int q, const float* w_qkv, const float* b_qkv, const float* w_o, const float* b_o,
+                    const float* w_add, const float* b_add, const float* q_vec, void* planes, hipStream_t stream);
+int launch_fused_fwd16v1(const Fused16Fwd& f, int h, void* attn16, hipStream_t stream);
 // order [n_classes][n_seq] ints, cnt title_order_cnt_ints(n_seq) ints (cnt[0 .. n_classes) = the list sizes).  n_classes 2: titles
 // with a real token | all-padding titles; 3: long | all-padding | short-prefix titles (see fused16.hip)
 size_t title_order_cnt_ints(int n_seq);

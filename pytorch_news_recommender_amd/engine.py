@@ -117,6 +117,8 @@ class NRMSEngine:
         self.fp16_user_encoder = False     # precision "fp16": the user encoder runs in bf16x3 unless this is set
         self.fp16_backward = True          # training in fp16 mode runs the fused fp16 backward (csrc/fused16_bwd.hip)
         self.loss_scale = 0.0              # fp16 backward: 0 = chosen on the device from max |dout| per call (nrms_hip.h)
+        self.fp16_wide_heads = True        # precision "fp16": the W_O + wide-head news encoder (nrms_v1) on csrc/fused16_v1.hip
+        self.fp16_wide_heads_backward = False   # ... its training step too (forward-only kernels so far: training stays bf16x3)
         self._gen = 0                      # generation stamp of _saved (checked by the autograd backward)
         # out-of-range word ids: counted on the device by nrms_sanitize_ids, surfaced without a host sync
         # (the count is copied to pinned memory behind the kernel and looked at on a later call)
@@ -136,6 +138,13 @@ class NRMSEngine:
         h = d.heads(enc)
         if enc == "user_encoder" and not self.fp16_user_encoder:
             return False
+        if d.output_proj:
+            # nrms_v1's news encoder (heads of 33..50 columns + W_O): csrc/fused16_v1.hip, padding-skipping path only
+            dk = d.word_embed_size // h
+            return (enc == "news_encoder" and self.fp16_wide_heads and self.pad_row_zero and not mask_mode
+                    and seq_len <= 32 and d.word_embed_size <= L["d_model"] and d.word_embed_size % 10 == 0
+                    and d.word_embed_size // 10 <= 32 and 32 < dk <= 50 and 3 * h + 1 <= 19 and h * max(dk - 48, 0) <= 16
+                    and d.query_vector_dim <= L["q_dim"] and (not training or self.fp16_wide_heads_backward))
         return (seq_len <= L["seq_len"] and d.word_embed_size <= L["d_model"] and h <= L["n_heads"]
                 and d.word_embed_size // h <= L["d_k"] and d.query_vector_dim <= L["q_dim"]
                 and not d.output_proj and not mask_mode and (not training or self.fp16_backward))
@@ -199,8 +208,9 @@ class NRMSEngine:
             # one scratch per tag: a training forward's token / title lists stay untouched until its backward reads them
             # (NRMS_FLAG_FWD_SCRATCH_KEPT), whatever inference or user-encoder passes run in between
             scratch = self._buf(tag + ".scratch16", (nbytes + 3) // 4)
+            attn = self._buf(tag + ".attn16", Mp * DP, h) if desc.use_output_proj else None   # head concatenation (fused16_v1.hip)
             dp = lambda z: None if z is None else z.data_ptr()
-            return _lib.EncoderActs(x=dp(x), qkv=None, attn=None, ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
+            return _lib.EncoderActs(x=dp(x), qkv=None, attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
         x = self._buf(tag + ".x", M * d) if gather else None
         qkv = self._buf(tag + ".qkv", M * 3 * d)
         attn = self._buf(tag + ".attn", M * d) if self.dims.output_proj else None

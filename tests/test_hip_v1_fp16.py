@@ -1,0 +1,82 @@
+"""precision = "fp16" for nrms_v1's news encoder (model/nrms_v1.py:109-162: heads of 50 columns, W_O, dropout after W_O):
+csrc/fused16_v1.hip against the oracle, at the fp16 mode's bar (north_star: scores within 1e-4 of the reference)."""
+import numpy as np
+import pytest
+import torch
+
+from pytorch_news_recommender_amd import _lib, synth
+from tests.test_hip_fp16 import score_bar
+from tests.test_hip_v1 import make_v1
+
+pytestmark = pytest.mark.gpu
+
+V1_SHAPES = {
+    # res_logs.md:4 / config.py:87-88: 300-wide embeddings, six title heads of 50, ten user heads, 20-word titles
+    "reference": (synth.Shape(n_words=5000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                              batch_size=16, history_len=50, n_candidates=5, n_words_title=20), 6, 1),
+    # 30-word titles: long titles (more than 15 words) next to paired short ones
+    "long_titles": (synth.Shape(n_words=3000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                                batch_size=8, history_len=20, n_candidates=5, n_words_title=30), 6, 5),
+    # heads of 40: no leftover features
+    "dk40": (synth.Shape(n_words=900, word_embed_size=240, num_attention_heads=6, query_vector_dim=64,
+                         batch_size=5, history_len=11, n_candidates=3, n_words_title=17), 6, 2),
+    # four heads of 50 on 200 columns, an odd title length
+    "dk50_h4": (synth.Shape(n_words=700, word_embed_size=200, num_attention_heads=4, query_vector_dim=100,
+                            batch_size=4, history_len=9, n_candidates=4, n_words_title=13), 4, 1),
+}
+
+
+def _news_precision(model, n, L, training):
+    return model.engine._desc("news_encoder", n, L, training=training).precision
+
+
+@pytest.mark.parametrize("case", sorted(V1_SHAPES))
+def test_v1_fp16_forward_against_oracle(case):
+    from oracle import nrms_oracle as orc
+    shape, title_heads, min_title = V1_SHAPES[case]
+    params = synth.make_params_v1(shape, seed=31)
+    batch = synth.make_batch(shape, seed=32, ragged=True, min_title=min_title, all_pad_title=True, mask_some_candidates=True)
+    model = make_v1(shape, params, title_heads, precision="fp16").eval()
+    assert _news_precision(model, 8, shape.n_words_title, False) == _lib.NRMS_PRECISION_FP16     # not the bf16x3 fallback
+    with torch.no_grad():
+        scores = model({k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}).cpu().numpy()
+        nv = model.get_news_vector(torch.from_numpy(batch["browsed_titles"]).reshape(-1, shape.n_words_title)).cpu().numpy()
+    pt = orc.to_torch(orc.v1_to_v0_names(params))
+    with torch.no_grad():
+        o_scores, _ = orc.forward(pt, batch, shape.num_attention_heads, news_heads=title_heads, embed_dropout=False)
+        o_nv = orc.news_encoder(pt, torch.from_numpy(batch["browsed_titles"]).reshape(-1, shape.n_words_title), title_heads,
+                                embed_dropout=False).numpy()
+    verr = float(np.abs(nv - o_nv).max())
+    err = float(np.abs(scores - o_scores.numpy()).max())
+    print("v1 fp16 %s: max |news vector - oracle| = %.3e (max |v| %.2f), max |score - oracle| = %.3e" %
+          (case, verr, float(np.abs(o_nv).max()), err))
+    assert verr < 1.5e-3 * max(1.0, float(np.abs(o_nv).max()))
+    assert err < score_bar(o_scores.numpy())
+
+
+def test_v1_fp16_forward_replays_its_dropout_mask():
+    """Dropout after W_O (nrms_v1.py:161): the kernel's keep mask lives on the padded [tokens, 10 x 32] layout of the
+    projection's output blocks (d / 10 columns each)."""
+    from oracle import nrms_oracle as orc
+    shape, title_heads, _ = V1_SHAPES["reference"]
+    params = synth.make_params_v1(shape, seed=41)
+    batch = synth.make_batch(shape, seed=42, ragged=True, min_title=1, all_pad_title=True)
+    model = make_v1(shape, params, title_heads, dropout=0.2, precision="fp16").train()
+    eng = model.engine
+    tb = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in batch.items()}
+    seed = 0x7654321
+    with torch.no_grad():
+        s = eng.forward(model._flat, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=False,
+                        p_drop=0.2, seed=seed).cpu().numpy()
+    assert _news_precision(model, 8, shape.n_words_title, False) == _lib.NRMS_PRECISION_FP16
+    n_titles = shape.batch_size * (shape.history_len + shape.n_candidates)
+    L, d = shape.n_words_title, shape.word_embed_size
+    kc_pad = eng.dropout_keep_mask(seed, 1, n_titles * L, 0.2, fp16_ctx=True).cpu().numpy()
+    kc = kc_pad.reshape(-1, 10, 32)[:, :, :d // 10].reshape(n_titles, L, d)
+    pt = orc.to_torch(orc.v1_to_v0_names(params))
+    with torch.no_grad():
+        o_scores, _ = orc.forward(pt, batch, shape.num_attention_heads, p_drop=0.2, keep={"ctx": torch.from_numpy(kc)},
+                                  news_heads=title_heads, embed_dropout=False)
+    err = float(np.abs(s - o_scores.numpy()).max())
+    print("v1 fp16 dropout replay: max |score - oracle| = %.3e" % err)
+    assert err < score_bar(o_scores.numpy())
