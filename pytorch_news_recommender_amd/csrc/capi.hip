@@ -300,7 +300,7 @@ static Bwd16Layout bwd16_layout(const nrms_encoder_desc* d) {
     const bool gather = d->vocab > 0;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    L.fused = take(fused16_bwd_layout((long)M, d->n_seq).total);
+    L.fused = take(d->use_output_proj ? fused16v1_bwd_bytes((long)M, d->n_seq, d->n_heads) : fused16_bwd_layout((long)M, d->n_seq).total);
     L.live = take(gather ? M * sizeof(int) : 0);
     L.pos = take(gather ? M * sizeof(int) : 0);
     L.n_live = take(gather ? 256 : 0);
@@ -317,7 +317,9 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
                          const nrms_encoder_acts* acts, const float* dout, const nrms_encoder_grads* grads, float* dx,
                          void* workspace, size_t workspace_bytes, hipStream_t s) {
     NRMS_REQUIRE(w && acts && dout && grads && workspace, "encoder_bwd(fp16): null argument");
-    NRMS_REQUIRE(desc->use_output_proj == 0, "encoder_bwd(fp16): the output projection has a fused fp16 forward only (train it in bf16x3)");
+    const bool v1 = desc->use_output_proj != 0;
+    NRMS_REQUIRE(!v1 || (w->w_o && acts->attn && grads->w_o && grads->b_o),
+                 "encoder_bwd(fp16): use_output_proj needs w_o, acts.attn, grads.w_o, grads.b_o");
     NRMS_REQUIRE(acts->x && acts->ctx && acts->t && acts->w, "encoder_bwd(fp16): acts.x, ctx, t, w are required");
     NRMS_REQUIRE(grads->w_qkv && grads->b_qkv && grads->w_add && grads->b_add && grads->q_vec, "encoder_bwd(fp16): null gradient buffer");
     const bool gather = desc->vocab > 0;
@@ -338,6 +340,7 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     f.loss_scale = desc->loss_scale;           // <= 0: device-side, from max |dout|
     f.drop = make_dropout(desc->seed, desc->p_drop_ctx);
     f.dw_qkv = grads->w_qkv; f.db_qkv = grads->b_qkv; f.dw_add = grads->w_add; f.db_add = grads->b_add; f.dq_vec = grads->q_vec;
+    if (v1) { f.w_o = w->w_o; f.attn16 = acts->attn; f.dw_o = grads->w_o; f.db_o = grads->b_o; }
     int rc;
     int* live = (int*)(base + L.live);
     int* n_live = (int*)(base + L.n_live);
@@ -376,7 +379,7 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     // are complete in stream order, nrms_encoder_bwd_wqkv joins the rest (a data-parallel caller starts the table
     // all-reduce in between)
     f.defer_join = (desc->flags & NRMS_FLAG_DEFER_WQKV) != 0;
-    rc = launch_fused_bwd16(f, s);
+    rc = v1 ? launch_fused_bwd16v1(f, s) : launch_fused_bwd16(f, s);
     if (rc) return rc;
     if (gather) {
         const Dropout drop_e = make_dropout(desc->seed, desc->p_drop_embed);

@@ -14,61 +14,9 @@
 // Replaces autograd through model/nrms_v0.py:13-23,46-76,100-126,154-176,188-199 (`loss.backward()`, train_eval.py:126).
 #include <stdlib.h>
 
-#include "fused16.h"
+#include "fused16_bwd.h"
 
 namespace nrms {
-
-constexpr int B16_RED_QKV = 3 * 10 * 32;                  // d(b_qkv) sums, [tile][32]
-constexpr int B16_RED = B16_RED_QKV + 2 * F16_QP;         // + d(b_add)[QP] + d(q_vec)[QP]
-constexpr int B16_DQ = 96 * 10;                           // dqkv16 row pitch: [head][Q|K|V][32]
-
-struct Bwd16Args {
-    int n_seq, S, d, h, dk, q;
-    int n_groups;               // ceil(n_seq / F16_WAVES) (+1 with an order list)
-    const _Float16* x16;        // [rows][KP]
-    const int* pos;             // token -> x16 / dqkv16 row, -1 = padding token; null: row = token
-    const int* n_rows;          // device: number of compact rows (with pos); x16 row *n_rows is the padding token's row
-    const int64_t* ids;         // non-null: all-padding titles take the closed form
-    const int* order;           // [n_cls][n_seq] title lists of launch_title_order (null: titles in index order)
-    const int* order_cnt;
-    int n_cls;                  // 2: titles with a real token | all-padding titles.  3: long | all-padding | short titles -- then
-                                // the pooling kernel hands the attention kernel the d(ctx) of a short title COMPRESSED to its
-                                // n + 1 tile rows (the padding tokens' rows summed into one) and the attention kernel puts
-                                // two short titles into one 32-row tile, as the forward does (fused16.hip, fused_fwd16p_kernel)
-    const _Float16* btiles;     // [4h][32][KP]: the h tiles Wadd_h^T (32 features x QP), then per head W'_q | W_k | W_v
-    const float* bqkv32;        // [3h][32]
-    const _Float16* qv16;       // [QP]
-    const _Float16* ctx16;      // [n_seq*S][DP]   (forward)
-    const _Float16* t16;        // [n_seq*S][QP]   (forward)
-    const float* w;             // [n_seq*S]       (forward)
-    const _Float16* dout16;     // [n_seq][DP]  x loss scale, P16 order
-    _Float16* dz16;             // [n_seq*S][QP]
-    _Float16* dctx16;           // [n_seq*S][DP]  d(ctx) after the dropout mask, P16 order (written and re-read per wave)
-    _Float16* dqkv16;           // [rows][B16_DQ]
-    float* red;                 // [gridDim.x][B16_RED] per-workgroup column sums (reduced afterwards, fixed order)
-    Dropout drop;
-    int dbg;                    // timing experiments only (NRMS_F16_DBG): 4 = no dZ16 / d(ctx)16 stores, 8 = no d(ctx) products
-};
-
-// X^T for a 32x32 accumulator X: one product with the k-permuted identity (idf[s][j] = (n == row held as element j))
-__device__ __forceinline__ f32x16 transpose32(const f32x16& x, const h8 (&idf)[2]) {
-    f32x16 z = mfma32h(acc_frag(x, 0), idf[0], zero16());
-    return mfma32h(acc_frag(x, 1), idf[1], z);
-}
-
-// sum over the 16 rows a lane holds
-__device__ __forceinline__ float regsum(const f32x16& x) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { s0 += x[4 * g]; s1 += x[4 * g + 1]; s2 += x[4 * g + 2]; s3 += x[4 * g + 3]; }
-    return (s0 + s1) + (s2 + s3);
-}
-
-// X^T from the two operand fragments of X (rows of X = k): one product with the k-permuted identity per fragment
-__device__ __forceinline__ f32x16 transpose_frags(const h8& x0, const h8& x1, const h8 (&idf)[2]) {
-    f32x16 z = mfma32h(x0, idf[0], zero16());
-    return mfma32h(x1, idf[1], z);
-}
 
 // SB = 32-row blocks per sequence (1: titles / short histories, two workgroups per CU; 2: sequences of up to 64 rows, one
 // workgroup per CU with up to 512 registers per lane) -- see fused16.hip.
@@ -272,6 +220,11 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
                         for (int e = 0; e < 8; ++e) dct[8 * c + e] *= sc[e];
                     }
+                }
+                if (a.v1 && valid && (!live || (nshort >= 0 && l32 >= 16))) {
+                    _Float16* dcrow = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
+                    *reinterpret_cast<h8*>(dcrow) = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                    *reinterpret_cast<h8*>(dcrow + 512) = h8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
                 if (live && !F16_DBG(a.dbg, 4)) {                     // (zero beyond the sequence: dZ and w are 0 there); the
                     // attention kernel reads the rows of titles with a real token only
@@ -750,22 +703,6 @@ __global__ __launch_bounds__(256) void prep16b_kernel(Prep16bArgs a) {
 // output columns of one row per register quad, stored as 16 bytes (a quarter of the store instructions of the row-in-registers
 // form).  (Round 2's kernel -- one wave per 32 rows, weights through a register-staged ring, A fragments straight from
 // global -- ran at 0.37 ms: every tile step exposed a global-load latency.)
-constexpr int DX_BM = 256, DX_BK = 64, DX_THREADS = 512;
-constexpr int DX_SLABS = B16_DQ / DX_BK;                    // 15
-constexpr int DX_A_BYTES = DX_BM * DX_BK * 2;               // 32 KB
-constexpr int DX_B_BYTES = DX_BK * F16_KP * 2;              // 40 KB
-constexpr int DX_SLOT = DX_A_BYTES + DX_B_BYTES;
-static_assert(B16_DQ % DX_BK == 0 && F16_KP == 320, "15 slabs of 64; 10 column tiles of 32");
-struct Dx16Args {
-    int M;                    // upper bound of the rows (sizes the grid)
-    const int* m_dev;         // rows actually present (device), or null
-    const _Float16* a16;      // [rows][B16_DQ]
-    const _Float16* xtiles;   // [DX_SLABS][4][10][2][32][8]
-    float* c;                 // [rows][ldc] fp32 (scale removed) -- or OUT16: fp16 [rows][F16_KP], still multiplied by the scale
-    int ldc, d;
-    const float* sc;          // device: {loss scale, 1 / loss scale}
-};
-
 template <bool OUT16>
 __global__ __launch_bounds__(DX_THREADS, 2) void gemm16_dx_kernel(Dx16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -785,7 +722,7 @@ __global__ __launch_bounds__(DX_THREADS, 2) void gemm16_dx_kernel(Dx16Args a) {
     for (int i = 0; i < 4; ++i) {
         const int r = 8 * (wave + 8 * i) + (lane >> 3);
         const int piece = (lane & 7) ^ ((r >> 1) & 7);
-        asrc[i] = reinterpret_cast<const char*>(a.a16 + (long)min(row0 + r, M - 1) * B16_DQ) + piece * 16;
+        asrc[i] = reinterpret_cast<const char*>(a.a16 + (long)min(row0 + r, M - 1) * a.lda) + piece * 16;
     }
     const char* bsrc = reinterpret_cast<const char*>(a.xtiles) + wave * 1024 + lane * 16;
     auto issue = [&](int slab, int slot) {
@@ -818,8 +755,8 @@ __global__ __launch_bounds__(DX_THREADS, 2) void gemm16_dx_kernel(Dx16Args a) {
     issue(0, 0);
     __asm__ volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll 1
-    for (int slab = 0; slab < DX_SLABS; ++slab) {
-        if (slab + 1 < DX_SLABS) issue(slab + 1, (slab + 1) & 1);
+    for (int slab = 0; slab < a.n_slabs; ++slab) {
+        if (slab + 1 < a.n_slabs) issue(slab + 1, (slab + 1) & 1);
         const char* st = smem + (slab & 1) * DX_SLOT;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1043,12 +980,12 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
 
 // dW[nmap[n]][kmap[k]] += scale[n] * sum_splits partial[.][n][k]   (maps: -1 = padding, dropped)
 __global__ void tn16_reduce_kernel(const float* partial, int splits, int N, int K, const int* nmap, const int* kmap,
-                                   const float* nscale, int ldw, float* dW) {
+                                   const float* nscale, int ldw, float* dW, float* dbias) {
     const long total = (long)N * K;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int n = (int)(idx / K), k = (int)(idx - (long)n * K);
         const int nd = nmap[n], kd = kmap[k];
-        if (nd < 0 || kd < 0) continue;
+        if (nd < 0 || kd == -1 || (kd < 0 && dbias == nullptr)) continue;       // kd -2: the operand's ones column = the bias gradient
         const float* pp = partial + idx;
         // eight independent partial sums: eight loads in flight per thread (two made this kernel latency-bound); the
         // association is fixed, so the result is reproducible
@@ -1059,7 +996,9 @@ __global__ void tn16_reduce_kernel(const float* partial, int splits, int N, int 
             for (int u = 0; u < 8; ++u) s[u] += pp[(long)(sp + u) * total];
         }
         for (; sp < splits; ++sp) s[0] += pp[(long)sp * total];
-        dW[(long)nd * ldw + kd] += (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * nscale[n];
+        const float tot = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) * nscale[n];
+        if (kd >= 0) dW[(long)nd * ldw + kd] += tot;
+        else dbias[nd] += tot;
     }
 }
 
@@ -1169,17 +1108,19 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
     return L;
 }
 
-static int launch_tn16(bool frag_layout, const _Float16* A, int lda, int N, const _Float16* B, int ldb, int K, int M, const int* m_dev,
-                       float* partial, int splits, const int* nmap, const int* kmap, const float* nscale, int ldw, float* dW,
-                       hipStream_t stream, const char* name) {
+int launch_tn16(int geom, const _Float16* A, int lda, int N, const _Float16* B, int ldb, int K, int M, const int* m_dev,
+                float* partial, int splits, const int* nmap, const int* kmap, const float* nscale, int ldw, float* dW,
+                hipStream_t stream, const char* name, float* dbias) {
     Tn16Args t{};
     t.M = M; t.m_dev = m_dev; t.A = A; t.lda = lda; t.N = N; t.B = B; t.ldb = ldb; t.K = K; t.partial = partial;
-    // fragment-order operands = the additive product (one 224 x 320 block), row-major = the Q|K|V product (320 x 160 blocks)
+    // geom 1 (fragment-order operands, one 224 x 320 block) = the additive product; 0 (row-major, 320 x 160 blocks) = the
+    // Q|K|V product; 2 (fragment order, 320 x 160 blocks) = d(W_O) of nrms_v1
     typedef void (*Kern)(Tn16Args);
-    const Kern fn = frag_layout ? (Kern)gemm16_tn_kernel<true, 2, 7, 4, 5> : (Kern)gemm16_tn_kernel<false, 4, 5, 2, 5>;
-    const int aw = frag_layout ? Tn16Add::AW : Tn16Qkv::AW, bw = frag_layout ? Tn16Add::BW : Tn16Qkv::BW;
+    const Kern fn = geom == 1 ? (Kern)gemm16_tn_kernel<true, 2, 7, 4, 5> : geom == 2 ? (Kern)gemm16_tn_kernel<true, 4, 5, 2, 5>
+                                                                                     : (Kern)gemm16_tn_kernel<false, 4, 5, 2, 5>;
+    const int aw = geom == 1 ? Tn16Add::AW : Tn16Qkv::AW, bw = geom == 1 ? Tn16Add::BW : Tn16Qkv::BW;
     t.splits = splits; t.n_blk = cdiv(N, aw); t.k_blk = cdiv(K, bw);
-    const size_t lds = 2 * (size_t)(frag_layout ? Tn16Add::STAGE : Tn16Qkv::STAGE);
+    const size_t lds = 2 * (size_t)(geom == 1 ? Tn16Add::STAGE : Tn16Qkv::STAGE);
     const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return NRMS_ELAUNCH; }
     {
@@ -1190,8 +1131,49 @@ static int launch_tn16(bool frag_layout, const _Float16* A, int lda, int N, cons
     if (rc) return rc;
     TimingScope ts("tn_reduce", stream);
     hipLaunchKernelGGL(tn16_reduce_kernel, dim3(cdiv((long)N * K, 256)), dim3(256), 0, stream, partial, splits, N, K, nmap, kmap,
-                       nscale, ldw, dW);
+                       nscale, ldw, dW, dbias);
     return check_launch("tn16_reduce");
+}
+
+size_t bwd16_fused_lds(bool two) {
+    // ring + column sums + the per-wave staging rows of the atomic-free reductions (the pooling kernel's are the larger)
+    static_assert(F16_WAVES * 2 * F16_QT * 32 + 2 * F16_WAVES * 32 >= 2 * F16_WAVES * 3 * 32, "the attention kernel's staging fits the same size");
+    return (size_t)3 * F16_SLOT + (size_t)B16_RED * 4 + (size_t)(F16_WAVES * (two ? 2 : 1) * 2 * F16_QT * 32 + 2 * F16_WAVES * 32) * 4;
+}
+
+int launch_bwd16_pool(const Bwd16Args& a, int n_wg, bool two, hipStream_t stream) {
+    const size_t lds = bwd16_fused_lds(two);
+    const void* fp = two ? (const void*)fused_bwd16_pool_kernel<2> : (const void*)fused_bwd16_pool_kernel<1>;
+    const hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("fused_bwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    TimingScope ts(two ? "fused64_bwd16_pool" : "fused_bwd16_pool", stream);
+    if (two) hipLaunchKernelGGL(fused_bwd16_pool_kernel<2>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL(fused_bwd16_pool_kernel<1>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+    return check_launch("fused_bwd16_pool");
+}
+
+int launch_dx16(const Dx16Args& g, bool out16, hipStream_t stream) {
+    if ((g.d & 3) != 0 || ((uintptr_t)g.c & 15) != 0) { set_error("gemm16_dx: dx must be 16-byte aligned, d %% 4 == 0"); return NRMS_EINVAL; }
+    const size_t lds = (size_t)2 * DX_SLOT;
+    const void* fn = out16 ? (const void*)gemm16_dx_kernel<true> : (const void*)gemm16_dx_kernel<false>;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("gemm16_dx: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
+    TimingScope ts("dx_bwd", stream);
+    if (out16) hipLaunchKernelGGL(gemm16_dx_kernel<true>, dim3(cdiv(g.M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
+    else hipLaunchKernelGGL(gemm16_dx_kernel<false>, dim3(cdiv(g.M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
+    return check_launch("gemm16_dx");
+}
+
+int launch_dout16(long n_seq, int d, int h, int dk, float fixed_scale, float* sc, const float* dout, _Float16* dout16, hipStream_t stream) {
+    unsigned* max_bits = (unsigned*)(sc + 2);
+    // loss scale: from max |dout| on the device unless the caller fixed it (fixed_scale > 0)
+    if (hipMemsetAsync(max_bits, 0, sizeof(unsigned), stream) != hipSuccess) { set_error("fused_bwd16: memset failed"); return NRMS_ELAUNCH; }
+    const long nd = n_seq * d;
+    if (!(fixed_scale > 0.f))
+        hipLaunchKernelGGL(absmax_kernel, dim3(nd > 1024L * 1024 ? 1024 : (int)cdiv(nd, 1024)), dim3(256), 0, stream, nd, dout, max_bits);
+    hipLaunchKernelGGL(dout16_kernel, dim3(cdiv(n_seq * F16_DP, 256) > 4096 ? 4096 : cdiv(n_seq * F16_DP, 256)),
+                       dim3(256), 0, stream, n_seq, d, h, dk, fixed_scale, max_bits, sc, dout, dout16);
+    return check_launch("dout16");
 }
 
 int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
@@ -1218,7 +1200,6 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     int* kmap_ctx = (int*)(nscale_add + F16_QP);
     float* sc = (float*)(base + L.scale);                      // device: {scale, 1 / scale}
     if (f.sc_out != nullptr) *f.sc_out = sc;
-    unsigned* max_bits = (unsigned*)(sc + 2);
     float* partial_qkv = (float*)(base + L.partial);
     float* partial_add = (float*)(base + L.partial + up256((size_t)L.tn_splits_qkv * B16_DQ * F16_KP * 4));
     { const int jr = fused_bwd16_join(stream); if (jr) return jr; }      // an un-joined earlier call on this stream: order it first
@@ -1234,13 +1215,8 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         p.btiles = btiles; p.xtiles = xtiles; p.qv16 = qv16; p.bqkv32 = bqkv32;
         TimingScope ts("prep16", stream);
         hipLaunchKernelGGL(prep16b_kernel, dim3(2048), dim3(256), 0, stream, p);
-        // loss scale: from max |dout| on the device unless the caller fixed it (f.loss_scale > 0)
-        if (hipMemsetAsync(max_bits, 0, sizeof(unsigned), stream) != hipSuccess) { set_error("fused_bwd16: memset failed"); return NRMS_ELAUNCH; }
-        const long nd = (long)f.n_seq * f.d;
-        if (!(f.loss_scale > 0.f))
-            hipLaunchKernelGGL(absmax_kernel, dim3(nd > 1024L * 1024 ? 1024 : (int)cdiv(nd, 1024)), dim3(256), 0, stream, nd, f.dout, max_bits);
-        hipLaunchKernelGGL(dout16_kernel, dim3(cdiv((long)f.n_seq * F16_DP, 256) > 4096 ? 4096 : cdiv((long)f.n_seq * F16_DP, 256)),
-                           dim3(256), 0, stream, (long)f.n_seq, f.d, f.h, dk, f.loss_scale, max_bits, sc, f.dout, dout16);
+        int rc0 = launch_dout16((long)f.n_seq, f.d, f.h, dk, f.loss_scale, sc, f.dout, dout16, stream);
+        if (rc0) return rc0;
         hipLaunchKernelGGL(maps16_kernel, dim3(cdiv(B16_DQ, 256)), dim3(256), 0, stream, f.d, f.h, dk, f.q, sc, qscale,
                            nmap_qkv, nscale_qkv, kmap_x, nmap_add, nscale_add, kmap_ctx);
         int rc = check_launch("prep16b");
@@ -1261,25 +1237,19 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     const int n_wg = a.n_groups < L.n_wg ? a.n_groups : L.n_wg;
     {
         const bool two = f.S > 32;
-        // ring + column sums + the per-wave staging rows of the atomic-free reductions (the pooling kernel's are the larger)
-        const size_t lds = (size_t)3 * F16_SLOT + (size_t)B16_RED * 4 +
-                           (size_t)(F16_WAVES * (two ? 2 : 1) * 2 * F16_QT * 32 + 2 * F16_WAVES * 32) * 4;
-        static_assert(F16_WAVES * 2 * F16_QT * 32 + 2 * F16_WAVES * 32 >= 2 * F16_WAVES * 3 * 32, "the attention kernel's staging fits the same size");
-        const void* fp = two ? (const void*)fused_bwd16_pool_kernel<2> : (const void*)fused_bwd16_pool_kernel<1>;
+        const size_t lds = bwd16_fused_lds(two);
         const void* fa = two ? (const void*)fused_bwd16_attn_kernel<2> : (const void*)fused_bwd16_attn_kernel<1>;
-        hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("fused_bwd16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
         {
-            TimingScope ts(two ? "fused64_bwd16_pool" : "fused_bwd16_pool", stream);
-            if (two) hipLaunchKernelGGL(fused_bwd16_pool_kernel<2>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
-            else hipLaunchKernelGGL(fused_bwd16_pool_kernel<1>, dim3(n_wg), dim3(F16_THREADS), lds, stream, a);
+            const int rcp = launch_bwd16_pool(a, n_wg, two, stream);
+            if (rcp) return rcp;
         }
         if (side) {
             // d(W_add)[q][f] = sum_tok dZ[tok][q] ctx[tok][f] needs only the pooling kernel's dZ16: beside the attention kernel
             int rc = side_order(ss, 0, stream, s_add, "fused_bwd16");
             if (rc) return rc;
-            rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
+            rc = launch_tn16(1, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
                              L.tn_splits_add, nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, s_add, "dwadd_bwd");
             if (rc) return rc;
             if (hipEventRecord(ss->ev[2], s_add) != hipSuccess) { set_error("fused_bwd16: hipEventRecord failed"); return NRMS_ELAUNCH; }
@@ -1303,7 +1273,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     }
     int rc = NRMS_OK;
     if (!side) {
-        rc = launch_tn16(true, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
+        rc = launch_tn16(1, dz16, F16_QP, F16_QP, (const _Float16*)f.ctx16, F16_DP, F16_DP, Mp, nullptr, partial_add,
                          L.tn_splits_add, nmap_add, kmap_ctx, nscale_add, f.d, f.dw_add, stream, "dwadd_bwd");
         if (rc) return rc;
     }
@@ -1312,7 +1282,7 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
         rc = side_order(ss, 1, stream, s_qkv, "fused_bwd16");
         if (rc) return rc;
     }
-    rc = launch_tn16(false, dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial_qkv,
+    rc = launch_tn16(0, dqkv16, B16_DQ, B16_DQ, (const _Float16*)f.x16, F16_KP, F16_KP, (int)M, f.n_rows_dev, partial_qkv,
                      L.tn_splits_qkv, nmap_qkv, kmap_x, nscale_qkv, f.d, f.dw_qkv, s_qkv, "dwqkv_bwd");
     if (rc) return rc;
     if (side && hipEventRecord(ss->ev[3], s_qkv) != hipSuccess) { set_error("fused_bwd16: hipEventRecord failed"); return NRMS_ELAUNCH; }
@@ -1320,16 +1290,8 @@ int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream) {
     {
         Dx16Args g{};
         g.M = (int)M; g.m_dev = f.n_rows_dev; g.a16 = dqkv16; g.xtiles = xtiles; g.c = f.dx; g.ldc = f.d; g.d = f.d;
-        g.sc = sc;
-        if ((f.d & 3) != 0 || ((uintptr_t)f.dx & 15) != 0) { set_error("gemm16_dx: dx must be 16-byte aligned, d %% 4 == 0"); return NRMS_EINVAL; }
-        const size_t lds = (size_t)2 * DX_SLOT;
-        const void* fn = f.dx_fp16 ? (const void*)gemm16_dx_kernel<true> : (const void*)gemm16_dx_kernel<false>;
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("gemm16_dx: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
-        TimingScope ts("dx_bwd", stream);
-        if (f.dx_fp16) hipLaunchKernelGGL(gemm16_dx_kernel<true>, dim3(cdiv(M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
-        else hipLaunchKernelGGL(gemm16_dx_kernel<false>, dim3(cdiv(M, DX_BM)), dim3(DX_THREADS), lds, stream, g);
-        rc = check_launch("gemm16_dx");
+        g.sc = sc; g.lda = B16_DQ; g.n_slabs = DX_SLABS;
+        rc = launch_dx16(g, f.dx_fp16, stream);
     }
     if (side && rc == NRMS_OK) {                                    // join: the caller's stream continues after both GEMMs
         if (f.defer_join) ss->pending = true;                       // ... or later, in fused_bwd16_join

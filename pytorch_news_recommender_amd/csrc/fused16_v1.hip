@@ -17,25 +17,9 @@
 // Covered: the padding-skipping path (NRMS_FLAG_PAD_ROW_ZERO), seq_len <= 32, d <= 316 with d / hv <= 32 for hv = 10 output
 // blocks, 32 < d_k <= 50 with h (d_k - 48) <= 16 leftover features and 3 h + 1 <= 19 k-steps -- the reference's v1
 // configuration (config.py:87-88: six title heads of 50 on 300-wide embeddings).  Anything else stays on the bf16x3 kernels.
-#include "fused16.h"
+#include "fused16_v1.h"
 
 namespace nrms {
-
-struct V1Geom {
-    int d, h, dk, hv, dkv;      // model width, attention heads, d_k; output blocks ("virtual heads") and their width
-    int kl, lo;                 // k-step of the leftover features, leftover features per head (d_k - 48, >= 0)
-    int n_head_tiles;           // 6 h
-};
-
-__host__ __device__ inline V1Geom v1_geom(int d, int h) {
-    V1Geom g;
-    g.d = d; g.h = h; g.dk = d / h;
-    g.hv = 10; g.dkv = d / 10;
-    g.kl = 3 * h;
-    g.lo = g.dk > 48 ? g.dk - 48 : 0;
-    g.n_head_tiles = 6 * h;
-    return g;
-}
 
 bool fused16v1_supported(int S, int d, int h, int q, const char** why) {
     const char* w = nullptr;
@@ -48,17 +32,6 @@ bool fused16v1_supported(int S, int d, int h, int q, const char** why) {
     if (why) *why = w;
     return w == nullptr;
 }
-
-// column (0 .. 319) of attn feature fh of head hd in the stored / operand order of attn16
-__host__ __device__ inline int v1_attn_col(const V1Geom& g, int hd, int fh) {
-    if (fh < 48) {
-        const int t = fh & 15;
-        const int p = 8 * ((t >> 2) & 1) + (((t >> 3) << 2) | (t & 3));         // P16 order inside a k-step (acc_frag's order)
-        return 16 * (3 * hd + (fh >> 4)) + p;
-    }
-    return 16 * g.kl + g.lo * hd + (fh - 48);
-}
-constexpr int V1_ONES_COL = 16 * 19;        // k-step 19, position 0: the ones column (bias of W_O)
 
 // ---- planes: [6 h head tiles | hv W_O tiles | 7 additive tiles] (each 32 x 320 fp16 in DMA order), boeff32, badd32, qv32
 struct Fused16V1Layout { size_t tiles, boeff32, badd32, qv32, total; int n_tiles; };
@@ -385,6 +358,9 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
             }
         };
         if (skip_heads) {
+            if (TRAIN && valid) {                                   // d(W_O) contracts attn16 with d(ctx)16 over ALL rows (zeros here)
+                for (int ks = 0; ks < F16_CS; ++ks) *reinterpret_cast<h8*>(a.attn16 + frag_off((long)sq, F16_CS, ks, l32, hh)) = z8;
+            }
 #pragma unroll 1
             for (int j = 0; j < g.hv; ++j) {
                 f32x16 cx = rows_of(a.boeff32 + 32 * j, hh);          // all-padding title: W_O b_v + b_o in every row

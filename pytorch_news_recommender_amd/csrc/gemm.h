@@ -385,8 +385,14 @@ struct Fused16Bwd {
     const float** sc_out;     // receives the device address of {scale, 1 / scale} (optional)
     bool defer_join;          // leave the two weight-gradient GEMMs running on their helper streams when the call returns
                               // (dx is complete in stream order); fused_bwd16_join() orders them before later work
+    // nrms_v1's news encoder (launch_fused_bwd16v1): the output projection, the forward's head concatenation, their gradients
+    const float* w_o; const void* attn16; float* dw_o; float* db_o;
 };
 int launch_fused_bwd16(const Fused16Bwd& f, hipStream_t stream);
+// fused16_v1_bwd.hip: the backward of fused16_v1.hip (needs pos / ids / order: the padding-skipping path); workspace =
+// fused16v1_bwd_bytes(M, n_seq, h) bytes
+size_t fused16v1_bwd_bytes(long M, int n_seq, int h);
+int launch_fused_bwd16v1(const Fused16Bwd& f, hipStream_t stream);
 int fused_bwd16_join(hipStream_t stream);
 
 // embed.hip

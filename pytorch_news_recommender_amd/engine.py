@@ -118,7 +118,7 @@ class NRMSEngine:
         self.fp16_backward = True          # training in fp16 mode runs the fused fp16 backward (csrc/fused16_bwd.hip)
         self.loss_scale = 0.0              # fp16 backward: 0 = chosen on the device from max |dout| per call (nrms_hip.h)
         self.fp16_wide_heads = True        # precision "fp16": the W_O + wide-head news encoder (nrms_v1) on csrc/fused16_v1.hip
-        self.fp16_wide_heads_backward = False   # ... its training step too (forward-only kernels so far: training stays bf16x3)
+        self.fp16_wide_heads_backward = True    # ... its training step too (csrc/fused16_v1_bwd.hip); False: training in bf16x3
         self._gen = 0                      # generation stamp of _saved (checked by the autograd backward)
         # out-of-range word ids: counted on the device by nrms_sanitize_ids, surfaced without a host sync
         # (the count is copied to pinned memory behind the kernel and looked at on a later call)

@@ -80,3 +80,50 @@ def test_v1_fp16_forward_replays_its_dropout_mask():
     err = float(np.abs(s - o_scores.numpy()).max())
     print("v1 fp16 dropout replay: max |score - oracle| = %.3e" % err)
     assert err < score_bar(o_scores.numpy())
+
+
+# ---- training: csrc/fused16_v1_bwd.hip --------------------------------------------------------------------------------
+GRAD_REL, GRAD_ABS = 4e-3, 2e-6           # as tests/test_hip_fp16.py: relative to each tensor's scale
+
+
+def _v1_grad_report(grads, o_grads, back, tag):
+    for v0name, r in o_grads.items():
+        r = np.asarray(r)
+        got = np.asarray(grads[back[v0name]])
+        scale, err = float(np.abs(r).max()), float(np.abs(got - r).max())
+        print("   %-10s %-62s scale %.2e  max err %.2e  (%.1e of scale)" % (tag, v0name, scale, err, err / (scale + 1e-30)))
+        floor = GRAD_ABS
+        if "news_encoder" in v0name and v0name.endswith("W_K.bias"):
+            # analytically zero: the rounding noise of cancelling dK terms, which scale like d(W_Q.bias)
+            floor = max(floor, GRAD_REL * float(np.abs(np.asarray(o_grads[v0name.replace("W_K", "W_Q")])).max()))
+        assert err <= GRAD_REL * scale + floor, (tag, v0name, err, scale)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+@pytest.mark.parametrize("case", sorted(V1_SHAPES))
+def test_v1_fp16_forward_backward_against_oracle(case, p_drop):
+    from oracle import nrms_oracle as orc
+    from tests.test_hip_v1 import fwd_bwd
+    shape, title_heads, min_title = V1_SHAPES[case]
+    params = synth.make_params_v1(shape, seed=51)
+    batch = synth.make_batch(shape, seed=52, ragged=True, min_title=min_title, all_pad_title=True, mask_some_candidates=True)
+    model = make_v1(shape, params, title_heads, dropout=p_drop, precision="fp16").train()
+    assert _news_precision(model, 8, shape.n_words_title, True) == _lib.NRMS_PRECISION_FP16      # the fused backward, not bf16x3
+    scores, loss, grads = fwd_bwd(model, batch)
+    keep = None
+    if p_drop > 0:
+        sv = model.engine._saved
+        n_titles = shape.batch_size * (shape.history_len + shape.n_candidates)
+        L, d = shape.n_words_title, shape.word_embed_size
+        kc = model.engine.dropout_keep_mask(sv["seed"], 1, n_titles * L, p_drop, fp16_ctx=True).cpu().numpy()
+        keep = {"ctx": torch.from_numpy(kc.reshape(-1, 10, 32)[:, :, :d // 10].reshape(n_titles, L, d).copy())}
+    v0 = orc.v1_to_v0_names(params)
+    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(v0, batch, shape.num_attention_heads, p_drop=p_drop, keep=keep,
+                                                      news_heads=title_heads, embed_dropout=False)
+    valid = batch["candidate_mask"] == 1
+    err = float(np.abs(scores - o_scores)[valid].max())
+    print("v1 fp16 train %s p=%.1f: max |score - oracle| = %.3e, |loss diff| %.2e" % (case, p_drop, err, abs(loss - o_loss)))
+    assert err < score_bar(o_scores[valid])
+    back = {v: k for k, v in zip(params.keys(), v0.keys())}
+    _v1_grad_report(grads, o_grads, back, case)
+    assert not grads[back["news_encoder.word_embedding.0.weight"]][0].any()
