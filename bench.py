@@ -262,25 +262,32 @@ def v1_leg(dev, B):
     """SURVEY a-3' / f-3: one nrms_v1 train step (model/nrms_v1.py: W_O, per-encoder heads, candidate mask; like the
     reference's forward, nrms_v1.py:286, the model applies no attention mask -- the masked primitives are tested apart) with
     the reference's v1 configuration (config.py: 20-word titles, 6 title heads of 50 / 10 user heads of 30), dropout 0.2,
-    in the bf16x3 mode (the fused fp16 kernels cover the v0 topology only)."""
+    in the fp16 mode (csrc/fused16_v1.hip + fused16_v1_bwd.hip for the news encoder; the user encoder in bf16x3 as in the
+    headline configuration) and, beside it, with both encoders in bf16x3."""
     from pytorch_news_recommender_amd.model.nrms_v1_hip import Model as V1Model
     shape = synth.Shape(n_words=synth.BENCH.n_words, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                         batch_size=B, history_len=50, n_candidates=5, n_words_title=20)
-    cfg = Config("nrms_v1")
-    cfg.__nrms__()
-    cfg.num_attention_heads, cfg.title_heads_num = 10, 6
-    cfg.dropout, cfg.learning_rate, cfg.precision = 0.2, 1e-3, "bf16x3"
     params = synth.make_params_v1(shape, seed=0)
-    m = V1Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
-    m = m.to(dev).train()
     batch = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch(shape, seed=1, batch_size=B).items()}
-    for _ in range(2):
-        m.train_step(batch)
-    n = 5
-    t = timed(lambda: m.train_step(batch), n)
-    return {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n, "precision": "bf16x3",
-            "workload": "B=%d, H=50, C=5, title 20 words, d=300, 6 title heads / 10 user heads, W_O, candidate mask" % B}
+    res = {}
+    for prec in ("fp16", "bf16x3"):
+        cfg = Config("nrms_v1")
+        cfg.__nrms__()
+        cfg.num_attention_heads, cfg.title_heads_num = 10, 6
+        cfg.dropout, cfg.learning_rate, cfg.precision = 0.2, 1e-3, prec
+        m = V1Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        m = m.to(dev).train()
+        for _ in range(2):
+            m.train_step(batch)
+        n = 5
+        t = timed(lambda: m.train_step(batch), n)
+        res[prec] = {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n}
+        del m
+    out = dict(res["fp16"])
+    out.update({"precision": "fp16", "bf16x3": res["bf16x3"],
+                "workload": "B=%d, H=50, C=5, title 20 words, d=300, 6 title heads / 10 user heads, W_O, candidate mask" % B})
+    return out
 
 
 def main():
