@@ -108,16 +108,7 @@ __global__ __launch_bounds__(256) void prep16v1_kernel(Prep16V1Args a) {
             if (qq < a.q && f < g.dkv && head < g.hv) v = a.w_add[(long)qq * g.d + head * g.dkv + f];
             a.tiles[((long)g.n_head_tiles + g.hv + (qq >> 5)) * 32 * KP + dma_tile_pos(qq & 31, p)] = (_Float16)v;
         } else if (i < n1 + n2 + n3 + n4) {
-            // the pre-dropout context row of an all-padding title: W_O b_v + b_o, per output block
-            const long jx = i - n1 - n2 - n3;
-            const int f = (int)(jx & 31), j = (int)(jx >> 5);
-            float v = 0.f;
-            if (f < g.dkv) {
-                const int o = j * g.dkv + f;
-                v = a.b_o[o];
-                for (int c = 0; c < g.d; ++c) v += a.w_o[(long)o * g.d + c] * a.b_qkv[2 * g.d + c];
-            }
-            a.boeff32[jx] = v;
+            // (boeff32: boeff16v1_kernel)
         } else if (i < n1 + n2 + n3 + n4 + n5) {
             const long jx = i - n1 - n2 - n3 - n4;
             a.badd32[jx] = jx < a.q ? a.b_add[jx] * 2.885390082f : 0.f;
@@ -126,6 +117,22 @@ __global__ __launch_bounds__(256) void prep16v1_kernel(Prep16V1Args a) {
             a.qv32[jx] = jx < a.q ? a.q_vec[jx] : 0.f;
         }
     }
+}
+
+// the pre-dropout context row of an all-padding title: W_O b_v + b_o per output block; one wave per output feature
+__global__ __launch_bounds__(256) void boeff16v1_kernel(V1Geom g, const float* w_o, const float* b_o, const float* b_qkv, float* boeff32) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // idx = 32 j + f
+    if (idx >= g.hv * 32) return;
+    const int j = idx >> 5, f = idx & 31;
+    float v = 0.f;
+    if (f < g.dkv) {
+        const int o = j * g.dkv + f;
+        for (int c = lane; c < g.d; c += 64) v += w_o[(long)o * g.d + c] * b_qkv[2 * g.d + c];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+        v += b_o[o];
+    }
+    if (lane == 0) boeff32[idx] = v;
 }
 
 struct Fwd16V1Args {
@@ -223,13 +230,11 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
 #pragma unroll
     for (int i = 0; i < 2; ++i) tok_ok[i] = val[i] && l32 < S;
 
-    // ---- tile steps: 6 h head tiles (not for all-padding titles), then per title the hv W_O tiles (not for all-padding titles)
-    // and the 7 additive tiles
-    const int n_head_steps = skip_heads ? 0 : g.n_head_tiles;
-    const int pass_len = skip_heads ? F16_QT : g.hv + F16_QT;
-    const int first_pass_tile = skip_heads ? g.n_head_tiles + g.hv : g.n_head_tiles;
-    const int n_steps = n_head_steps + pass_len * NT;
-    auto tile_at = [&](int step) { return step < n_head_steps ? step : first_pass_tile + (step - n_head_steps) % pass_len; };
+    // ---- tile steps: 6 h head tiles and the hv W_O tiles, once per wave (not for all-padding titles), then the 7 additive tiles
+    // once per title
+    const int n_head_steps = skip_heads ? 0 : g.n_head_tiles + g.hv;
+    const int n_steps = n_head_steps + F16_QT * NT;
+    auto tile_at = [&](int step) { return step < n_head_steps ? step : g.n_head_tiles + g.hv + (step - n_head_steps) % F16_QT; };
     using Ring = TileRingDMA<3>;
     constexpr int AH = Ring::AHEAD;
     Ring ring;
@@ -247,18 +252,20 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
             for (int s = 0; s < F16_KS; ++s) xf[s] = z8;
         }
     }
-    // attn16: the k-steps behind the heads' full ones (leftovers, unused, the ones column) start as zeros + the 1.0
-    if (!skip_heads) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i < NT && val[i]) {
-                for (int ks = g.kl; ks < F16_CS; ++ks) {
-                    h8 v = z8;
-                    if (ks == 19 && hh == 0 && tok_ok[i]) v[0] = (_Float16)1.0f;
-                    *reinterpret_cast<h8*>(a.attn16 + frag_off((long)seq[i], F16_CS, ks, l32, hh)) = v;
-                }
-            }
+    // attn16 holds the TILE's rows: a long title its S token rows; a short title its n real tokens and, in row n, the one row all
+    // its padding tokens share (rows beyond: zeros) -- the form the backward's d(W_O) product contracts with the compressed d(o).
+    // row_ok: this lane's tile row is such a row.  The k-steps behind the heads' full ones (leftovers, unused, the ones column)
+    // start as zeros + the 1.0, and so do the rows 16 .. 31 of a short title's block.
+    const int myseq = myp ? seq[1] : seq[0];
+    const bool row_ok = myval && (pair ? (myr < myn || (myr == myn && myn < S)) : myr < S);
+    if (!skip_heads && myval) {
+        for (int ks = g.kl; ks < F16_CS; ++ks) {
+            h8 v = z8;
+            if (ks == 19 && hh == 0 && row_ok) v[0] = (_Float16)1.0f;
+            *reinterpret_cast<h8*>(a.attn16 + frag_off((long)myseq, F16_CS, ks, myr, hh)) = v;
         }
+        if (pair)
+            for (int ks = 0; ks < F16_CS; ++ks) *reinterpret_cast<h8*>(a.attn16 + frag_off((long)myseq, F16_CS, ks, 16 + myr, hh)) = z8;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): see fused_fwd16_kernel
     __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -267,6 +274,24 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
     int n = 0;
     auto pre = [&](int gq) { if (n + AH < n_steps) ring.load_piece_at(n + AH, tile_at(n + AH), gq); };
     auto idle_step = [&]() { if (n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH)); };
+    // output block j of title i (its S token rows in the lanes): dropout, ctx16
+    auto drop_store = [&](int i, int j, f32x16& cx) {
+        if (a.drop.thresh != 0u) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint64_t e0 = (uint64_t)(tok0[i] + l32) * (uint64_t)DP + (uint64_t)(j * 32 + 16 * c + 8 * hh);
+                float sc[8];
+                dropout_scale8(a.drop.seed, 1u, e0 >> 3, a.drop.thresh16, a.drop.inv_keep, sc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cx[8 * c + e] *= sc[e];
+            }
+        }
+        if (val[i]) {
+            _Float16* dst = a.ctx16 + frag_off((long)seq[i], F16_CS, 2 * j, l32, hh);
+            *reinterpret_cast<h8*>(dst) = tok_ok[i] ? acc_frag(cx, 0) : z8;
+            *reinterpret_cast<h8*>(dst + 512) = tok_ok[i] ? acc_frag(cx, 1) : z8;
+        }
+    };
     if (!skip_heads) {
 #pragma unroll 1
         for (int head = 0; head < g.h; ++head) {
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
                 for (int r = 0; r < 16; ++r) st[r] *= inv;
             }
             const h8 pf0 = acc_frag(st, 0), pf1 = acc_frag(st, 1);
-            // ---- ctx^T of the two blocks, each title's rows of it into attn16
+            // ---- ctx^T of the two blocks: this lane's tile row of it into attn16
 #pragma unroll 1
             for (int b = 0; b < 2; ++b) {
                 f32x16 vv = zero16(), ct = zero16();
@@ -307,88 +332,69 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
                     ct = mfma32h(acc_frag(vv, 0), pf0, zero16());
                     ct = mfma32h(acc_frag(vv, 1), pf1, ct);
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (i < NT && val[i]) {
-                        f32x16 cx = ct;
-                        if (pair) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                cx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane[i], __float_as_int(ct[r])));
-                        }
-                        const h8 f0 = tok_ok[i] ? acc_frag(cx, 0) : z8;
-                        _Float16* dst = a.attn16 + frag_off((long)seq[i], F16_CS, 3 * head + 2 * b, l32, hh);
-                        *reinterpret_cast<h8*>(dst) = f0;                                  // features 32 b .. 32 b + 15
-                        if (b == 0) {
-                            *reinterpret_cast<h8*>(dst + 512) = tok_ok[i] ? acc_frag(cx, 1) : z8;      // features 16 .. 31
-                        } else if (g.lo > 0 && hh == 0 && tok_ok[i]) {
-                            // features 48, 49 (rows 16, 17 of the block: registers 8, 9 of the lower lane half) into the leftover k-step
-                            _Float16* lp = a.attn16 + ((long)seq[i] * F16_CS + g.kl) * 512 + l32 * 16 + g.lo * head;
-                            for (int e = 0; e < g.lo; ++e) lp[e] = (_Float16)cx[8 + e];
-                        }
+                if (myval) {
+                    _Float16* dst = a.attn16 + frag_off((long)myseq, F16_CS, 3 * head + 2 * b, myr, hh);
+                    *reinterpret_cast<h8*>(dst) = row_ok ? acc_frag(ct, 0) : z8;                      // features 32 b .. 32 b + 15
+                    if (b == 0) {
+                        *reinterpret_cast<h8*>(dst + 512) = row_ok ? acc_frag(ct, 1) : z8;            // features 16 .. 31
+                    } else if (g.lo > 0 && hh == 0 && row_ok) {
+                        // features 48, 49 (rows 16, 17 of the block: registers 8, 9 of the lower lane half) into the leftover k-step
+                        _Float16* lp = a.attn16 + ((long)myseq * F16_CS + g.kl) * 512 + myr * 16 + g.lo * head;
+                        for (int e = 0; e < g.lo; ++e) lp[e] = (_Float16)ct[8 + e];
                     }
                 }
                 ring.step_barrier(n); ++n;
             }
         }
+        // ---- W_O on the tile's rows (a pair: both titles at once), then per title its S token rows (token t of a short title = its
+        // row min(t, n)), the dropout, ctx16 in v0's layout
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's attn16 stores have landed
+        h8 af[F16_CS];
+        {
+            const _Float16* src = a.attn16 + frag_off((long)myseq, F16_CS, 0, myr, hh);
+#pragma unroll
+            for (int s = 0; s < F16_CS; ++s) af[s] = *reinterpret_cast<const h8*>(src + 512 * s);
+            if (!myval) {
+#pragma unroll
+                for (int s = 0; s < F16_CS; ++s) af[s] = z8;
+            }
+        }
+#pragma unroll 1
+        for (int j = 0; j < g.hv; ++j) {
+            f32x16 ot = zero16();
+            if (any_live) tile_mma<true>(ot, ring, n, af, pre); else idle_step();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i < NT) {
+                    f32x16 cx = ot;
+                    if (pair) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            cx[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane[i], __float_as_int(ot[r])));
+                    }
+                    drop_store(i, j, cx);
+                }
+            }
+            ring.step_barrier(n); ++n;
+        }
+    } else {
+        if (TRAIN && val[0]) {                                      // d(W_O) contracts attn16 with d(ctx)16 over ALL rows (zeros here)
+            for (int ks = 0; ks < F16_CS; ++ks) *reinterpret_cast<h8*>(a.attn16 + frag_off((long)seq[0], F16_CS, ks, l32, hh)) = z8;
+        }
+#pragma unroll 1
+        for (int j = 0; j < g.hv; ++j) {
+            f32x16 cx = rows_of(a.boeff32 + 32 * j, hh);            // all-padding title: W_O b_v + b_o in every row
+            drop_store(0, j, cx);
+        }
     }
 
-    // ---- per title: W_O (+ dropout) -> ctx16 in v0's layout, then the additive attention and the pooling
+    // ---- per title: the additive attention and the pooling
 #pragma unroll 1
     for (int i = 0; i < NT; ++i) {
         const bool valid = i ? val[1] : val[0];
         const bool tok = i ? tok_ok[1] : tok_ok[0];
         const int sq = i ? seq[1] : seq[0];
         const long t0 = i ? tok0[1] : tok0[0];
-        auto drop_store = [&](int j, f32x16& cx) {                   // output block j of title i: dropout, ctx16
-            if (a.drop.thresh != 0u) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const uint64_t e0 = (uint64_t)(t0 + l32) * (uint64_t)DP + (uint64_t)(j * 32 + 16 * c + 8 * hh);
-                    float sc[8];
-                    dropout_scale8(a.drop.seed, 1u, e0 >> 3, a.drop.thresh16, a.drop.inv_keep, sc);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) cx[8 * c + e] *= sc[e];
-                }
-            }
-            if (valid) {
-                _Float16* dst = a.ctx16 + frag_off((long)sq, F16_CS, 2 * j, l32, hh);
-                *reinterpret_cast<h8*>(dst) = tok ? acc_frag(cx, 0) : z8;
-                *reinterpret_cast<h8*>(dst + 512) = tok ? acc_frag(cx, 1) : z8;
-            }
-        };
-        if (skip_heads) {
-            if (TRAIN && valid) {                                   // d(W_O) contracts attn16 with d(ctx)16 over ALL rows (zeros here)
-                for (int ks = 0; ks < F16_CS; ++ks) *reinterpret_cast<h8*>(a.attn16 + frag_off((long)sq, F16_CS, ks, l32, hh)) = z8;
-            }
-#pragma unroll 1
-            for (int j = 0; j < g.hv; ++j) {
-                f32x16 cx = rows_of(a.boeff32 + 32 * j, hh);          // all-padding title: W_O b_v + b_o in every row
-                drop_store(j, cx);
-            }
-        } else {
-            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's attn16 stores have landed
-            h8 af[F16_CS];
-            {
-                const _Float16* src = a.attn16 + frag_off((long)sq, F16_CS, 0, l32, hh);
-#pragma unroll
-                for (int s = 0; s < F16_CS; ++s) af[s] = *reinterpret_cast<const h8*>(src + 512 * s);
-            }
-#pragma unroll 1
-            for (int j = 0; j < g.hv; ++j) {
-                f32x16 ot = zero16();
-                if (valid) tile_mma<true>(ot, ring, n, af, pre); else idle_step();
-                drop_store(j, ot);
-                ring.step_barrier(n); ++n;
-            }
-        }
-        if (valid) {
-            for (int j = g.hv; j < F16_CS / 2; ++j) {               // (no such block for hv = 10)
-                _Float16* dst = a.ctx16 + frag_off((long)sq, F16_CS, 2 * j, l32, hh);
-                *reinterpret_cast<h8*>(dst) = z8;
-                *reinterpret_cast<h8*>(dst + 512) = z8;
-            }
-        }
         // ---- additive attention + pooling over the ten output blocks (fused_fwd16_kernel's last phase)
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         h8 cf[F16_CS];
@@ -467,6 +473,7 @@ int launch_prep16v1(int d, int h, int q, const float* w_qkv, const float* b_qkv,
     a.badd32 = (float*)(base + L.badd32); a.qv32 = (float*)(base + L.qv32);
     TimingScope ts("prep16", stream);
     hipLaunchKernelGGL(prep16v1_kernel, dim3(2048), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(boeff16v1_kernel, dim3(a.g.hv * 8), dim3(256), 0, stream, a.g, w_o, b_o, b_qkv, a.boeff32);
     return check_launch("prep16v1");
 }
 

@@ -461,12 +461,21 @@ __global__ __launch_bounds__(256) void closed16v1_wo_kernel(V1Geom g, const floa
         if (c == 0) db_o[o] += e;
     }
 }
-// ... and d(b_v)[c] += sum_o W_O[o][c] E[o]
-__global__ __launch_bounds__(256) void closed16v1_bv_kernel(V1Geom g, const float* w_o, const float* ebuf, float* db_qkv) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.d) return;
+// ... and d(b_v)[c] += sum_o W_O[o][c] E[o]: 32 columns per workgroup, the o range dealt over 32 row groups (a single thread per
+// column walked 300 dependent loads: 0.12 ms for a 90-kflop product)
+__global__ __launch_bounds__(1024) void closed16v1_bv_kernel(V1Geom g, const float* w_o, const float* ebuf, float* db_qkv) {
+    __shared__ float part[32][33];
+    const int cl = threadIdx.x & 31, og = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int o = 0; o < g.d; ++o) s += w_o[(long)o * g.d + c] * ebuf[(o / g.dkv) * 32 + o % g.dkv];
+    if (c < g.d)
+        for (int o = og; o < g.d; o += 32) s += w_o[(long)o * g.d + c] * ebuf[(o / g.dkv) * 32 + o % g.dkv];
+    part[og][cl] = s;
+    __syncthreads();
+    if (og != 0 || c >= g.d) return;
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += part[r][cl];               // fixed order
     db_qkv[2 * g.d + c] += s;
 }
 
@@ -619,7 +628,7 @@ int launch_fused_bwd16v1(const Fused16Bwd& f, hipStream_t stream) {
         TimingScope ts("red16", stream);
         hipLaunchKernelGGL(red16v1_kernel, dim3(cdiv(192 * f.h, 32)), dim3(1024), 0, stream, 1, red_attn, n_wg, g, f.q, sc,
                            f.db_qkv, f.db_add, f.dq_vec, ebuf);
-        hipLaunchKernelGGL(closed16v1_bv_kernel, dim3(cdiv(f.d, 256)), dim3(256), 0, stream, g, f.w_o, ebuf, f.db_qkv);
+        hipLaunchKernelGGL(closed16v1_bv_kernel, dim3(cdiv(f.d, 32)), dim3(1024), 0, stream, g, f.w_o, ebuf, f.db_qkv);
         rc = check_launch("red16v1");
         if (rc) return rc;
     }

@@ -1,5 +1,5 @@
 """Times nrms_v1's Model.train_step (bench.py's v1 variant: 20-word titles, 6 title heads of 50 / 10 user heads of 30, W_O,
-masks, dropout 0.2) with the per-kernel timers.  GPU box only.  Usage: python tools/bench_v1.py [fp32|bf16x3] [B]"""
+masks, dropout 0.2) with the per-kernel timers.  GPU box only.  Usage: python tools/bench_v1.py [fp16|fp32|bf16x3] [B]"""
 import os
 import sys
 
@@ -9,7 +9,7 @@ import torch
 from pytorch_news_recommender_amd import synth
 from tests.test_hip_v1 import make_v1
 
-prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 shape = synth.Shape(n_words=synth.BENCH.n_words, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
                     batch_size=B, history_len=50, n_candidates=5, n_words_title=20)
@@ -38,7 +38,7 @@ rows = []
 for name in ("qkv_proj_fwd", "out_proj_fwd", "attn_fwd", "attn_bwd", "addattn_fwd", "addattn_bwd_rows", "dctx_bwd", "dwadd_bwd",
              "dwo_bwd", "dattn_bwd", "dwqkv_bwd", "dx_bwd", "gather_dropout", "scatter_dropout", "fill_pad_rows", "transpose",
              "permute_rows", "split_planes", "compact_rows", "sanitize_ids", "click", "ce_loss", "adam", "tn_reduce", "padsum_reduce",
-             "colsum", "colsum_add"):
+             "colsum", "colsum_add", "fused_fwd16", "fused_bwd16_pool", "fused_bwd16_attn", "prep16", "red16", "closed16"):
     t, k = eng.timing_read(name)
     if k:
         rows.append((t / 3, name, k / 3))
