@@ -592,10 +592,21 @@ __global__ __launch_bounds__(256) void absmax_kernel(long n, const float* x, uns
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-        for (long i = tid; i < n / 4; i += nth) {
+        const long n4 = n / 4;
+        long i = tid;
+        for (; i + 3 * nth < n4; i += 4 * nth) {               // four loads in flight per thread (one was a chain of HBM round trips)
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x4[i + u * nth];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[u][e]) & 0x7FFFFFFFu);   // nan / inf sort above every finite value
+        }
+        for (; i < n4; i += nth) {
             const f32x4 v = x4[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7FFFFFFFu);     // nan / inf sort above every finite value
+            for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7FFFFFFFu);
         }
         for (long i = (n & ~3L) + tid; i < n; i += nth) m = max(m, __float_as_uint(x[i]) & 0x7FFFFFFFu);
     } else {

@@ -7,8 +7,8 @@
 //   fused_bwd16v1_attn_kernel, one wave per long title / pair of short titles:
 //       phase A  d(attn)^T = W_O^T d(o)^T as 2 h tiles of [32 features x tile rows] (feature blocks of the heads), parked in a
 //                per-wave scratch (written and re-read by the same lanes; 48 MB for the whole grid: it lives in the caches);
-//       phase B  per head, over the two feature blocks b: Q_b^T, K_b^T, V_b^T recomputed from x16 (six tiles), S^T = sum_b
-//                K_b Q_b^T, P^T, dP^T = sum_b V_b d(attn_b)^T, dS^T, and per block dV_b, dK_b, dQ_b -> dqkv16 rows of
+//       phase B  per head, over the two feature blocks b: V_b^T, Q_b^T, K_b^T recomputed from x16 (six tiles), dP^T = sum_b V_b
+//                d(attn_b)^T, S^T = sum_b K_b Q_b^T, P^T, dS^T, and per block dV_b, dK_b, dQ_b -> dqkv16 rows of
 //                [head][Q0 K0 Q1 K1 V0 V1][32] columns (192 per head), bias column sums without atomics
 //   gemm16_dx (18 slabs for six heads), gemm16_tn: d(W_qkv) = dQKV^T X, d(W_add) = dZ^T ctx, and
 //       d(W_O) = d(o)^T attn over ALL stored rows (short titles: the compressed d(o) block against the expanded attn rows is the
@@ -153,11 +153,30 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_bwd16v1_attn_kernel(Bwd1
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's scratch stores have landed
 #pragma unroll 1
         for (int head = 0; head < H; ++head) {
+            // tile order of a head: V0 V1 Q0 K0 Q1 K1 -- dP^T needs only V and d(attn), so it is formed first and the V fragments
+            // never coexist with the Q | K fragments of both blocks (which must survive until dS^T exists)
             h8 dc[2][2];                                                // d(attn)^T of the head's two feature blocks, operand fragments
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) dc[b][c] = live ? *reinterpret_cast<const h8*>(scr + (4 * head + 2 * b + c) * 512) : z8;
+            // dP^T[j][i] = sum_b sum_f V_b^T[f][j] d(attn_b)^T[f][i]
+            f32x16 dst = zero16();
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                ring.load(n + 2);
+                {
+                    f32x16 t = zero16();
+                    if (live) {
+                        tile_mma<true>(t, ring, n, xf);
+                        dst = mfma32h(acc_frag(t, 0), dc[b][0], dst);
+                        dst = mfma32h(acc_frag(t, 1), dc[b][1], dst);
+                    }
+                }
+                ring.store(n + 2);
+                __syncthreads();
+                ++n;
+            }
             h8 qf[2][2], kf[2][2];
             f32x16 pt = zero16();
 #pragma unroll
@@ -178,13 +197,17 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_bwd16v1_attn_kernel(Bwd1
                     kf[b][0] = acc_frag(t, 0); kf[b][1] = acc_frag(t, 1);
                 }
                 ring.store(n + 2);
-                __syncthreads();
-                ++n;
+                if (b == 0) { __syncthreads(); ++n; }
                 if (live) {
                     pt = mfma32h(kf[b][0], qf[b][0], pt);               // S^T[j][i] over this block's features
                     pt = mfma32h(kf[b][1], qf[b][1], pt);
                 }
             }
+            // d(attn)^T again, for dV (re-read from the scratch: cheaper than 16 registers held across the four tiles above)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) dc[b][c] = live ? *reinterpret_cast<const h8*>(scr + (4 * head + 2 * b + c) * 512) : z8;
             if (live) {
                 float m = NEG;
 #pragma unroll
@@ -197,22 +220,6 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_bwd16v1_attn_kernel(Bwd1
                 const float inv = 1.0f / sum;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pt[r] *= inv;
-            }
-            // dP^T[j][i] = sum_b sum_f V_b^T[f][j] d(attn_b)^T[f][i]
-            f32x16 dst = zero16();
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                ring.load(n + 2);
-                {
-                    f32x16 t = zero16();
-                    if (live) {
-                        tile_mma<true>(t, ring, n, xf);
-                        dst = mfma32h(acc_frag(t, 0), dc[b][0], dst);
-                        dst = mfma32h(acc_frag(t, 1), dc[b][1], dst);
-                    }
-                }
-                ring.store(n + 2);
-                if (b == 0) { __syncthreads(); ++n; }
             }
             float* srow = stg + (((head & 1) * F16_WAVES + wave) * 6) * 32 + l32;
             if (!live && hh == 0) {
@@ -339,8 +346,9 @@ __global__ __launch_bounds__(256) void prep16bv1_kernel(Prep16bV1Args a) {
                 const int j = fpad >> 5, fo = fpad & 31;
                 if (fh < g.dk && fo < g.dkv && j < g.hv) v = a.w_o[(long)(j * g.dkv + fo) * g.d + hd * g.dk + fh];
             } else {
-                const int t = tile - 10 - 2 * g.h, hd = t / 6, t6 = t - 6 * hd;
-                const int which = t6 < 4 ? (t6 & 1) : 2, blk = t6 < 4 ? (t6 >> 1) : (t6 - 4);
+                // stream order of a head's tiles: V0 V1 Q0 K0 Q1 K1 (fused_bwd16v1_attn_kernel)
+                const int t = tile - 10 - 2 * g.h, hd = t / 6, s6 = t - 6 * hd;
+                const int which = s6 < 2 ? 2 : ((s6 - 2) & 1), blk = s6 < 2 ? s6 : ((s6 - 2) >> 1);
                 const int fh = 32 * blk + f;
                 if (fh < g.dk && c < g.d) v = a.w_qkv[((long)which * g.d + hd * g.dk + fh) * g.d + c] * (which == 0 ? qscale : 1.0f);
                 if (fh < g.dk && c == g.d) v = a.b_qkv[which * g.d + hd * g.dk + fh] * (which == 0 ? qscale : 1.0f);   // ones column

@@ -127,3 +127,52 @@ def test_v1_fp16_forward_backward_against_oracle(case, p_drop):
     back = {v: k for k, v in zip(params.keys(), v0.keys())}
     _v1_grad_report(grads, o_grads, back, case)
     assert not grads[back["news_encoder.word_embedding.0.weight"]][0].any()
+
+
+def test_v1_fp16_is_bit_reproducible_with_and_without_helper_streams(monkeypatch):
+    """As tests/test_hip_v1.py::test_helper_streams_do_not_change_a_bit, for the fused fp16 kernels of the v1 news encoder:
+    d(W_O) | d(b_o), d(W_add) (helper stream 0) and d(W_qkv) (helper stream 1) against a single-stream run, and two runs of the
+    same configuration -- every gradient is a fixed-order sum (the all-padding titles' closed form included)."""
+    from tests.test_hip_v1 import fwd_bwd
+    shape = synth.Shape(n_words=4000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=24, history_len=50, n_candidates=5, n_words_title=20)
+    batch = synth.make_batch(shape, seed=44, ragged=True, min_title=1, all_pad_title=True, mask_some_candidates=True)
+    res = []
+    for no_side in (False, True, False):
+        if no_side:
+            monkeypatch.setenv("NRMS_NO_SIDE_STREAMS", "1")
+        else:
+            monkeypatch.delenv("NRMS_NO_SIDE_STREAMS", raising=False)
+        model = make_v1(shape, synth.make_params_v1(shape, seed=43), 6, precision="fp16").train()
+        assert _news_precision(model, 8, 20, True) == _lib.NRMS_PRECISION_FP16
+        res.append(fwd_bwd(model, batch))
+        torch.cuda.synchronize()
+    for other in (res[1], res[2]):
+        assert np.array_equal(res[0][0], other[0])
+        for n in res[0][2]:
+            assert np.array_equal(res[0][2][n], other[2][n]), n
+
+
+def test_v1_fp16_routes_what_the_fused_kernels_do_not_cover_to_bf16x3():
+    """Masked encoders (nrms_v1.py:15-23,87-105: pair mask / additive mask -- the model's own forward passes none), titles longer
+    than 32 words, heads of 32 columns or fewer with W_O: precision "fp16" runs them on the split-bf16 kernels (the masked
+    primitives are tested against the oracle in tests/test_hip_v1.py in that mode); the C ABI refuses them in fp16."""
+    import ctypes as C
+    shape, title_heads, _ = V1_SHAPES["reference"]
+    model = make_v1(shape, synth.make_params_v1(shape, seed=1), title_heads, precision="fp16").train()
+    eng = model.engine
+    BF = _lib.PRECISIONS["bf16x3"]
+    assert eng._desc("news_encoder", 8, 20, mask_mode=1, training=True).precision == BF
+    assert eng._desc("news_encoder", 8, 20, mask_mode=2).precision == BF
+    assert eng._desc("news_encoder", 8, 40).precision == BF
+    assert eng._desc("user_encoder", 8, 50).precision == BF
+    assert eng._desc("news_encoder", 8, 20).precision == _lib.NRMS_PRECISION_FP16
+    lib = _lib.load()
+    for kw in (dict(mask_mode=1), dict(seq_len=40), dict(n_heads=10), dict(flags=0), dict(p_drop_embed=0.1)):
+        args = dict(n_seq=4, seq_len=20, d_model=300, n_heads=6, q_dim=200, vocab=100, p_drop_embed=0.0, p_drop_ctx=0.0,
+                    precision=_lib.NRMS_PRECISION_FP16, use_output_proj=1, mask_mode=0, flags=_lib.NRMS_FLAG_PAD_ROW_ZERO,
+                    seed=0, loss_scale=0.0, p_drop_attn=0.0)
+        args.update(kw)
+        desc = _lib.EncoderDesc(**args)
+        assert lib.nrms_encoder_fwd_scratch_bytes(C.byref(desc)) == 0, kw
+        assert b"fp16" in lib.nrms_last_error(), kw

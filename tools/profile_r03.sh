@@ -21,6 +21,12 @@ step "hbm traffic" timeout -k 10 400 python3 tools/hbm_traffic.py "$OUT/traffic"
 cp "$OUT/traffic/hbm_traffic.json" "$SUM/r03_fp16_hbm_traffic.json" 2>/dev/null
 step "sq counters" timeout -k 10 700 bash tools/pmc_sq.sh r03 tools/train_steps.py --steps 3 > "$OUT/sq.log" 2>&1
 cp "$ROOT/gpurun_out/sq_r03/sq_summary.txt" "$SUM/r03_fp16_sq_counters.txt" 2>/dev/null
+cd /tmp
+step "v1 kernel stats" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_v1" -- python3 "$ROOT/tools/train_steps.py" \
+    --model v1 --steps 6 > "$OUT/v1_under_profiler.log" 2> "$OUT/stats_v1.err"
+cd "$ROOT"
+cp $(find "$OUT/stats_v1" -name "*kernel_stats.csv" | head -1) "$SUM/r03_v1_fp16_kernel_stats.csv" 2>/dev/null
+step "v1 step" timeout -k 10 300 python3 tools/bench_v1.py fp16 > "$SUM/r03_v1_step_kernels.txt" 2> "$OUT/v1_step.err"
 step "bench" timeout -k 10 500 python3 bench.py --no-live-traffic > "$SUM/r03_bench_fp16.json" 2> "$OUT/bench.err"
 step "bench 2 ranks (gloo, one GPU)" env NRMS_DIST_BACKEND=gloo timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
     --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 > "$SUM/r03_bench_2rank_gloo.json" 2> "$OUT/bench2.err"

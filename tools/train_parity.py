@@ -1,6 +1,6 @@
 """Training-trajectory parity of the precision modes: the same model (bench dimensions), the same synthetic corpus, batches
 and dropout-free steps in fp32 and in fp16 / bf16x3; prints the per-step loss gap and the dev AUC after training.
-GPU box only.  Usage: python tools/train_parity.py [steps] [dropout]"""
+GPU box only.  Usage: python tools/train_parity.py [steps] [dropout] [v0|v1]   (v1: nrms_v1 -- 20-word titles, six title heads of 50, W_O)"""
 import os
 import sys
 
@@ -11,16 +11,22 @@ import torch
 from pytorch_news_recommender_amd import train_eval
 from pytorch_news_recommender_amd.config import Config
 from pytorch_news_recommender_amd.data_handler import DeviceFeed, SyntheticMind
-from pytorch_news_recommender_amd.model.nrms_hip import Model
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 240
 dropout = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+variant = sys.argv[3] if len(sys.argv) > 3 else "v0"
+if variant == "v1":
+    from pytorch_news_recommender_amd.model.nrms_v1_hip import Model
+else:
+    from pytorch_news_recommender_amd.model.nrms_hip import Model
 
 
 def run(prec):
-    cfg = Config("nrms_hip")
+    cfg = Config("nrms_v1" if variant == "v1" else "nrms_hip")
     cfg.__nrms__()
-    cfg.n_words_title, cfg.batch_size, cfg.dropout, cfg.precision, cfg.learning_rate = 30, 256, dropout, prec, 1e-3
+    cfg.n_words_title, cfg.batch_size, cfg.dropout, cfg.precision, cfg.learning_rate = (20 if variant == "v1" else 30), 256, dropout, prec, 1e-3
+    if variant == "v1":
+        cfg.num_attention_heads, cfg.title_heads_num = 10, 6
     cfg.max_candidate_size = 40
     corpus = SyntheticMind(cfg, n_news=4000, seed=0)
     table = torch.from_numpy(np.asarray(corpus.embedding_table(cfg.word_embed_size), dtype=np.float32))
