@@ -116,7 +116,7 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
     NRMS_REQUIRE(d->q_dim > 0 && (d->q_dim & 3) == 0 && d->q_dim <= 512, "%s: q_dim=%d must be a multiple of 4 <= 512",
                  who, d->q_dim);
     NRMS_REQUIRE(d->p_drop_attn >= 0.f && d->p_drop_attn < 1.f, "%s: p_drop_attn must be in [0,1)", who);
-    if (wide_attention(d))
+    if (wide_attention(d) && d->precision != NRMS_PRECISION_FP16)       // (the fused fp16 kernels have their own shape rules, below)
         NRMS_REQUIRE(!(d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO)) && d->p_drop_ctx == 0.f,
                      "%s: d_k > 64 or odd d_k (the shape-general attention) supports neither NRMS_FLAG_PAD_ROW_ZERO nor "
                      "p_drop_ctx", who);

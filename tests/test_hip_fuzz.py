@@ -100,3 +100,66 @@ def test_fuzz_fp32(case):
 @given(cases(min_width=60))
 def test_fuzz_fp16(case):
     _run(case, "fp16")
+
+
+@st.composite
+def v1_cases(draw):
+    """nrms_v1 geometries inside the fused fp16 kernels of the news encoder (csrc/fused16_v1.hip: 32 < d_k <= 50, 3 h + 1 <= 19
+    k-steps, h (d_k - 48) <= 16 leftover features, d a multiple of 20 with d / 10 <= 32): (title heads, d_k) pairs, any title
+    length up to 32, user heads that divide d."""
+    ht, dk = draw(st.sampled_from([(2, 50), (2, 40), (3, 40), (4, 35), (4, 45), (4, 50), (5, 36), (5, 48), (6, 40), (6, 50)]))
+    d = ht * dk
+    hu = draw(st.sampled_from([x for x in (1, 2, 4, 5, 10) if d % x == 0 and d // x <= 64]))
+    return dict(d=d, ht=ht, hu=hu, q=4 * draw(st.integers(15, 56)), B=draw(st.integers(1, 7)), H=draw(st.integers(1, 50)),
+                C=draw(st.integers(1, 6)), L=draw(st.integers(1, 32)), seed=draw(st.integers(0, 10 ** 6)), hole=draw(st.booleans()),
+                p_drop=draw(st.sampled_from([0.0, 0.2])))
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(v1_cases())
+def test_fuzz_v1_fp16(case):
+    from oracle import nrms_oracle as orc
+    from pytorch_news_recommender_amd import _lib
+    from tests.test_hip_v1 import fwd_bwd, make_v1
+    from tests.test_hip_fp16 import score_bar
+    shape = synth.Shape(n_words=211, word_embed_size=case["d"], num_attention_heads=case["hu"], query_vector_dim=case["q"],
+                        batch_size=case["B"], history_len=case["H"], n_candidates=case["C"], n_words_title=case["L"])
+    params = synth.make_params_v1(shape, seed=case["seed"])
+    batch = synth.make_batch(shape, seed=case["seed"] + 1, ragged=True, min_title=1, empty_history_user=True,
+                             all_pad_title=True, mask_some_candidates=True)
+    if case["hole"] and case["L"] >= 3:
+        rng = np.random.default_rng(case["seed"] + 2)
+        for key in ("browsed_titles", "candidate_titles"):
+            t = batch[key]
+            hit = rng.random(t.shape[:2]) < 0.3
+            pos = rng.integers(0, case["L"] - 1, size=t.shape[:2])
+            b, s = np.nonzero(hit)
+            t[b, s, pos[b, s]] = 0
+    model = make_v1(shape, params, case["ht"], dropout=case["p_drop"], precision="fp16").train()
+    assert model.engine._desc("news_encoder", 4, case["L"], training=True).precision == _lib.NRMS_PRECISION_FP16, case
+    scores, loss, grads = fwd_bwd(model, batch)
+    keep = None
+    if case["p_drop"] > 0:
+        sv = model.engine._saved
+        n_titles = case["B"] * (case["H"] + case["C"])
+        kc = model.engine.dropout_keep_mask(sv["seed"], 1, n_titles * case["L"], case["p_drop"], fp16_ctx=True).cpu().numpy()
+        keep = {"ctx": torch.from_numpy(kc.reshape(-1, 10, 32)[:, :, :case["d"] // 10].reshape(n_titles, case["L"], case["d"]).copy())}
+    v0 = orc.v1_to_v0_names(params)
+    o_scores, o_loss, o_grads, aux = orc.loss_and_grads(v0, batch, case["hu"], p_drop=case["p_drop"], keep=keep,
+                                                        news_heads=case["ht"], embed_dropout=False)
+    valid = batch["candidate_mask"] == 1
+    assert (scores[~valid] == np.float32(-1e9)).all()
+    if not valid.any():
+        return
+    err = float(np.abs(scores - o_scores)[valid].max())
+    terms = float(np.abs(aux["cand"] * aux["user"][:, None, :]).sum(-1)[valid].max())
+    assert err < max(score_bar(o_scores[valid]), 1e-3 * terms), (case, err, terms)
+    back = {v: k for k, v in zip(params.keys(), v0.keys())}
+    floor = 1e-4 * max(float(np.abs(v).max()) for v in o_grads.values()) + 2e-6
+    for n, ref in o_grads.items():
+        sc = float(np.abs(ref).max())
+        bad = float(np.abs(grads[back[n]] - ref).max())
+        if n.endswith("W_K.bias"):
+            sc = max(sc, float(np.abs(o_grads[n.replace("W_K", "W_Q")]).max()))
+        assert bad <= 8e-3 * sc + floor, (case, n, bad, sc)
+    assert not grads[back["news_encoder.word_embedding.0.weight"]][0].any()
