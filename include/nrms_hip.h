@@ -50,7 +50,13 @@ extern "C" {
                                    (fp16 operands: 11 significant bits, fp32 accumulate), Q/K/V, attention probabilities
                                    and tanh(.) register-resident, activations kept for the backward in fp16.
                                    Restrictions: seq_len <= 64, d_model <= 316, d_k <= 32, n_heads <= 10, q_dim <= 224,
-                                   no output projection, no masks (NRMS_EINVAL otherwise).  Activation buffers change
+                                   no output projection, no masks (NRMS_EINVAL otherwise).  With use_output_proj (the
+                                   news encoder of nrms_v1, model/nrms_v1.py:109-162: heads wider than 32 + W_O,
+                                   dropout after W_O): vocab > 0 with NRMS_FLAG_PAD_ROW_ZERO and no embedding dropout,
+                                   seq_len <= 32, 32 < d_k <= 50, 3 n_heads + 1 <= 19, n_heads (d_k - 48) <= 16,
+                                   d_model <= 316 a multiple of 10 (d_model / 10 <= 32), q_dim <= 224; the context
+                                   dropout then acts on the ten [d_model / 10]-wide blocks of the projection's output
+                                   (same padded [M, 320] counter layout).  Activation buffers change
                                    meaning (see nrms_encoder_acts); context-dropout counters run over the padded
                                    [M, NRMS_FP16_DP] layout, 32 columns per head, in the 16-bit-field scheme
                                    (nrms_dropout_keep_mask with d = 320 and site 1 | NRMS_DROPOUT_FIELDS16). */
@@ -154,7 +160,9 @@ typedef struct nrms_encoder_acts {
     /* NRMS_PRECISION_FP16: x, ctx, t hold fp16 with the FIXED pitches KP = 320, DP = 320, QP = 224
      * (NRMS_FP16_KP / _DP / _QP):  x [M + 1, KP] (required for both encoders: gathered embeddings / the cast input),
      * ctx [Mp, DP] and t [Mp, QP] with Mp = n_seq * (seq_len <= 32 ? 32 : 64) rows (every sequence padded to whole
-     * 32-row blocks, internal fragment order); w [M] fp32; qkv and attn are unused (may be NULL). */
+     * 32-row blocks, internal fragment order); w [M] fp32; qkv is unused (may be NULL); attn is unused unless
+     * use_output_proj, then fp16 [Mp, DP] (the head concatenation in the operand order of the W_O tiles; read by the
+     * backward's d(w_o) product). */
 } nrms_encoder_acts;
 
 /* Forward: embedding gather(+dropout) -> QKV projection -> per-head softmax(QK^T/sqrt(d_k))V

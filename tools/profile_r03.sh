@@ -23,7 +23,7 @@ step "sq counters" timeout -k 10 700 bash tools/pmc_sq.sh r03 tools/train_steps.
 cp "$ROOT/gpurun_out/sq_r03/sq_summary.txt" "$SUM/r03_fp16_sq_counters.txt" 2>/dev/null
 cd /tmp
 step "v1 kernel stats" timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_v1" -- python3 "$ROOT/tools/train_steps.py" \
-    --model v1 --steps 6 > "$OUT/v1_under_profiler.log" 2> "$OUT/stats_v1.err"
+    --model v1 --steps 20 > "$OUT/v1_under_profiler.log" 2> "$OUT/stats_v1.err"
 cd "$ROOT"
 cp $(find "$OUT/stats_v1" -name "*kernel_stats.csv" | head -1) "$SUM/r03_v1_fp16_kernel_stats.csv" 2>/dev/null
 step "v1 step" timeout -k 10 300 python3 tools/bench_v1.py fp16 > "$SUM/r03_v1_step_kernels.txt" 2> "$OUT/v1_step.err"
