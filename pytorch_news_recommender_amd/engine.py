@@ -151,7 +151,8 @@ class NRMSEngine:
 
     def set_precision(self, precision):
         """"fp32" (exact f32 MFMA), "bf16x3" (split-bf16 projections, ~2^-16 relative), "bf16", or "fp16"
-        (fused one-wave-per-sequence kernels on fp16 MFMA, fp16 activations; bf16x3 where a shape is outside them)."""
+        (fused one-wave-per-sequence kernels on fp16 MFMA, fp16 activations -- v0's news encoder and, with output_proj, nrms_v1's
+        six-heads-of-50 + W_O news encoder; bf16x3 where a shape, a mask or the user encoder is outside them)."""
         if precision not in _lib.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self.precision = precision
