@@ -373,6 +373,23 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     } else {
         f.dx = dx;
     }
+    // the grouped scatter's lists depend on the ids only: built on helper stream 1 beside the fused kernels (event 5 forks,
+    // event 4 joins in front of the scatter -- and on every error path, so the caller may reuse the workspace)
+    SideSet* ss_prep = (gather && skip_pad_rows(desc)) ? side_streams_for(s) : nullptr;
+    bool prepared = false;
+    if (ss_prep != nullptr) {
+        rc = side_order(ss_prep, 5, s, ss_prep->s[1], "encoder_bwd(fp16)");
+        if (rc) return rc;
+        rc = launch_scatter_prepare(M, desc->vocab, ids, live, n_live, (int*)(base + L.sscr), ss_prep->s[1]);
+        if (hipEventRecord(ss_prep->ev[4], ss_prep->s[1]) != hipSuccess) { set_error("encoder_bwd(fp16): hipEventRecord failed"); return NRMS_ELAUNCH; }
+        if (rc) { (void)hipStreamWaitEvent(s, ss_prep->ev[4], 0); return rc; }
+        prepared = true;
+    }
+    auto join_prepare = [&]() -> int {
+        if (!prepared) return NRMS_OK;
+        if (hipStreamWaitEvent(s, ss_prep->ev[4], 0) != hipSuccess) { set_error("encoder_bwd(fp16): hipStreamWaitEvent failed"); return NRMS_ELAUNCH; }
+        return NRMS_OK;
+    };
     const float* sc_dev = nullptr;
     f.sc_out = &sc_dev;
     // NRMS_FLAG_DEFER_WQKV: the two weight-gradient GEMMs stay on their helper streams; dX and the table gradient below
@@ -380,12 +397,16 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     // all-reduce in between)
     f.defer_join = (desc->flags & NRMS_FLAG_DEFER_WQKV) != 0;
     rc = v1 ? launch_fused_bwd16v1(f, s) : launch_fused_bwd16(f, s);
-    if (rc) return rc;
+    {
+        const int rj = join_prepare();
+        if (rc) return rc;
+        if (rj) return rj;
+    }
     if (gather) {
         const Dropout drop_e = make_dropout(desc->seed, desc->p_drop_embed);
         if (skip_pad_rows(desc))
             rc = launch_scatter_grouped(M, desc->vocab, d, ids, live, n_live, f.dx, drop_e, grads->table, (int*)(base + L.sscr), s,
-                                        f.dx_fp16, NRMS_FP16_KP, sc_dev);
+                                        f.dx_fp16, NRMS_FP16_KP, sc_dev, prepared);
         else       // dense rows (one per token): the atomic scatter walks the live list over the dense rows
             rc = launch_scatter_dense_rows(M, d, ids, live, n_live, f.dx, drop_e, grads->table, s);
     }

@@ -356,10 +356,9 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(int V, int d4, con
 
 size_t scatter_grouped_scratch_ints(long M, int V) { return (size_t)2 * (V + 64) + (size_t)M + 64; }
 
-// scratch: scatter_grouped_scratch_ints(M, V) ints.  dx is compact (row r belongs to token live[r]).
-int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const void* dx,
-                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream, bool dx_fp16, int ldx,
-                           const float* sc) {
+// The lists the grouped scatter walks (per table row: the compact rows of its occurrences, ascending) depend on the ids only:
+// a caller may build them early, on another stream (the fp16 backward does, beside its fused kernels), and pass prepared = true.
+int launch_scatter_prepare(long M, int V, const int64_t* ids, const int* live, const int* n_live, int* scratch, hipStream_t stream) {
     if (M <= 0) return NRMS_OK;
     int* cnt = scratch;                       // [V] counts -> exclusive offsets (in place)
     int* cursor = cnt + V + 64;               // [V]
@@ -371,7 +370,7 @@ int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* 
     }
     int blocks = cdiv(M, 256);
     if (blocks > 2048) blocks = 2048;
-    TimingScope ts("scatter_dropout", stream);
+    TimingScope ts("scatter_prepare", stream);
     hipLaunchKernelGGL(tok_hist_kernel, dim3(blocks), dim3(256), 0, stream, ids, live, n_live, cnt);
     {
         const int nb = cdiv(V, 1024);
@@ -380,6 +379,23 @@ int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* 
         hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(1024), 0, stream, V, nb, cnt, bsum, total);
     }
     hipLaunchKernelGGL(tok_place_kernel, dim3(blocks), dim3(256), 0, stream, ids, live, n_live, cnt, cursor, order);
+    return check_launch("scatter_prepare");
+}
+
+// scratch: scatter_grouped_scratch_ints(M, V) ints.  dx is compact (row r belongs to token live[r]).
+int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const void* dx,
+                           const Dropout& drop, float* dtable, int* scratch, hipStream_t stream, bool dx_fp16, int ldx,
+                           const float* sc, bool prepared) {
+    if (M <= 0) return NRMS_OK;
+    if (!prepared) {
+        const int rc = launch_scatter_prepare(M, V, ids, live, n_live, scratch, stream);
+        if (rc) return rc;
+    }
+    int* cnt = scratch;
+    int* cursor = cnt + V + 64;
+    int* total = cursor + V;
+    int* order = cursor + V + 64;
+    TimingScope ts("scatter_dropout", stream);
     if (dx_fp16)
         hipLaunchKernelGGL(scatter_grouped_kernel<true>, dim3(cdiv(V, 4)), dim3(256), 0, stream, V, d / 4, live, cnt, total, order, dx,
                            ldx, sc, drop, dtable);

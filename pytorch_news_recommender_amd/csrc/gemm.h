@@ -420,7 +420,9 @@ size_t scatter_grouped_scratch_ints(long M, int V);
 // dx: fp32 [rows][d], or (dx_fp16) fp16 [rows][ldx] multiplied by the loss scale whose reciprocal is sc[1] (device)
 int launch_scatter_grouped(long M, int V, int d, const int64_t* ids, const int* live, const int* n_live, const void* dx,
                            const Dropout& drop, float* dtable, int* scratch, hipStream_t stream, bool dx_fp16 = false, int ldx = 0,
-                           const float* sc = nullptr);
+                           const float* sc = nullptr, bool prepared = false);
+// the id-only part of the above (histogram of the live tokens' ids, offsets, placement): `prepared` = it has run on `scratch`
+int launch_scatter_prepare(long M, int V, const int64_t* ids, const int* live, const int* n_live, int* scratch, hipStream_t stream);
 // dx has one row per token; the live tokens' rows are scatter-added (float atomics)
 int launch_scatter_dense_rows(long M, int d, const int64_t* ids, const int* live, const int* n_live, const float* dx,
                               const Dropout& drop, float* dtable, hipStream_t stream);
