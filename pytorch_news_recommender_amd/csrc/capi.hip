@@ -255,9 +255,28 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     char* base = (char*)acts->scratch;
     const bool v1 = desc->use_output_proj != 0;
     NRMS_REQUIRE(!v1 || (w->w_o && w->b_o && acts->attn), "encoder_fwd(fp16): use_output_proj needs w_o, b_o and acts.attn");
-    int rc = v1 ? launch_prep16v1(d, h, q, w->w_qkv, w->b_qkv, w->w_o, w->b_o, w->w_add, w->b_add, w->q_vec, base + fs.planes, s)
-                : launch_prep16(d, h, q, w->w_qkv, w->b_qkv, w->w_add, w->b_add, w->q_vec, base + fs.planes, s);
-    if (rc) return rc;
+    // The weight planes (weights only) and the title lists (ids only) are built on helper stream 1 while the caller's stream
+    // compacts the token rows and gathers the embeddings (event 5 forks, event 4 joins in front of the fused kernel)
+    SideSet* ss = (gather && skip_pad_rows(desc)) ? side_streams_for(s) : nullptr;
+    hipStream_t s_prep = ss != nullptr ? ss->s[1] : s;
+    int rc;
+    if (ss != nullptr) {
+        rc = side_order(ss, 5, s, s_prep, "encoder_fwd(fp16)");
+        if (rc) return rc;
+    }
+    bool forked = ss != nullptr;
+    auto join_prep = [&]() -> int {                 // (also on the error paths: the caller may reuse the scratch)
+        if (!forked) return NRMS_OK;
+        forked = false;
+        if (hipEventRecord(ss->ev[4], s_prep) != hipSuccess || hipStreamWaitEvent(s, ss->ev[4], 0) != hipSuccess) {
+            set_error("encoder_fwd(fp16): joining the helper stream failed");
+            return NRMS_ELAUNCH;
+        }
+        return NRMS_OK;
+    };
+    rc = v1 ? launch_prep16v1(d, h, q, w->w_qkv, w->b_qkv, w->w_o, w->b_o, w->w_add, w->b_add, w->q_vec, base + fs.planes, s_prep)
+            : launch_prep16(d, h, q, w->w_qkv, w->b_qkv, w->w_add, w->b_add, w->q_vec, base + fs.planes, s_prep);
+    if (rc) { (void)join_prep(); return rc; }
     Fused16Fwd f{};
     f.n_seq = desc->n_seq; f.S = S; f.d = d; f.h = h; f.q = q;
     f.planes = base + fs.planes; f.x16 = acts->x; f.ctx16 = acts->ctx; f.t16 = acts->t; f.w = acts->w; f.out = out;
@@ -268,17 +287,18 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
             int* live = (int*)(base + fs.live);
             int* pos = (int*)(base + fs.pos);
             int* n_live = (int*)(base + fs.n_live);
+            int* order = (int*)(base + fs.order);
+            int* order_cnt = (int*)(base + fs.order_cnt);
+            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s_prep, 3);
+            if (rc) { (void)join_prep(); return rc; }
             rc = launch_compact_live_rows(M, ids, live, pos, n_live, (int*)(base + fs.cscr), s);
+            if (rc == NRMS_OK) rc = launch_gather16(M, d, L.KP, ids, live, n_live, w->table, drop_e, acts->x, s);
+            const int rj = join_prep();
             if (rc) return rc;
-            rc = launch_gather16(M, d, L.KP, ids, live, n_live, w->table, drop_e, acts->x, s);
-            if (rc) return rc;
+            if (rj) return rj;
             f.pos = pos;
             f.n_rows = n_live;
             f.ids = ids;
-            int* order = (int*)(base + fs.order);
-            int* order_cnt = (int*)(base + fs.order_cnt);
-            rc = launch_title_order(desc->n_seq, S, ids, order, order_cnt, s, 3);
-            if (rc) return rc;
             f.order = order; f.order_cnt = order_cnt;
         } else {
             rc = launch_gather16(M, d, L.KP, ids, nullptr, nullptr, w->table, drop_e, acts->x, s);
