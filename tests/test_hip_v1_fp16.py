@@ -242,3 +242,33 @@ def test_v1_fp16_at_the_benchmarked_size():
     assert torch.equal(s_perm, s1[perm])
     sd = model.engine.forward(flat, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=True, p_drop=0.2, seed=11)
     assert torch.isfinite(sd[valid]).all()
+
+
+def test_v1_fp16_deferred_wqkv_backward_equals_plain_backward():
+    """The data-parallel split of the backward (NRMS_FLAG_DEFER_WQKV + nrms_encoder_bwd_wqkv: the table gradient is complete
+    when the hook runs, the weight-gradient GEMMs of both helper streams -- d(W_add), d(W_O) | d(b_o) with the all-padding
+    titles' closed form, d(W_qkv) -- are joined afterwards) equals the one-call backward bit for bit, v1 news encoder in fp16."""
+    shape = synth.Shape(n_words=4000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=9, history_len=12, n_candidates=4, n_words_title=20)
+    params = synth.make_params_v1(shape, seed=141)
+    batch = synth.make_batch(shape, seed=142, ragged=True, min_title=1, all_pad_title=True)
+    model = make_v1(shape, params, 6, precision="fp16").train()
+    eng, flat, lay = model.engine, model._flat, model._layout
+    assert _news_precision(model, 8, 20, True) == _lib.NRMS_PRECISION_FP16
+    bt, ct, cm = (torch.from_numpy(batch[k]).cuda() for k in ("browsed_titles", "candidate_titles", "candidate_mask"))
+    s = eng.forward(flat, bt, ct, cm, training=True)
+    dsc = (torch.randn(s.shape, generator=torch.Generator().manual_seed(3)) * 1e-2).cuda()
+    g_plain = torch.zeros_like(flat)
+    eng.backward(flat, g_plain, dsc)
+    eng.forward(flat, bt, ct, cm, training=True)
+    g_split = torch.zeros_like(flat)
+    seen = []
+
+    def hook():
+        torch.cuda.synchronize()
+        seen.append(float(lay.view(g_split, "news_encoder.word_embedding.weight").abs().max()))
+
+    eng.backward(flat, g_split, dsc, table_grad_ready=hook)
+    assert len(seen) == 1 and seen[0] > 0.0
+    for n in lay.names:
+        assert torch.equal(lay.view(g_split, n), lay.view(g_plain, n)), n
