@@ -34,8 +34,8 @@ struct Bwd16Args {
     float* red;                 // [gridDim.x][B16_RED] per-workgroup column sums (reduced afterwards, fixed order)
     Dropout drop;
     int v1;                     // pool kernel under fused16_v1_bwd.hip (h, dk = the ten output blocks of W_O): d(ctx)16 is also an
-                                // operand of the d(W_O) product over ALL rows, so an all-padding title's rows and the rows 16..31
-                                // of a short title's compressed block are written as zeros
+                                // operand of the d(W_O) product over the whole 32-row blocks of the titles with a real token, so
+                                // the rows 16..31 of a short title's compressed block are written as zeros
     int dbg;                    // timing experiments only (NRMS_F16_DBG): 4 = no dZ16 / d(ctx)16 stores, 8 = no d(ctx) products
 };
 
@@ -87,6 +87,7 @@ int launch_dout16(long n_seq, int d, int h, int dk, float fixed_scale, float* sc
 // geom 0: row-major operands, 320 x 160 output blocks; 1: fragment-order operands, one 224 x 320 block; 2: fragment order, 320 x 160
 int launch_tn16(int geom, const _Float16* A, int lda, int N, const _Float16* B, int ldb, int K, int M, const int* m_dev,
                 float* partial, int splits, const int* nmap, const int* kmap, const float* nscale, int ldw, float* dW,
-                hipStream_t stream, const char* name, float* dbias = nullptr);
+                hipStream_t stream, const char* name, float* dbias = nullptr, const int* blk_list = nullptr, const int* blk_cnt = nullptr,
+                int blk_stride = 0);       // blk_*: geom 1 / 2 only, contract over the listed 32-row blocks (long + short title lists)
 
 }  // namespace nrms

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
                         for (int e = 0; e < 8; ++e) dct[8 * c + e] *= sc[e];
                     }
                 }
-                if (a.v1 && valid && (!live || (nshort >= 0 && l32 >= 16))) {
+                if (a.v1 && live && nshort >= 0 && l32 >= 16) {
                     _Float16* dcrow = a.dctx16 + frag_off((long)seq * SB + b, F16_CS, 2 * head, l32, hh);
                     *reinterpret_cast<h8*>(dcrow) = h8{0, 0, 0, 0, 0, 0, 0, 0};
                     *reinterpret_cast<h8*>(dcrow + 512) = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -843,6 +843,10 @@ struct Tn16Args {
     const _Float16* B; int ldb, K;       // [M][ldb], K used columns (multiple of 16)
     float* partial;           // [splits][N][K]
     int splits, n_blk, k_blk; // output blocks of AW x BW
+    // fragment-order operands only: the 32-row blocks to contract over, as two of the title lists of launch_title_order
+    // (blk_list[0 ..] and blk_list[2 blk_stride ..], sizes blk_cnt[0] and blk_cnt[2]: long and short titles -- the all-padding
+    // titles' blocks are skipped); null: all M / 32 blocks in order
+    const int* blk_list; const int* blk_cnt; int blk_stride;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -882,7 +886,8 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
     const int blk = idx % out_blocks, split = idx / out_blocks;
     const int bn = blk % a.n_blk, bk = blk / a.n_blk;
     const int ncol0 = bn * T16_AW, kcol0 = bk * T16_BW;
-    const int M = a.m_dev != nullptr ? *a.m_dev : a.M;
+    const int n_list0 = (FL && a.blk_list != nullptr) ? a.blk_cnt[0] : 0;
+    const int M = (FL && a.blk_list != nullptr) ? 32 * (n_list0 + a.blk_cnt[2]) : (a.m_dev != nullptr ? *a.m_dev : a.M);
     const int rps = (((M + a.splits - 1) / a.splits) + T16_MC - 1) / T16_MC * T16_MC;
     const int m_begin = split * rps, m_end = min(M, m_begin + rps);
 
@@ -898,7 +903,8 @@ __global__ __launch_bounds__(T16_THREADS, 2) void gemm16_tn_kernel(Tn16Args a) {
         else { r = sl / (width / 8); c = (sl % (width / 8)) * 8; }
     };
     auto load_stage = [&](Regs& R, int m0) {
-        const long blk = min(m0, max(m_end - 1, 0)) >> 5;             // fragment order: the 32-row block of this stage
+        long blk = min(m0, max(m_end - 1, 0)) >> 5;                   // fragment order: the 32-row block of this stage
+        if (FL && a.blk_list != nullptr && M > 0) blk = blk < n_list0 ? a.blk_list[blk] : a.blk_list[2 * (long)a.blk_stride + blk - n_list0];
 #pragma unroll
         for (int i = 0; i < T16_A_IT; ++i) {
             int r, c;
@@ -1121,9 +1127,10 @@ Fused16BwdLayout fused16_bwd_layout(long M, int n_seq) {
 
 int launch_tn16(int geom, const _Float16* A, int lda, int N, const _Float16* B, int ldb, int K, int M, const int* m_dev,
                 float* partial, int splits, const int* nmap, const int* kmap, const float* nscale, int ldw, float* dW,
-                hipStream_t stream, const char* name, float* dbias) {
+                hipStream_t stream, const char* name, float* dbias, const int* blk_list, const int* blk_cnt, int blk_stride) {
     Tn16Args t{};
     t.M = M; t.m_dev = m_dev; t.A = A; t.lda = lda; t.N = N; t.B = B; t.ldb = ldb; t.K = K; t.partial = partial;
+    t.blk_list = geom != 0 ? blk_list : nullptr; t.blk_cnt = blk_cnt; t.blk_stride = blk_stride;
     // geom 1 (fragment-order operands, one 224 x 320 block) = the additive product; 0 (row-major, 320 x 160 blocks) = the
     // Q|K|V product; 2 (fragment order, 320 x 160 blocks) = d(W_O) of nrms_v1
     typedef void (*Kern)(Tn16Args);

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
             if (ks == 19 && hh == 0 && row_ok) v[0] = (_Float16)1.0f;
             *reinterpret_cast<h8*>(a.attn16 + frag_off((long)myseq, F16_CS, ks, myr, hh)) = v;
         }
-        if (pair)
+        if (TRAIN && pair)                          // (read by the backward's d(W_O) product only)
             for (int ks = 0; ks < F16_CS; ++ks) *reinterpret_cast<h8*>(a.attn16 + frag_off((long)myseq, F16_CS, ks, 16 + myr, hh)) = z8;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): see fused_fwd16_kernel
@@ -378,9 +378,6 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
             ring.step_barrier(n); ++n;
         }
     } else {
-        if (TRAIN && val[0]) {                                      // d(W_O) contracts attn16 with d(ctx)16 over ALL rows (zeros here)
-            for (int ks = 0; ks < F16_CS; ++ks) *reinterpret_cast<h8*>(a.attn16 + frag_off((long)seq[0], F16_CS, ks, l32, hh)) = z8;
-        }
 #pragma unroll 1
         for (int j = 0; j < g.hv; ++j) {
             f32x16 cx = rows_of(a.boeff32 + 32 * j, hh);            // all-padding title: W_O b_v + b_o in every row

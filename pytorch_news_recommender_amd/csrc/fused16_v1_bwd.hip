@@ -11,8 +11,8 @@
 //                d(attn_b)^T, S^T = sum_b K_b Q_b^T, P^T, dS^T, and per block dV_b, dK_b, dQ_b -> dqkv16 rows of
 //                [head][Q0 K0 Q1 K1 V0 V1][32] columns (192 per head), bias column sums without atomics
 //   gemm16_dx (18 slabs for six heads), gemm16_tn: d(W_qkv) = dQKV^T X, d(W_add) = dZ^T ctx, and
-//       d(W_O) = d(o)^T attn over ALL stored rows (short titles: the compressed d(o) block against the expanded attn rows is the
-//       same sum); the ones column of attn16 makes d(b_o) one more column of that product
+//       d(W_O) = d(o)^T attn over the 32-row blocks of the titles with a real token (a short title's compressed d(o) block against
+//       its tile-row attn block is the same sum as token by token); the ones column of attn16 makes d(b_o) one more column of it
 //   all-padding titles (every attn row = b_v): d(b_o) += E, d(W_O) += E (x) b_v, d(b_v) += W_O^T E.
 #include <stdlib.h>
 
@@ -609,7 +609,7 @@ int launch_fused_bwd16v1(const Fused16Bwd& f, hipStream_t stream) {
                      L.splits_add, mp.nmap_add, mp.kmap_ctx, mp.nscale_add, f.d, f.dw_add, s_add, "dwadd_bwd");
     if (rc) return rc;
     rc = launch_tn16(2, dctx16, F16_DP, F16_DP, (const _Float16*)f.attn16, F16_DP, F16_DP, Mp, nullptr, (float*)(base + L.p_o),
-                     L.splits_o, mp.kmap_ctx, mp.kmap_attn, mp.nscale_o, f.d, f.dw_o, s_add, "dwo_bwd", f.db_o);
+                     L.splits_o, mp.kmap_ctx, mp.kmap_attn, mp.nscale_o, f.d, f.dw_o, s_add, "dwo_bwd", f.db_o, f.order, f.order_cnt, f.n_seq);
     if (rc) return rc;
     {
         TimingScope ts("closed16", s_add);

@@ -14,7 +14,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel symbol -> bench.py timer name
-TIMER_OF = [("fused_fwd16p_kernel", "fused_fwd16"), ("fused_fwd16_kernel<true, 1>", "fused_fwd16"), ("fused_fwd16_kernel<true, 2>", "fused64_fwd16"),
+TIMER_OF = [("fused_fwd16v1_kernel", "fused_fwd16"), ("fused_bwd16v1_attn_kernel", "fused_bwd16_attn"), ("gemm16_tn_kernel<true, 4", "dwo_bwd"),
+            ("fused_fwd16p_kernel", "fused_fwd16"), ("fused_fwd16_kernel<true, 1>", "fused_fwd16"), ("fused_fwd16_kernel<true, 2>", "fused64_fwd16"),
             ("fused_bwd16_pool_kernel<1>", "fused_bwd16_pool"), ("fused_bwd16_pool_kernel<2>", "fused64_bwd16_pool"),
             ("fused_bwd16_attn_kernel<1>", "fused_bwd16_attn"), ("fused_bwd16_attn_kernel<2>", "fused64_bwd16_attn"),
             ("gemm16_tn_kernel<true", "dwadd_bwd"), ("gemm16_tn_kernel<false", "dwqkv_bwd"),
@@ -97,8 +98,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--precision", default="fp16")
     ap.add_argument("--fp16-user-encoder", action="store_true")
+    ap.add_argument("--model", default="v0", choices=["v0", "v1"], help="v1: the nrms_v1 step of bench.py's variants")
     a = ap.parse_args()
-    res = collect(a.out_dir, a.steps, a.precision, ["--fp16-user-encoder"] if a.fp16_user_encoder else [])
+    res = collect(a.out_dir, a.steps, a.precision, (["--fp16-user-encoder"] if a.fp16_user_encoder else []) + (["--model", "v1"] if a.model == "v1" else []))
     print("HBM bytes per step: %.3f GB" % (res["step_bytes"] / 1e9))
     for n, v in list(res["by_kernel"].items())[:24]:
         print("   %-70s %.3f GB  (read %.3f, write %.3f; %.1f launches/step)" % (n[:70], v["total"] / 1e9, v["fetch_x2"] / 1e9, v["write"] / 1e9, v["launches_per_step"]))
