@@ -13,6 +13,15 @@ from pytorch_news_recommender_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+# NRMS_FUZZ_EXAMPLES=N: a longer, randomised campaign (the committed default: the same few dozen examples on every run)
+import os
+_N = os.environ.get("NRMS_FUZZ_EXAMPLES")
+_DERANDOMIZE = _N is None
+
+
+def _examples(default):
+    return int(_N) if _N else default
+
 
 @st.composite
 def cases(draw, min_width=4):
@@ -90,13 +99,13 @@ def _run(case, precision):
     assert not grads["news_encoder.word_embedding.0.weight"][0].any()
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_examples(30), deadline=None, derandomize=_DERANDOMIZE, suppress_health_check=list(HealthCheck))
 @given(cases())
 def test_fuzz_fp32(case):
     _run(case, "fp32")
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_examples(30), deadline=None, derandomize=_DERANDOMIZE, suppress_health_check=list(HealthCheck))
 @given(cases(min_width=60))
 def test_fuzz_fp16(case):
     _run(case, "fp16")
@@ -115,7 +124,7 @@ def v1_cases(draw):
                 p_drop=draw(st.sampled_from([0.0, 0.2])))
 
 
-@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=_examples(25), deadline=None, derandomize=_DERANDOMIZE, suppress_health_check=list(HealthCheck))
 @given(v1_cases())
 def test_fuzz_v1_fp16(case):
     from oracle import nrms_oracle as orc
