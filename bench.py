@@ -278,9 +278,9 @@ def v1_leg(dev, B):
         m = V1Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
         m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
         m = m.to(dev).train()
-        for _ in range(2):
+        for _ in range(3):
             m.train_step(batch)
-        n = 5
+        n = 10
         t = timed(lambda: m.train_step(batch), n)
         res[prec] = {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n}
         del m
