@@ -448,6 +448,10 @@ __global__ __launch_bounds__(F16_THREADS, F16_FWD_WGS) void fused_fwd16p_kernel(
     ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_steps; ring.wave = wave; ring.lane = lane; ring.l32 = l32; ring.hh = hh;
 #pragma unroll
     for (int i = 0; i < AH; ++i) ring.load_at(i, tile_at(i));       // (n_steps >= 7 > AH)
+    // the additive stage's per-row vectors (bias, query vector) live in LDS behind the ring: a global load per tile step in the
+    // additive loop puts a vmcnt wait -- which also drains the step's own stores -- in front of every tile's epilogue
+    float* addv = reinterpret_cast<float*>(smem + F16_FWD_SLOTS * F16_SLOT_DMA);          // [2][F16_QP]
+    for (int i = tid; i < 2 * F16_QP; i += F16_THREADS) addv[i] = i < F16_QP ? a.badd32[i] : a.qv32[i - F16_QP];
 
     h8 xf[F16_KS];
     {
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(F16_THREADS, F16_FWD_WGS) void fused_fwd16p_kernel(
         float score = 0.f;
 #pragma unroll 1
         for (int t = 0; t < F16_QT; ++t) {
-            const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
+            const f32x16 ba = rows_of(addv + 32 * t, hh), qq = rows_of(addv + F16_QP + 32 * t, hh);
             __builtin_amdgcn_sched_barrier(0);
             auto pre2 = [&](int g) { if (n + AH < n_steps) ring.load_piece_at(n + AH, tile_at(n + AH), g); };
             if (!valid && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
@@ -890,7 +894,7 @@ int launch_fused_fwd16(const Fused16Fwd& f, hipStream_t stream) {
     a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
     a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;
     const bool train = f.t16 != nullptr, two = f.S > 32;
-    const size_t lds = (size_t)(two ? 3 : F16_FWD_SLOTS) * F16_SLOT_DMA;
+    const size_t lds = (size_t)(two ? 3 : F16_FWD_SLOTS) * F16_SLOT_DMA + (size_t)2 * F16_QP * 4;     // (+ the paired kernel's additive vectors)
     a.dbg = 0;
 #ifdef NRMS_F16_EXPERIMENTS
     { const char* e = getenv("NRMS_F16_DBG"); a.dbg = e ? atoi(e) : 0; }

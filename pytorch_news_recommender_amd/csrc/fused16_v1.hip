@@ -241,6 +241,9 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
     ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_steps; ring.wave = wave; ring.lane = lane; ring.l32 = l32; ring.hh = hh;
 #pragma unroll
     for (int i = 0; i < AH; ++i) ring.load_at(i, tile_at(i));
+    // the additive stage's per-row vectors in LDS behind the ring (see fused_fwd16p_kernel)
+    float* addv = reinterpret_cast<float*>(smem + 3 * F16_SLOT_DMA);          // [2][F16_QP]
+    for (int i = tid; i < 2 * F16_QP; i += F16_THREADS) addv[i] = i < F16_QP ? a.badd32[i] : a.qv32[i - F16_QP];
 
     h8 xf[F16_KS];
     {
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(F16_THREADS, 2) void fused_fwd16v1_kernel(Fwd16V1Ar
         float score = 0.f;
 #pragma unroll 1
         for (int t = 0; t < F16_QT; ++t) {
-            const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
+            const f32x16 ba = rows_of(addv + 32 * t, hh), qq = rows_of(addv + F16_QP + 32 * t, hh);
             __builtin_amdgcn_sched_barrier(0);
             f32x16 tt = zero16();
             if (valid) tile_mma<true>(tt, ring, n, cf, pre); else idle_step();
@@ -489,7 +492,7 @@ int launch_fused_fwd16v1(const Fused16Fwd& f, int h, void* attn16, hipStream_t s
     a.badd32 = (const float*)(base + L.badd32); a.qv32 = (const float*)(base + L.qv32);
     a.attn16 = (_Float16*)attn16; a.ctx16 = (_Float16*)f.ctx16; a.t16 = (_Float16*)f.t16; a.w = f.w; a.out = f.out; a.drop = f.drop;
     const bool train = f.t16 != nullptr;
-    const size_t lds = (size_t)3 * F16_SLOT_DMA;
+    const size_t lds = (size_t)3 * F16_SLOT_DMA + (size_t)2 * F16_QP * 4;
     const void* fn = train ? (const void*)fused_fwd16v1_kernel<true> : (const void*)fused_fwd16v1_kernel<false>;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("fused_fwd16v1: hipFuncSetAttribute: %s", hipGetErrorString(e)); return NRMS_ELAUNCH; }
