@@ -102,6 +102,9 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? F16_FWD_WGS : 1) void fused_
     ring.smem = smem; ring.src = a.wtiles; ring.n_tiles = n_head_tiles + F16_QT; ring.wave = wave; ring.lane = lane; ring.l32 = l32; ring.hh = hh;
 #pragma unroll
     for (int i = 0; i < AH; ++i) ring.load(n_begin + i);
+    // the additive stage's per-row vectors in LDS behind the ring (see fused_fwd16p_kernel; visible after the prologue's barrier)
+    float* addv = reinterpret_cast<float*>(smem + (SB == 1 ? F16_FWD_SLOTS : 3) * F16_SLOT_DMA);      // [2][F16_QP]
+    for (int i = tid; i < 2 * F16_QP; i += F16_THREADS) addv[i] = i < F16_QP ? a.badd32[i] : a.qv32[i - F16_QP];
 
     // ---- this lane's x fragments: token 32 b + l32, features 16 s + 8 hh .. +7 (A operand of x W^T, B operand of W x^T)
     h8 xf[SB][F16_KS];
@@ -257,8 +260,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? F16_FWD_WGS : 1) void fused_
                                                                   //  epilogues across tiles and spill their accumulators)
         // tanh(y) = 1 - 2 / (exp(2 y) + 1) on v_exp / v_rcp: ~1e-7 absolute, far inside what fp16 keeps of it;
         // badd32 holds b * 2 log2(e), so exp(2 (x + b)) = exp2(x * c + b')
-        // (ordinary loads go BEFORE the tile's DMA: the memory counter is in order, waiting for a younger load would drain it)
-        const f32x16 ba = rows_of(a.badd32 + 32 * t, hh), qq = rows_of(a.qv32 + 32 * t, hh);
+        const f32x16 ba = rows_of(addv + 32 * t, hh), qq = rows_of(addv + F16_QP + 32 * t, hh);
         __builtin_amdgcn_sched_barrier(0);
         auto pre2 = [&](int g) { ring.load_group(n + AH, g); };
         if (!valid) ring.load(n + AH);
