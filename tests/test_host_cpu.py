@@ -218,6 +218,29 @@ def test_engine_scratch_bound_covers_library_sizes_and_flag_validation():
     assert b"flags" in lib.nrms_last_error()
 
 
+def test_fp16_descriptor_rules_without_gpu():
+    """What precision fp16 accepts is decided on the host (validate_desc): v0's fused kernels (no W_O, d_k <= 32, h <= 10), and with
+    use_output_proj the nrms_v1 news encoder (32 < d_k <= 50, padding-skipping path, no embedding dropout, seq_len <= 32).
+    The sizing calls answer 0 + an error text for everything else -- the host driver routes those passes to bf16x3."""
+    lib = _lib.load()
+    base = dict(n_seq=64, seq_len=20, d_model=300, n_heads=6, q_dim=200, vocab=1000, p_drop_embed=0.0, p_drop_ctx=0.2, precision=3,
+                use_output_proj=1, mask_mode=0, flags=_lib.NRMS_FLAG_PAD_ROW_ZERO, seed=0, loss_scale=0.0, p_drop_attn=0.0)
+    ok = _lib.EncoderDesc(**base)
+    fwd, bwd = lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(ok)), lib.nrms_encoder_bwd_workspace_bytes(ctypes.byref(ok))
+    assert fwd > 0 and bwd > 64 * 32 * 320 * 2 * 3, (fwd, bwd)            # (dZ16, d(ctx)16, dQKV16 ... of 64 titles)
+    for kw, word in ((dict(mask_mode=1), b"mask"), (dict(seq_len=40), b"seq_len"), (dict(n_heads=10), b"d_k"), (dict(flags=0), b"PAD_ROW_ZERO"),
+                     (dict(p_drop_embed=0.1), b"embedding dropout"), (dict(vocab=0, flags=0), b"news encoder"), (dict(d_model=320, n_heads=8), b"d_model"),
+                     (dict(p_drop_attn=0.1), b"p_drop_attn")):
+        bad = _lib.EncoderDesc(**dict(base, **kw))
+        assert lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(bad)) == 0, kw
+        msg = lib.nrms_last_error()
+        assert b"fp16" in msg and word in msg, (kw, msg)
+    v0 = _lib.EncoderDesc(**dict(base, use_output_proj=0, n_heads=10, seq_len=30))
+    assert lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(v0)) > 0
+    wide = _lib.EncoderDesc(**dict(base, use_output_proj=0))                     # six heads of 50 without W_O: not a fused shape
+    assert lib.nrms_encoder_fwd_scratch_bytes(ctypes.byref(wide)) == 0 and b"d_k <= 32" in lib.nrms_last_error()
+
+
 # ---- data feed (SURVEY a-12, f-2) -------------------------------------------------------------------
 def _g6_cfg(tmp_path=None):
     fx = synth.dataset_fixture_inputs()
