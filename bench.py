@@ -296,8 +296,10 @@ def v1_leg(dev, B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: steady state -- with 5 warm-up + 20 timed steps (0.09 s in all) the same box reads 2.5 ... 3.5 % lower (clocks, caches
+    # and the allocator are still settling: 150.4 ... 152.5 k against 155.8 ... 156.0 k users/s on one box, three runs each)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--users-per-gpu", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the secondary legs")
     ap.add_argument("--dense-padding", action="store_true",
