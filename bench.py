@@ -250,9 +250,9 @@ def naml_leg(dev, B):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     m = m.to(dev).train()
     batch = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch_naml(shape, seed=1).items()}
-    for _ in range(2):
+    for _ in range(3):
         m.train_step(batch)
-    n = 4
+    n = 10
     t = timed(lambda: m.train_step(batch), n)
     return {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n, "precision": "bf16x3",
             "workload": "B=%d, H=50, C=5, title 20 + abstract 40 words, d=300, news_feature_size=800" % B}
@@ -278,9 +278,9 @@ def v1_leg(dev, B):
         m = V1Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
         m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
         m = m.to(dev).train()
-        for _ in range(3):
+        for _ in range(10):
             m.train_step(batch)
-        n = 10
+        n = 30
         t = timed(lambda: m.train_step(batch), n)
         res[prec] = {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n}
         del m
