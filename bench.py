@@ -9,7 +9,7 @@ MIND shapes hist=50 cand=5 title_len=30 d=300 V=45800, 512 users per GPU).
 One step = forward + CE(label 0) + backward + [RCCL all-reduce of the flat gradient] + fused
 Adam over all 14.4 M parameters, dropout 0.2 on, synthetic batch already resident in HBM.
 Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (HIP events on the launch
-stream, a second pass over the same K steps), `roofline.step_frac` the whole step against the dense
+stream, a separate pass over the same K steps, run before the warm-up and the timed region), `roofline.step_frac` the whole step against the dense
 fp16/bf16 MFMA peak by BASELINE.md's formula, `cpu_baseline` the oracle's reference-shaped train
 step timed on this box's host cores (N=1 only, bounded sample), `modes` the other precision modes
 and the drop-in autograd + torch.optim.Adam loop on the same batch.
@@ -368,17 +368,35 @@ def main():
         return model.train_step(batch, world_size=world, all_reduce=reduce)
 
     log("model ready on %s (rank %d/%d), %d users/GPU, precision %s" % (dev, rank, world, B, args.precision))
+    # ---- the instrumented pass FIRST: K steps with the per-kernel HIP-event timers on (two events created and recorded
+    # around each launch slow a step by a few %, so they are NOT on during the timed region) and the helper streams off (a
+    # kernel's duration under the timed region's overlap is not its own); `kernels` / `roofline` come from this pass, on every
+    # rank so collectives stay aligned.  It runs before the W warm-up steps and the timed region, not after them: a process
+    # that has stepped for only W = 5 steps is still 2.5 ... 3.5 % below its steady state (clocks, caches; same box: 150.4 ...
+    # 152.5 k users/s after 5 steps, 155.8 ... 156.0 k after 30 or 50), and sustained training is what `value` stands for.
+    step()
+    torch.cuda.synchronize()
+    log("first step done")
+    os.environ["NRMS_NO_SIDE_STREAMS"] = "1"
+    for _ in range(args.steps):            # K settling steps in the same configuration, not recorded (the kernels' durations
+        step()                             # are also 5 % longer in a process that has only just started stepping)
+    eng.timing_reset()
+    eng.timing(True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt_instr = time.perf_counter() - t1
+    eng.timing(False)
+    os.environ.pop("NRMS_NO_SIDE_STREAMS", None)
+    log("instrumented pass: %d settling + %d recorded steps, the recorded ones in %.3f s" % (args.steps, args.steps, dt_instr))
     for i in range(args.warmup):
         step()
-        if i == 0:
-            torch.cuda.synchronize()
-            log("first step done")
     torch.cuda.synchronize()
     log("warm-up done")
-    # ---- the timed region: EXACTLY K un-instrumented steps.  (The per-kernel HIP-event timers -- two events
-    # created and recorded around each launch of a step -- slow a step by a few %, so they are NOT on during the
-    # timed region; the per-kernel durations of `kernels` / `roofline` come from a second, instrumented pass over
-    # the same K steps right after it, on every rank so collectives stay aligned.)
+    # ---- the timed region: EXACTLY K un-instrumented steps
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -392,21 +410,6 @@ def main():
     loss = float(loss_sum) / B
     log("timed region: %d steps in %.3f s" % (args.steps, dt))
     eng.check_ids()
-    # The timed region overlaps the two weight-gradient GEMMs with other kernels on helper streams; a kernel's
-    # duration under that overlap is not its own, so the instrumented pass serialises the step (one stream).
-    os.environ["NRMS_NO_SIDE_STREAMS"] = "1"
-    eng.timing_reset()
-    eng.timing(True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt_instr = time.perf_counter() - t1
-    eng.timing(False)
-    os.environ.pop("NRMS_NO_SIDE_STREAMS", None)
-    log("instrumented pass: %d steps in %.3f s" % (args.steps, dt_instr))
 
     # ---- data-parallel facts (every rank takes part; rank 0 reports)
     dp = None
@@ -572,8 +575,8 @@ def main():
                                        {"fp32": "f32-input MFMA dense peak", "bf16": "bf16 MFMA dense peak", "fp16": "fp16 MFMA dense peak",
                                         "bf16x3": "bf16 dense peak / 3 (3 bf16 MFMAs per fp32-equivalent step by construction)"}[kprec[dom]]),
                          "avg_launch_ms": dom_ms / max(dom_n, 1),
-                         "timing_note": "kernel durations: HIP events on the launch stream, recorded in a second pass of the "
-                                        "same %d steps right after the (un-instrumented) timed region, with the helper streams off "
+                         "timing_note": "kernel durations: HIP events on the launch stream, recorded in a separate pass of the "
+                                        "same %d steps (after as many unrecorded settling steps) before the warm-up and the (un-instrumented) timed region, with the helper streams off "
                                         "(NRMS_NO_SIDE_STREAMS) so that no two kernels share the GPU; that pass ran at "
                                         "%.2f ms/step" % (args.steps, dt_instr / args.steps * 1e3),
                          "algorithmic_per_step": by if bound == "hbm" else fl,
