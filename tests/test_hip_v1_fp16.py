@@ -272,3 +272,23 @@ def test_v1_fp16_deferred_wqkv_backward_equals_plain_backward():
     assert len(seen) == 1 and seen[0] > 0.0
     for n in lay.names:
         assert torch.equal(lay.view(g_split, n), lay.view(g_plain, n)), n
+
+
+def test_run_v0_entry_point_with_nrms_v1_in_fp16(tmp_path, monkeypatch):
+    """The reference's entry contract (run_v0.py --model nrms_v1 -> model.Model(config, args) -> model.nrms_v1) with
+    --precision fp16 on the synthetic corpus: MyDataset batches, autograd + torch.optim.Adam through the fused fp16 news encoder
+    (the default title geometry of config.py: 20-word titles, six title heads), a dev evaluation, and -- if one was written --
+    a checkpoint with the reference's v1 names behind the wrapper's prefix."""
+    import os
+    from pytorch_news_recommender_amd import run_v0
+    monkeypatch.chdir(tmp_path)
+    hist = run_v0.main(["--model", "nrms_v1", "--dataset", "synthetic", "--precision", "fp16", "--epochs", "1", "--synthetic_users", "256",
+                        "--batch_size", "32", "--max_batches", "6", "--num_workers", "0", "--description", "T",
+                        "--data_path", str(tmp_path / "data_processed"), "--save_path", str(tmp_path / "save")])
+    assert len(hist["losses"]) == 6 and np.isfinite(hist["losses"]).all()
+    assert hist["aucs"] and 0.0 < hist["aucs"][-1][1] < 1.0
+    save = tmp_path / "save"
+    for f in (os.listdir(save) if os.path.isdir(save) else []):       # (a checkpoint is written only when the dev AUC improves on 0.5)
+        if f.endswith(".ckpt"):
+            sd = torch.load(os.path.join(save, f), map_location="cpu", weights_only=True)
+            assert "model.news_encoder.multi_head_self_attention.output_linear.weight" in sd
