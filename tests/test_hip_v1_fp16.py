@@ -292,3 +292,33 @@ def test_run_v0_entry_point_with_nrms_v1_in_fp16(tmp_path, monkeypatch):
         if f.endswith(".ckpt"):
             sd = torch.load(os.path.join(save, f), map_location="cpu", weights_only=True)
             assert "model.news_encoder.multi_head_self_attention.output_linear.weight" in sd
+
+
+@pytest.mark.parametrize("variant", ["v0", "v1"])
+def test_fp16_backward_without_the_kept_forward_scratch_rebuilds_the_same_lists(variant, monkeypatch):
+    """NRMS_FLAG_FWD_SCRATCH_KEPT is an optimisation of the host driver (the backward reads the token / title lists its forward
+    left in acts.scratch); a C-ABI caller that does not set it gets the lists rebuilt in the backward's workspace (and the
+    context-dropout mask regenerated) -- the same gradients, bit for bit.  Both fused fp16 news encoders, dropout on."""
+    from pytorch_news_recommender_amd import _lib as lib_mod
+    from tests.test_hip_parity import make_model
+    if variant == "v1":
+        shape, title_heads, _ = V1_SHAPES["long_titles"]
+        model = make_v1(shape, synth.make_params_v1(shape, seed=3), title_heads, dropout=0.2, precision="fp16").train()
+    else:
+        shape = synth.Shape(n_words=3000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                            batch_size=8, history_len=20, n_candidates=5, n_words_title=30)
+        model = make_model(shape, synth.make_params(shape, seed=3), dropout=0.2, precision="fp16").train()
+    batch = synth.make_batch(shape, seed=4, ragged=True, min_title=1, all_pad_title=True)
+    eng, flat = model.engine, model._flat
+    bt, ct, cm = (torch.from_numpy(batch[k]).cuda() for k in ("browsed_titles", "candidate_titles", "candidate_mask"))
+    grads = []
+    for kept in (True, False):
+        if not kept:
+            monkeypatch.setattr(lib_mod, "NRMS_FLAG_FWD_SCRATCH_KEPT", 0)
+        s = eng.forward(flat, bt, ct, cm, training=True, p_drop=0.2, seed=77)
+        dsc = (torch.randn(s.shape, generator=torch.Generator().manual_seed(5)) * 1e-2).cuda()
+        g = torch.zeros_like(flat)
+        eng.backward(flat, g, dsc)
+        grads.append(g)
+    assert float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1])
