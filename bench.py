@@ -40,7 +40,9 @@ PEAKS = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_16_MFMA_TFLOPS / 3.0, "bf1
 DTYPES = {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA inputs hi+lo, fp32 accumulate, fp32 storage)",
           "bf16": "bf16 (MFMA inputs), fp32 accumulate, fp32 storage",
           "fp16": "f16 (MFMA inputs and saved activations; fp32 accumulate, softmax, loss, master weights and Adam)"}
-PARITY = {"fp32": "<=1.5e-7", "bf16x3": "<=5e-7", "bf16": "~3e-4 (fails 1e-4)", "fp16": "4.4e-5 (inside 1e-4)"}
+# bars asserted against the ORACLE at the bench size (tests/test_hip_fullsize.py::test_every_mode_against_the_oracle_at_full_size)
+PARITY = {"fp32": "<= 1e-5 (asserted vs the oracle at this size)", "bf16x3": "<= 2e-5 (asserted vs the oracle at this size)",
+          "bf16": "~3e-4 (fails 1e-4; never a default)", "fp16": "<= 1e-4 (asserted vs the oracle at this size; measured value in config)"}
 FLOP_PER_USER_TRAIN = 3558309000.0  # BASELINE.md section 2 / SURVEY 8d: nrms_v0, H=50, C=5, L=30, d=300, h=10, q=200
 
 
@@ -113,8 +115,11 @@ OTHER_TIMERS = ("tn_reduce", "red16", "prep16", "title_order", "cast16", "split_
                 "permute_rows", "compact_rows", "sanitize_ids", "fill_pad_rows", "padsum")
 
 
+_T0 = time.time()
+
+
 def log(msg):
-    print("[bench] " + msg, file=sys.stderr, flush=True)
+    print("[bench %6.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def host_threads():
@@ -124,7 +129,25 @@ def host_threads():
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) can be far below its affinity set: more threads than that
+    # only fight each other
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    log("host cores: os.cpu_count %s, affinity %d, cgroup quota %s" % (os.cpu_count(), n, quota))
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
 
 
 def cpu_model_name():
@@ -159,18 +182,21 @@ def cpu_baseline(shape, budget_s=60.0):
 
     dt32 = run(32, 3, 5)
     log("cpu baseline: B=32 %.2f s/step on %d threads" % (dt32, threads))
+    # the bench's own batch (512 users) when 1 warm-up + 3 timed steps of it fit the budget; a step gets cheaper per user as B
+    # grows (measured 0.35 ... 0.45 of the B = 32 cost per user at B = 256), estimated at 0.5 to stay on the safe side
     big = 64
     for cand in (512, 256, 128):
-        if dt32 * cand / 32.0 * 8 <= budget_s:          # steps get cheaper per user as B grows: a safe over-estimate
+        if dt32 * cand / 32.0 * 0.5 * 4 <= budget_s:
             big = cand
             break
-    dtb = run(big, 3, 5)
+    dtb = run(big, 1, 3)
     log("cpu baseline: B=%d %.2f s/step" % (big, dtb))
     best = max((32 / dt32, 32, dt32), (big / dtb, big, dtb))
     return {"value": best[0], "unit": "users/s", "cores": threads, "kind": "port", "cpu": cpu_model_name(),
-            "sample": "3 warm-up + 5 timed train steps at B=32 and at B=%d (the largest of 512/256/128/64 fitting %.0f s), same "
-                      "H/C/L/d/V, dropout 0.2, per-slot encoder loop + torch Adam, fp32, torch %s CPU; value = the better of "
-                      "the two (B=%d)" % (big, budget_s, torch.__version__, best[1]),
+            "sample": "3 warm-up + 5 timed train steps at B=32 and 1 warm-up + 3 timed at B=%d (the largest of 512/256/128/64 "
+                      "estimated to fit %.0f s), same H/C/L/d/V, dropout 0.2, per-slot encoder loop + torch Adam, fp32, torch %s CPU, "
+                      "%d threads = min(affinity set, cgroup CPU quota) of this process, i.e. every core it may use; value = the better of the two (B=%d)" % (
+                          big, budget_s, torch.__version__, threads, best[1]),
             "by_batch": {"32": {"users_per_s": 32 / dt32, "ms_per_step": dt32 * 1e3},
                          str(big): {"users_per_s": big / dtb, "ms_per_step": dtb * 1e3}},
             "ms_per_step": best[2] * 1e3}
@@ -203,35 +229,49 @@ def eval_path_leg(model, dev):
                for b in DataLoader(ds, batch_size=per_batch, shuffle=False, num_workers=0)]
     model.eval()
     eng = model.engine
-    ev = {"impressions": n_imp, "batch": per_batch, "slots_per_impression": 350}
-    with torch.no_grad():
-        def run_all():
-            for b in batches:
-                model(b)
-        model.dedup_inference = False
-        run_all()
-        ev["all_slots_impressions_per_s"] = n_imp * 3 / timed(run_all, 3)
-        model.dedup_inference = True
-        strip = [{k: v for k, v in b.items() if k not in ("browsed_ids", "candidate_ids")} for b in batches]
 
-        def run_hash():
-            for b in strip:
-                model(b)
-        run_hash()
-        ev["unique_titles_impressions_per_s"] = n_imp * 3 / timed(run_hash, 3)
-        ev["unique_title_fraction"] = model.last_unique_titles / float(per_batch * 350)
+    def measure():
+        ev = {}
+        with torch.no_grad():
+            def run_all():
+                for b in batches:
+                    model(b)
+            model.dedup_inference = False
+            run_all()
+            ev["all_slots_impressions_per_s"] = n_imp * 3 / timed(run_all, 3)
+            model.dedup_inference = True
+            strip = [{k: v for k, v in b.items() if k not in ("browsed_ids", "candidate_ids")} for b in batches]
 
-        def run_cached():
-            eng.news_cache_begin()
-            for b in batches:
-                model(b)
-            return eng.news_cache_end()
-        run_cached()
-        t = timed(run_cached, 3)
-        stats = run_cached()
-        ev["news_cache_impressions_per_s"] = n_imp * 3 / t
-        ev["news_cache_encoded_titles"] = stats["encoded"]
-        ev["news_cache_lookups"] = stats["lookups"]
+            def run_hash():
+                for b in strip:
+                    model(b)
+            run_hash()
+            ev["unique_titles_impressions_per_s"] = n_imp * 3 / timed(run_hash, 3)
+            ev["unique_title_fraction"] = model.last_unique_titles / float(per_batch * 350)
+
+            def run_cached():
+                eng.news_cache_begin()
+                for b in batches:
+                    model(b)
+                return eng.news_cache_end()
+            run_cached()
+            t = timed(run_cached, 3)
+            stats = run_cached()
+            ev["news_cache_impressions_per_s"] = n_imp * 3 / t
+            ev["news_cache_encoded_titles"] = stats["encoded"]
+            ev["news_cache_lookups"] = stats["lookups"]
+        return ev
+
+    # precision "fp16" evaluates in bf16x3 unless config.fp16_inference is set (AUC parity: evaluation scores 2e-6 from the oracle)
+    keep = bool(getattr(cfg, "fp16_inference", False))
+    cfg.fp16_inference = False
+    ev = {"impressions": n_imp, "batch": per_batch, "slots_per_impression": 350,
+          "inference_precision": "bf16x3" if cfg.precision in ("fp16", "bf16x3") else cfg.precision}
+    ev.update(measure())
+    if cfg.precision == "fp16":
+        cfg.fp16_inference = True
+        ev["fp16_inference_opt_in"] = measure()
+    cfg.fp16_inference = keep
     model.train()
     return ev
 
@@ -270,11 +310,13 @@ def v1_leg(dev, B):
     params = synth.make_params_v1(shape, seed=0)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch(shape, seed=1, batch_size=B).items()}
     res = {}
-    for prec in ("fp16", "bf16x3"):
+    # "default": config.precision = "fp16" as the headline uses it -- for nrms_v1 that keeps the W_O news encoder in bf16x3 (its
+    # fused fp16 form is outside the absolute 1e-4 at this size, so it is opt-in: config.fp16_v1_news_encoder)
+    for tag, opt_in in (("default", False), ("fp16_news_encoder_opt_in", True)):
         cfg = Config("nrms_v1")
         cfg.__nrms__()
         cfg.num_attention_heads, cfg.title_heads_num = 10, 6
-        cfg.dropout, cfg.learning_rate, cfg.precision = 0.2, 1e-3, prec
+        cfg.dropout, cfg.learning_rate, cfg.precision, cfg.fp16_v1_news_encoder = 0.2, 1e-3, "fp16", opt_in
         m = V1Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.weight"])
         m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
         m = m.to(dev).train()
@@ -282,13 +324,14 @@ def v1_leg(dev, B):
             m.train_step(batch)
         n = 30
         t = timed(lambda: m.train_step(batch), n)
-        res[prec] = {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n}
+        res[tag] = {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n}
         del m
-    out = dict(res["fp16"])
-    out.update({"precision": "fp16", "bf16x3": res["bf16x3"],
-                "score_parity_vs_fp32": "fp16: rms 4.2e-5, max 1.56e-4 over the 2 555 scores of this batch (score rms 0.092, max 0.36; "
-                                        "2 % of them further than 1e-4) -- profiles/r03_v1_fullsize_parity.txt, DESIGN.md section 2; "
-                                        "bf16x3: 1e-6",
+    out = dict(res["default"])
+    out.update({"precision": "bf16x3 (what config.precision = 'fp16' selects for nrms_v1: scores 2e-6 from the oracle at this size, "
+                             "tests/test_hip_v1_fp16.py::test_v1_default_routing_against_the_oracle_at_the_benchmarked_size)",
+                "fp16_news_encoder_opt_in": dict(res["fp16_news_encoder_opt_in"], score_parity=(
+                    "OUTSIDE north_star's absolute 1e-4: max 1.56e-4 over the 2 555 scores of this batch, 2 % of them beyond 1e-4 "
+                    "(score rms 0.092, max 0.36) -- config.fp16_v1_news_encoder = True, never a default")),
                 "workload": "B=%d, H=50, C=5, title 20 words, d=300, 6 title heads / 10 user heads, W_O, candidate mask" % B})
     return out
 
@@ -301,6 +344,8 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--users-per-gpu", type=int, default=512)
+    ap.add_argument("--resident-batches", type=int, default=32,
+                    help="distinct synthetic batches resident in HBM that the steps cycle over (1 = replay one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the secondary legs")
     ap.add_argument("--dense-padding", action="store_true",
                     help="diagnostics: process padding tokens densely (as if embedding row 0 were not zero)")
@@ -316,8 +361,9 @@ def main():
                     help="precision fp16: run the user encoder (3 %% of the flops) on the fused fp16 kernels too instead of "
                          "bf16x3 -- faster, but the scores then sit AT the 1e-4 bar on 512-user batches")
     ap.add_argument("--precision", default="fp16", choices=["fp32", "bf16x3", "bf16", "fp16"],
-                    help="fp16 (default): fused one-wave-per-title kernels, scores 4.4e-5 from the reference (bar 1e-4); "
-                         "bf16x3: split-bf16 projections (5e-7); fp32 = exact f32 MFMA; bf16 misses the bar (3e-4)")
+                    help="fp16 (default): fused one-wave-per-title kernels, scores inside 1e-4 of the oracle at 512 users "
+                         "(the measured maximum is in the JSON line); bf16x3: split-bf16 projections (2e-6); fp32 = exact f32 MFMA; "
+                         "bf16 misses the bar (3e-4)")
     args = ap.parse_args()
 
     # N > 1: have RCCL write its topology / algorithm choices (rings, trees, channels, transports) to a per-rank file so
@@ -355,8 +401,13 @@ def main():
     model._rank_salt = rank * 0x632BE59BD9B4E019
     eng = model.engine
     parallel.broadcast_parameters(model._flat)
-    batch_np = synth.make_batch(shape, seed=1 + rank, batch_size=B)      # each rank: its own users
-    batch = {k: torch.from_numpy(v).to(dev) for k, v in batch_np.items()}
+    # each rank: its own users; the timed loop cycles over N_BATCHES distinct resident batches, so word ids, scatter groups,
+    # title classes and cache state differ from step to step and `loss` stays a training loss (one replayed batch is memorised
+    # within a few dozen steps)
+    N_BATCHES = max(1, args.resident_batches)
+    batches_np = [synth.make_batch(shape, seed=1 + rank + 1000 * i, batch_size=B) for i in range(N_BATCHES)]
+    batches = [{k: torch.from_numpy(v).to(dev) for k, v in b.items()} for b in batches_np]
+    batch_np, batch = batches_np[0], batches[0]
     reduce = None
     if world > 1:
         if args.grad_sync == "sharded":
@@ -364,8 +415,33 @@ def main():
         else:
             reduce = parallel.GradAllReduce()
 
+    counter = [0]
+
     def step():
-        return model.train_step(batch, world_size=world, all_reduce=reduce)
+        b = batches[counter[0] % N_BATCHES]
+        counter[0] += 1
+        return model.train_step(b, world_size=world, all_reduce=reduce)
+
+    # ---- score parity of the timed mode, measured here (outside every timed region): the training forward of the timed
+    # precision against the library's exact fp32 mode (itself pinned to the oracle at this size by
+    # tests/test_hip_fullsize.py::test_every_mode_against_the_oracle_at_full_size) on timed batch 0, dropout off, initial weights
+    def score_gap():
+        p_keep, prec_keep = cfg.dropout, cfg.precision
+        cfg.dropout = 0.0
+        try:
+            with torch.no_grad():
+                bt, ct, cm = batch["browsed_titles"], batch["candidate_titles"], batch["candidate_mask"]
+                cfg.precision = "fp32"
+                ref = model.engine.forward(model._flat, bt, ct, cm, training=True).clone()
+                cfg.precision = prec_keep
+                got = model.engine.forward(model._flat, bt, ct, cm, training=True)
+                e = (got - ref)[cm == 1].abs()
+                return float(e.max()), float(ref[cm == 1].abs().max())
+        finally:
+            cfg.dropout, cfg.precision = p_keep, prec_keep
+            model.engine        # re-applies config.precision
+
+    parity_init = score_gap() if rank == 0 else None
 
     log("model ready on %s (rank %d/%d), %d users/GPU, precision %s" % (dev, rank, world, B, args.precision))
     # ---- the instrumented pass FIRST: K steps with the per-kernel HIP-event timers on (two events created and recorded
@@ -480,11 +556,10 @@ def main():
 
     out = None
     if rank == 0:
-        live = float((batch_np["browsed_titles"] != 0).sum() + (batch_np["candidate_titles"] != 0).sum())
-        live_frac = live / float(B * (shape.history_len + shape.n_candidates) * shape.n_words_title)
+        live = float(sum((b["browsed_titles"] != 0).sum() + (b["candidate_titles"] != 0).sum() for b in batches_np))
+        live_frac = live / float(N_BATCHES * B * (shape.history_len + shape.n_candidates) * shape.n_words_title)
         compact = bool(eng.pad_row_zero)
-        titles = np.concatenate([batch_np["browsed_titles"].reshape(-1, shape.n_words_title),
-                                 batch_np["candidate_titles"].reshape(-1, shape.n_words_title)])
+        titles = np.concatenate([b[k].reshape(-1, shape.n_words_title) for b in batches_np for k in ("browsed_titles", "candidate_titles")])
         allpad_frac = 1.0 - float((titles != 0).any(axis=1).mean())
         fp16_news = args.precision == "fp16"
         work = kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news, bool(args.fp16_user_encoder))
@@ -551,7 +626,11 @@ def main():
         out = {
             "metric": "users/sec (train step) NRMS MIND-small hist=50 cand=5",
             "value": users_per_s, "unit": "users/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "warmup_effective": 1 + 2 * args.steps + args.warmup,
+            "warmup_note": "steps this process had run when the timed region started: 1 first step + K settling + K instrumented "
+                           "(per-kernel timers, helper streams off) + W warm-up; steady state is what `value` reports -- a process "
+                           "that has stepped only W = 5 times reads 2.5 ... 3.5 % lower (DESIGN 6)",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "configs[1] shapes: NRMS(nrms_v0) train step, %d users/GPU, hist=50, "
                                    "cand=5, title_len=30, d=300, h=10, q=200, V=45800, dropout=0.2, Adam(lr=1e-3)" % B,
@@ -562,7 +641,12 @@ def main():
                                                   "embedding row 0 is zero" if compact else
                                                   "dX + embedding scatter (dead values)"),
                        "parallelism": "dp%d" % world, "precision": args.precision,
-                       "score_parity_vs_reference": PARITY[args.precision]},
+                       "resident_batches": N_BATCHES,
+                       "score_parity_vs_reference": (
+                           "max |score - exact fp32 mode| = %.2e over the valid scores of timed batch 0 (max |score| %.3f), training "
+                           "forward, dropout off, initial weights, measured in this run; the fp32 mode is pinned to the oracle at this "
+                           "size to 1e-5 and this mode to 1e-4 by tests/test_hip_fullsize.py" % parity_init),
+                       "score_parity_max_abs": parity_init[0]},
             "loss": loss,
             "roofline": {"bound": bound, "kernel": dom, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": achieved / peak, "traffic": traffic,
@@ -598,6 +682,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         modes = {}
         n = max(3, args.steps // 2)
+        log("secondary legs: modes")
         try:
             for prec in ("bf16x3", "fp32", "fp16"):
                 if prec == args.precision:
@@ -630,10 +715,12 @@ def main():
         except Exception as e:
             modes["error"] = repr(e)
         out["modes"] = modes
+        log("secondary legs: variants (nrms_naml, nrms_v1)")
         try:
             out["variants"] = {"nrms_naml": naml_leg(dev, B), "nrms_v1": v1_leg(dev, B)}
         except Exception as e:       # secondary leg only
             out["variants"] = {"error": repr(e)}
+        log("secondary legs: evaluation path")
         try:
             out["eval_path"] = eval_path_leg(model, dev)
         except Exception as e:       # secondary leg only: never lose the headline line
@@ -642,7 +729,9 @@ def main():
     # host thread that launches the GPU legs above (the ~50-launch bf16x3 step measured 58 k instead of 72 k users/s behind it)
     if world == 1 and not args.no_cpu_baseline and rank == 0:
         torch.cuda.synchronize()
+        log("cpu baseline")
         out["cpu_baseline"] = cpu_baseline(shape, budget_s=args.cpu_budget_s)
+        log("done")
     if rank == 0:
         print(json.dumps(out), flush=True)
     parallel.barrier()

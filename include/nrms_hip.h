@@ -14,11 +14,15 @@
  *     are caller buffers; workspace sizes come from the *_workspace_bytes queries.
  *   - every call is asynchronous on `stream`, re-entrant across streams, and returns
  *     0 on success or a negative NRMS_E* code; nrms_last_error() gives the (thread-local) text.
- *     One exception to the re-entrancy: nrms_encoder_bwd forks its weight-gradient GEMMs onto helper streams the library
- *     creates once per process (two for NRMS_PRECISION_FP16, one for the other modes) and joins them before it returns
- *     (or in nrms_encoder_bwd_wqkv, NRMS_FLAG_DEFER_WQKV), so one backward may be in flight per process at a time
- *     (serialise them if several host threads train in one process; one process per GPU -- the deployment this library is
- *     built for -- never does).  The environment variable NRMS_NO_SIDE_STREAMS keeps everything on `stream`.
+ *     Helper streams: nrms_encoder_bwd forks its weight-gradient GEMMs (and the fp16 calls their id-only / weight-only
+ *     bookkeeping) onto two helper streams that belong to the pair (device, caller `stream`): created the first time that
+ *     stream makes such a call, never shared between caller streams, forked from and joined back into `stream` with events
+ *     inside the call -- before it returns, on the error paths too, or in nrms_encoder_bwd_wqkv under NRMS_FLAG_DEFER_WQKV.
+ *     Several backwards may therefore be in flight in one process as long as they are on DIFFERENT streams (two engines on
+ *     two streams train concurrently); calls on the SAME stream must be issued by one host thread at a time, as stream order
+ *     demands anyway.  A pending deferred join (NRMS_FLAG_DEFER_WQKV, fp16) is flushed by the next nrms_encoder_fwd /
+ *     nrms_encoder_bwd on that stream in ANY precision, so a caller that never calls nrms_encoder_bwd_wqkv still gets
+ *     correct ordering.  The environment variable NRMS_NO_SIDE_STREAMS keeps everything on `stream`.
  *   - all matrices are row-major and dense; fp32 unless stated.  M = n_seq * seq_len.
  *   - gradients are ACCUMULATED (+=) into the caller's buffers (zero them per step, as
  *     `model.zero_grad()` does at train_eval.py:115).
@@ -109,7 +113,11 @@ typedef struct nrms_encoder_desc {
     float    loss_scale;   /* NRMS_PRECISION_FP16 backward only: the fp16 gradient tensors are carried multiplied by a
                               power of two and the results divided by it.  <= 0 (recommended): chosen on the device per
                               call as the power of two that puts max |dout| into [64, 128), so no loss reduction, batch
-                              size or world size can overflow or flush the fp16 tensors; > 0: used as given */
+                              size or world size can overflow or flush the fp16 tensors -- 2^9 of head room for the tensors
+                              derived from dout (dZ, d(ctx), dQKV, dX).  Weights of unusual norm can use that up: the
+                              gradients then come out inf / nan, nrms_adam_step_guarded / nrms_grad_guard count them, and
+                              the caller backs off with loss_scale = -n (a negative integer, n <= 24): n more powers of
+                              two of head room, max |dout| into [64, 128) / 2^n.  > 0: used as given */
     float    p_drop_attn;  /* dropout on the attention PROBABILITIES (nrms_naml.py:36-39, dropout site 2; 0 in nrms_v0 /
                               nrms_v1); not combinable with NRMS_PRECISION_FP16.  With NRMS_FLAG_PAD_ROW_ZERO an
                               all-padding sequence keeps a closed form: context of query i = b_v x (kept keys of i) /
@@ -237,6 +245,18 @@ int nrms_ce_loss_fwd_bwd(int32_t B, int32_t C, const float* scores, float* loss_
 int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    double lr, double beta1, double beta2, double eps, int32_t step, float grad_scale,
                    void* stream);
+
+/* The same update, but an element whose (scaled) gradient is inf or nan is left out -- param, exp_avg and exp_avg_sq keep
+ * their values there, so one overflowing fp16 backward cannot poison Adam's moments for the rest of training -- and counted:
+ * *n_nonfinite (device int32, caller-zeroed) += number of elements skipped.  The caller reads the counter when it chooses to
+ * (asynchronously) and lowers the fp16 loss scale (nrms_encoder_desc.loss_scale = -n).  Data parallel: every rank applies
+ * this to the same reduced gradient and skips the same elements. */
+int nrms_adam_step_guarded(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                           double lr, double beta1, double beta2, double eps, int32_t step, float grad_scale,
+                           int32_t* n_nonfinite, void* stream);
+/* For callers that run their own optimizer (torch.optim.Adam on the autograd path, train_eval.py:126-127): inf / nan elements
+ * of grad [n] are replaced by 0 in place and counted into *n_nonfinite (device int32, caller-zeroed). */
+int nrms_grad_guard(size_t n, float* grad, int32_t* n_nonfinite, void* stream);
 
 /* Per-impression AUC of evaluate() (train_eval.py:219-227,255-271 + evaluation.py:26-27):
  * scores, labels [n_imp, max_c] (padded), lens [n_imp] = candidates actually shown;

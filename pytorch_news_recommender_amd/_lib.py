@@ -81,6 +81,9 @@ SIGNATURES = {
                                        C.c_void_p]),
     "nrms_adam_step": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_int32, C.c_float, C.c_void_p]),
+    "nrms_adam_step_guarded": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                         C.c_double, C.c_double, C.c_double, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "nrms_grad_guard": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_impression_auc": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "nrms_dropout_keep_mask": (C.c_int, [C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p,

@@ -259,7 +259,8 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     // compacts the token rows and gathers the embeddings (event 5 forks, event 4 joins in front of the fused kernel)
     SideSet* ss = (gather && skip_pad_rows(desc)) ? side_streams_for(s) : nullptr;
     hipStream_t s_prep = ss != nullptr ? ss->s[1] : s;
-    int rc;
+    int rc = fused_bwd16_join(s);                  // a deferred join of an earlier backward on this stream uses the same events
+    if (rc) return rc;
     if (ss != nullptr) {
         rc = side_order(ss, 5, s, s_prep, "encoder_fwd(fp16)");
         if (rc) return rc;
@@ -672,6 +673,10 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     float* dq_partial = (float*)(base + L.dq_partial);
     void* wplanes = (void*)(base + L.wplanes);
 
+    // a deferred fp16 join still pending on this stream (NRMS_FLAG_DEFER_WQKV without nrms_encoder_bwd_wqkv yet): order it
+    // first -- the events and helper streams below are the same set
+    rc = fused_bwd16_join(s);
+    if (rc) return rc;
     SideSet* ss = side_streams_for(s);
     const bool side = ss != nullptr;
     hipStream_t s2 = side ? ss->s[0] : s;

@@ -578,11 +578,14 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 // gradient tensors derived from dout have ~2^9 of head room and ~2^20 below them whatever the caller's loss reduction,
 // batch size or data-parallel world size is).  A fixed scale (desc.loss_scale > 0) is used as given.
 // sc[0] = scale, sc[1] = 1 / scale (both exact powers of two); every kernel that removes the scale reads sc[1].
+// desc.loss_scale = -n (a negative integer): n more powers of two of head room, max |dout| into [64, 128) / 2^n -- the
+// caller's back-off after nrms_adam_step_guarded / nrms_grad_guard reported non-finite gradients.
 __device__ __forceinline__ float loss_scale_from_max(unsigned max_bits, float fixed) {
     if (fixed > 0.f) return fixed;
     const int e = (int)((max_bits >> 23) & 0xFF) - 127;             // 2^e <= max < 2^(e+1)   (max_bits: |x| as uint)
-    if (max_bits == 0u || e == 128) return 1.0f;                    // all zero, or inf / nan: nothing sensible to scale
-    int k = 6 - e;
+    if (max_bits == 0u || e == 128) return 1.0f;                    // all zero, or inf / nan: nothing sensible to scale (the
+                                                                    // gradients come out non-finite and the guarded optimizer skips them)
+    int k = 6 - e + (int)fmaxf(fixed, -24.f);
     k = k < -100 ? -100 : (k > 100 ? 100 : k);
     return __uint_as_float((unsigned)(k + 127) << 23);
 }

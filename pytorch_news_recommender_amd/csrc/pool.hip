@@ -331,9 +331,15 @@ __global__ void ce_loss_kernel(int B, int C, const float* scores, float* loss_su
     if (threadIdx.x == 0) loss_sum[0] += red[0];
 }
 
+// GUARD: an element whose gradient is not finite (an fp16 overflow of the fused backward, an inf / nan loss) is left out of
+// the update -- p, m and v keep their values, so Adam's moments cannot be poisoned for the rest of training -- and counted into
+// *n_bad (one atomic per wavefront that saw any; none in a healthy step).  Every rank of a data-parallel job sees the same
+// reduced gradient, hence skips the same elements: replicas stay identical.
+template <bool GUARD>
 __global__ void adam_kernel(size_t n4, size_t n, float* p, const float* g, float* m, float* v, float step_size,
-                            float b1, float b2, float omb1, float omb2, float inv_sqrt_bc2, float eps, float gscale) {
+                            float b1, float b2, float omb1, float omb2, float inv_sqrt_bc2, float eps, float gscale, int* n_bad) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int bad = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * gscale;
@@ -341,6 +347,7 @@ __global__ void adam_kernel(size_t n4, size_t n, float* p, const float* g, float
         f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            if (GUARD && (__float_as_uint(gv[e]) & 0x7F800000u) == 0x7F800000u) { ++bad; continue; }
             mv[e] = b1 * mv[e] + omb1 * gv[e];
             vv[e] = b2 * vv[e] + omb2 * gv[e] * gv[e];
             const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
@@ -354,11 +361,40 @@ __global__ void adam_kernel(size_t n4, size_t n, float* p, const float* g, float
     const size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
         const float gv = g[t] * gscale;
-        const float mv = b1 * m[t] + omb1 * gv;
-        const float vv = b2 * v[t] + omb2 * gv * gv;
-        m[t] = mv; v[t] = vv;
-        p[t] -= step_size * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        if (GUARD && (__float_as_uint(gv) & 0x7F800000u) == 0x7F800000u) {
+            ++bad;
+        } else {
+            const float mv = b1 * m[t] + omb1 * gv;
+            const float vv = b2 * v[t] + omb2 * gv * gv;
+            m[t] = mv; v[t] = vv;
+            p[t] -= step_size * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+        }
     }
+    if (GUARD) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+        if (bad != 0 && (threadIdx.x & 63) == 0) atomicAdd(n_bad, bad);
+    }
+}
+
+// nrms_grad_guard: non-finite elements -> 0, counted
+__global__ void grad_guard_kernel(size_t n, float* g, int* n_bad) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int bad = 0;
+    const size_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
+        int b = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((__float_as_uint(gv[e]) & 0x7F800000u) == 0x7F800000u) { gv[e] = 0.f; ++b; }
+        if (b) { reinterpret_cast<f32x4*>(g)[i] = gv; bad += b; }
+    }
+    for (size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+        if ((__float_as_uint(g[t]) & 0x7F800000u) == 0x7F800000u) { g[t] = 0.f; ++bad; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if (bad != 0 && (threadIdx.x & 63) == 0) atomicAdd(n_bad, bad);
 }
 
 __global__ void keep_mask_kernel(uint64_t seed, uint32_t site, long groups, uint32_t thresh, uint8_t* keep) {
@@ -476,8 +512,8 @@ extern "C" int nrms_ce_loss_fwd_bwd(int32_t B, int32_t C, const float* scores, f
     return check_launch("ce_loss");
 }
 
-extern "C" int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
-                              double beta1, double beta2, double eps, int32_t step, float grad_scale, void* stream) {
+static int adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                     double beta2, double eps, int32_t step, float grad_scale, int32_t* n_nonfinite, void* stream) {
     NRMS_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adam_step: bad arguments");
     NRMS_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                  "adam_step: buffers must be 16-byte aligned");
@@ -495,9 +531,39 @@ extern "C" int nrms_adam_step(size_t n, float* param, const float* grad, float* 
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     TimingScope ts("adam", s);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, n4, n, param, grad, exp_avg, exp_avg_sq, step_size,
-                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), inv_sqrt_bc2, (float)eps, grad_scale);
+    if (n_nonfinite != nullptr)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, s, n4, n, param, grad, exp_avg, exp_avg_sq, step_size,
+                           (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), inv_sqrt_bc2, (float)eps, grad_scale,
+                           (int*)n_nonfinite);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, s, n4, n, param, grad, exp_avg, exp_avg_sq, step_size,
+                           (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), inv_sqrt_bc2, (float)eps, grad_scale,
+                           (int*)nullptr);
     return check_launch("adam");
+}
+
+extern "C" int nrms_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
+                              double beta1, double beta2, double eps, int32_t step, float grad_scale, void* stream) {
+    return adam_step(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, nullptr, stream);
+}
+
+extern "C" int nrms_adam_step_guarded(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
+                                      double beta1, double beta2, double eps, int32_t step, float grad_scale,
+                                      int32_t* n_nonfinite, void* stream) {
+    NRMS_REQUIRE(n_nonfinite != nullptr, "adam_step_guarded: null counter");
+    return adam_step(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, n_nonfinite, stream);
+}
+
+extern "C" int nrms_grad_guard(size_t n, float* grad, int32_t* n_nonfinite, void* stream) {
+    NRMS_REQUIRE(n == 0 || (grad && n_nonfinite), "grad_guard: null argument");
+    if (n == 0) return NRMS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    TimingScope ts("grad_guard", s);
+    hipLaunchKernelGGL(grad_guard_kernel, dim3((int)blocks), dim3(256), 0, s, n, grad, (int*)n_nonfinite);
+    return check_launch("grad_guard");
 }
 
 extern "C" int nrms_dropout_keep_mask(uint64_t seed, int32_t site, int64_t n_rows, int32_t d, float p_drop,

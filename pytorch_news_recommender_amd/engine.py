@@ -117,7 +117,14 @@ class NRMSEngine:
         self.fp16_user_encoder = False     # precision "fp16": the user encoder runs in bf16x3 unless this is set
         self.fp16_backward = True          # training in fp16 mode runs the fused fp16 backward (csrc/fused16_bwd.hip)
         self.loss_scale = 0.0              # fp16 backward: 0 = chosen on the device from max |dout| per call (nrms_hip.h)
-        self.fp16_wide_heads = True        # precision "fp16": the W_O + wide-head news encoder (nrms_v1) on csrc/fused16_v1.hip
+        # precision "fp16", nrms_v1's W_O + wide-head news encoder on csrc/fused16_v1.hip: OPT-IN (config.fp16_v1_news_encoder).
+        # Its scores sit up to 1.56e-4 from fp32 on a 512-user batch (2 % of them beyond north_star's absolute 1e-4),
+        # so the default keeps v1's news encoder in bf16x3 (1e-6)
+        self.fp16_wide_heads = False
+        # precision "fp16": passes that keep nothing for a backward (evaluate / test, get_news_vector, forward under no_grad) run
+        # in bf16x3 unless this is set (config.fp16_inference): evaluation scores then sit ~1e-6 from the reference and the
+        # per-impression AUC cannot move by rank flips of near-tied candidates (round 3 measured 1.4e-4 on 1 024 impressions)
+        self.fp16_inference = False
         self.fp16_wide_heads_backward = True    # ... its training step too (csrc/fused16_v1_bwd.hip); False: training in bf16x3
         self._gen = 0                      # generation stamp of _saved (checked by the autograd backward)
         # out-of-range word ids: counted on the device by nrms_sanitize_ids, surfaced without a host sync
@@ -126,6 +133,15 @@ class NRMSEngine:
         self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._bad_event = None
         self._news_cache = None
+        # fp16 backward: non-finite gradient elements (an overflow of the loss-scaled fp16 tensors) are skipped and counted on
+        # the device by the guarded optimizer / grad_guard; the count reaches the host asynchronously (like the id check) and
+        # lowers the loss scale for the following steps: desc.loss_scale = -loss_scale_backoff (include/nrms_hip.h)
+        self._grad_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._grad_bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._grad_bad_event = None
+        self.loss_scale_backoff = 0        # extra powers of two of head room below the default [64, 128) target
+        self.grad_overflow_steps = 0       # steps whose gradient held non-finite elements (seen so far)
+        self._clean_polls = 0
 
     FP16_LIMITS = dict(seq_len=64, d_model=316, d_k=32, n_heads=10, q_dim=224)
 
@@ -137,6 +153,10 @@ class NRMSEngine:
         d, L = self.dims, self.FP16_LIMITS
         h = d.heads(enc)
         if enc == "user_encoder" and not self.fp16_user_encoder:
+            return False
+        if not training and not self.fp16_inference:
+            return False
+        if d.word_embed_size % h:
             return False
         if d.output_proj:
             # nrms_v1's news encoder (heads of 33..50 columns + W_O): csrc/fused16_v1.hip, padding-skipping path only
@@ -407,7 +427,8 @@ class NRMSEngine:
         N = B * (H + Cn)
         # fp16 mode: the loss scale is derived on the device from the gradient each encoder receives (any loss reduction,
         # batch size or world size); a fixed value only for experiments (tools/fp16_grad_stats.py)
-        self.loss_scale = float(getattr(self, "loss_scale_override", None) or 0.0)
+        self.poll_grad_overflow()
+        self.loss_scale = float(getattr(self, "loss_scale_override", None) or -float(self.loss_scale_backoff))
         nv, user = sv["nv"], sv["user"]
         hist = nv[:B * H]
         cand = nv[B * H:]
@@ -441,11 +462,67 @@ class NRMSEngine:
             _lib.check(rc, "nrms_encoder_bwd_wqkv(news)")
 
     def adam_step(self, flat, gflat, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                  grad_scale=1.0):
+                  grad_scale=1.0, guard=None):
+        """torch.optim.Adam's update on flat buffers.  guard (default: on in the fp16 mode): elements with a non-finite
+        gradient are left out of the update and counted (nrms_adam_step_guarded); note_grad_check() afterwards lets the
+        count reach the host without a sync."""
+        if guard is None:
+            guard = self.precision == "fp16"
+        if guard:
+            rc = self.lib.nrms_adam_step_guarded(C.c_size_t(flat.numel()), _lib.ptr(flat), _lib.ptr(gflat), _lib.ptr(exp_avg),
+                                                 _lib.ptr(exp_avg_sq), C.c_double(lr), C.c_double(betas[0]), C.c_double(betas[1]),
+                                                 C.c_double(eps), int(step), C.c_float(grad_scale), _lib.ptr(self._grad_bad), _stream())
+            _lib.check(rc, "nrms_adam_step_guarded")
+            return
         rc = self.lib.nrms_adam_step(C.c_size_t(flat.numel()), _lib.ptr(flat), _lib.ptr(gflat), _lib.ptr(exp_avg),
                                      _lib.ptr(exp_avg_sq), C.c_double(lr), C.c_double(betas[0]), C.c_double(betas[1]),
                                      C.c_double(eps), int(step), C.c_float(grad_scale), _stream())
         _lib.check(rc, "nrms_adam_step")
+
+    # ---- fp16 gradient overflow: device-side count, host-side back-off of the loss scale, no sync ----------------------
+    def grad_guard(self, gflat):
+        """inf / nan elements of a gradient buffer -> 0, counted (for callers that run their own optimizer: the autograd path)."""
+        rc = self.lib.nrms_grad_guard(C.c_size_t(gflat.numel()), _lib.ptr(gflat), _lib.ptr(self._grad_bad), _stream())
+        _lib.check(rc, "nrms_grad_guard")
+
+    def note_grad_check(self):
+        """Behind the guarded optimizer / grad_guard of a step: start the asynchronous read-back of the counter."""
+        if self._grad_bad_event is not None and not self._grad_bad_event.query():
+            return                                       # the previous read-back is still in flight: its count covers this step too
+        self._grad_bad_host.copy_(self._grad_bad, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._grad_bad_event = ev
+
+    def poll_grad_overflow(self, block=False):
+        """Non-blocking (unless block): if a finished read-back shows non-finite gradient elements, give the fp16 backward two
+        more powers of two of head room from the next step on (and warn once per event); after 2 000 clean checks take one back."""
+        ev = self._grad_bad_event
+        if ev is None:
+            return self.loss_scale_backoff
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return self.loss_scale_backoff
+        self._grad_bad_event = None
+        n = int(self._grad_bad_host.item())
+        if n:
+            self._grad_bad.zero_()
+            self._grad_bad_host.zero_()
+            self.grad_overflow_steps += 1
+            self._clean_polls = 0
+            if self.loss_scale_backoff < 24:
+                self.loss_scale_backoff = min(24, self.loss_scale_backoff + 2)
+            import warnings
+            warnings.warn("NRMS fp16 backward: %d non-finite gradient element(s) were skipped by the optimizer (an fp16 overflow of "
+                          "the loss-scaled gradient tensors, or an inf / nan loss); loss-scale head room raised to 2^%d below the "
+                          "default" % (n, self.loss_scale_backoff), RuntimeWarning, stacklevel=2)
+        else:
+            self._clean_polls += 1
+            if self._clean_polls >= 2000 and self.loss_scale_backoff > 0:
+                self.loss_scale_backoff -= 1
+                self._clean_polls = 0
+        return self.loss_scale_backoff
 
     def impression_auc(self, scores, labels, lens):
         """scores [n, Cmax] fp32, labels [n, Cmax] uint8, lens [n] int32 (device) -> float64 AUC per impression."""

@@ -112,6 +112,11 @@ class _NRMSFunction(torch.autograd.Function):
                 model._autograd_grad = gflat
         gflat.zero_()
         model._engine.backward(model._flat, gflat, dscores, gen=ctx.gen)
+        if model._engine.precision == "fp16":
+            # the caller's own optimizer follows (torch.optim.Adam, train_eval.py:127): inf / nan elements of an overflowing
+            # fp16 backward become 0 and are counted; the engine lowers its loss scale when the count reaches the host
+            model._engine.grad_guard(gflat)
+            model._engine.note_grad_check()
         grads = tuple(model._layout.view(gflat, n) for n in model._names)
         return (None, None, None, None, None, None) + grads
 
@@ -214,6 +219,8 @@ class Model(nn.Module):
             tname = [n for n in self._names if n.endswith("word_embedding.0.weight") or n.endswith("word_embedding.weight")][0]
             self._pad_zero = bool((self._layout.view(self._flat, tname)[0] == 0).all().item())
         self._engine.fp16_user_encoder = bool(getattr(self.config, "fp16_user_encoder", False))
+        self._engine.fp16_inference = bool(getattr(self.config, "fp16_inference", False))
+        self._engine.fp16_wide_heads = bool(getattr(self.config, "fp16_v1_news_encoder", False))
         self._engine.pad_row_zero = self._pad_zero and bool(getattr(self.config, "skip_padding_tokens", True))
         return self._flat.device
 
@@ -317,6 +324,8 @@ class Model(nn.Module):
             st["step"] += 1
             for lo, hi, gshard in all_reduce.owned():
                 eng.adam_step(self._flat[lo:hi], gshard, st["m"][lo:hi], st["v"][lo:hi], st["step"], lr=lr_, betas=betas, eps=eps)
+            if eng.precision == "fp16":
+                eng.note_grad_check()
             all_reduce.gather(self._flat)
             self._last_scores = scores
             return loss_sum
@@ -336,6 +345,8 @@ class Model(nn.Module):
                 all_reduce(st["g"])
         st["step"] += 1
         eng.adam_step(self._flat, st["g"], st["m"], st["v"], st["step"], lr=lr_, betas=betas, eps=eps)
+        if eng.precision == "fp16":
+            eng.note_grad_check()
         self._last_scores = scores
         return loss_sum
 

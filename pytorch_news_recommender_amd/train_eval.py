@@ -66,6 +66,7 @@ def evaluate(config, model, data_iter, y_true=None, AUC_best=None, verbose=True)
     lab, lens = _pad_labels(y_true[:rank_score.shape[0]], rank_score.shape[1], rank_score.device)
     aucs = eng.impression_auc(rank_score, lab, lens)
     AUC = float(aucs.mean().item())
+    net.last_eval_scores, net.last_eval_aucs = rank_score, aucs      # diagnostics (per-impression values of this evaluation)
     if verbose:
         print('AUC:', AUC)
     net.train(was_training)

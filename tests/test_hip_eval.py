@@ -136,13 +136,14 @@ def test_train_evaluate_checkpoint_loop(tmp_path):
     m2.dedup_inference = False
     assert abs(train_eval.evaluate(cfg, m2, dl, dev_labels, verbose=False) - auc1) < 1e-6
     m2.dedup_inference = True
-    # the same trained weights scored in the other precision modes: the dev AUC moves by less than two rank flips (one flip
-    # among ~20 candidates of one of 256 impressions is ~2e-4 here; at bench size, 1 024 impressions: 4.4e-6, tools/train_parity.py)
+    # the same trained weights evaluated under the other precision settings: bf16x3 directly, and "fp16", whose evaluation
+    # passes run in bf16x3 by default (config.fp16_inference) -- the dev AUC must agree to north_star's 1e-4 (one rank flip
+    # among ~20 candidates of one of these 256 impressions would already be 2e-4)
     for prec in ("bf16x3", "fp16"):
         cfg.precision = prec
         auc_p = train_eval.evaluate(cfg, m2, dl, dev_labels, verbose=False)
         assert m2.engine.precision == prec
-        assert abs(auc_p - auc1) < 4e-4, (prec, auc_p, auc1)
+        assert abs(auc_p - auc1) <= 1e-4, (prec, auc_p, auc1)
     cfg.precision = "fp32"
     out = train_eval.test(cfg, m2, dl, [len(y) for y in dev_labels], out_file=str(tmp_path / "sub.txt"))
     first = open(out).readline().split(" ", 1)
@@ -249,3 +250,93 @@ def test_run_demo_entry_point_batch_32(tmp_path, monkeypatch):
     assert len(hist["losses"]) == 6 and np.isfinite(hist["losses"]).all()
     assert hist["aucs"] and 0.0 < hist["aucs"][-1][1] < 1.0
     assert os.path.exists(tmp_path / "data_processed" / "all_word_embedding_v3.npz")
+
+
+def _rank_flips(s_a, s_b, labels):
+    """(positive, negative) pairs of an impression whose order differs between two score sets (ties count as half a flip,
+    as they do in the rank statistic)."""
+    flips, where = 0.0, []
+    for i, y in enumerate(labels):
+        y = np.asarray(y, dtype=bool)
+        a, b = s_a[i, :len(y)], s_b[i, :len(y)]
+        ca = np.sign(a[y][:, None] - a[~y][None, :])
+        cb = np.sign(b[y][:, None] - b[~y][None, :])
+        f = float(np.abs(ca - cb).sum()) / 2.0
+        if f:
+            flips += f
+            where.append((i, f, int(y.sum()) * int((~y).sum())))
+    return flips, where
+
+
+def test_auc_parity_of_the_fp16_mode_at_the_train_parity_size():
+    """north_star: click scores AND AUC within 1e-4 of the reference (evaluate(), train_eval.py:229-273).  The size of
+    tools/train_parity.py: bench dimensions, 240 Adam steps of 256 users WITH dropout 0.2 in the exact fp32 mode (so the weights
+    are trained ones and the scores are no longer the small scores of an initialisation), then the SAME weights evaluated on
+    1 024 dev impressions in every mode.  precision = "fp16" evaluates in bf16x3 by default (config.fp16_inference = False): its
+    dev AUC must sit within 1e-4 of the fp32 mode's (measured: identical to ~1e-7), every score within 2e-5.  The opt-in
+    fp16_inference = True is what round 3 measured at 1.4e-4: its gap is a handful of rank flips between candidates whose fp32
+    scores are closer than the fp16 score error -- counted and printed here, and held to a looser, stated bar (4e-4)."""
+    from pytorch_news_recommender_amd import train_eval
+    from pytorch_news_recommender_amd.config import Config
+    from pytorch_news_recommender_amd.data_handler import DeviceFeed, SyntheticMind
+    from pytorch_news_recommender_amd.model.nrms_hip import Model
+    cfg = Config("nrms_hip")
+    cfg.__nrms__()
+    cfg.n_words_title, cfg.batch_size, cfg.dropout, cfg.precision, cfg.learning_rate = 30, 256, 0.2, "fp32", 1e-3
+    cfg.max_candidate_size = 40
+    corpus = SyntheticMind(cfg, n_news=4000, seed=0)
+    table = torch.from_numpy(np.asarray(corpus.embedding_table(cfg.word_embed_size), dtype=np.float32))
+    torch.manual_seed(0)
+    model = Model(cfg, pretrained_word_embedding=table).cuda().train()
+    feed = DeviceFeed(cfg, corpus.train_samples(256 * 40), type=0, id2title_dict=corpus.id2title_dict,
+                      id2abst_dict=corpus.id2abst_dict, batch_size=256, device="cuda", shuffle=True, drop_last=True, seed=3)
+    dev_samples, dev_labels = corpus.eval_samples(1024, max_shown=30)
+    dev = DeviceFeed(cfg, dev_samples, type=1, id2title_dict=corpus.id2title_dict, id2abst_dict=corpus.id2abst_dict,
+                     batch_size=256, device="cuda")
+    steps = 0
+    while steps < 240:
+        for b in feed:
+            model.train_step(b)
+            steps += 1
+            if steps >= 240:
+                break
+    res = {}
+    for tag, prec, inf16 in (("fp32", "fp32", False), ("bf16x3", "bf16x3", False), ("fp16 (default: bf16x3 inference)", "fp16", False),
+                             ("fp16 + fp16_inference", "fp16", True)):
+        cfg.precision, cfg.fp16_inference = prec, inf16
+        auc = train_eval.evaluate(cfg, model, dev, dev_labels, verbose=False)
+        res[tag] = (auc, model.last_eval_scores.cpu().numpy().copy())
+    cfg.precision, cfg.fp16_inference = "fp32", False
+    auc32, s32 = res["fp32"]
+    valid = np.zeros_like(s32, dtype=bool)
+    for i, y in enumerate(dev_labels):
+        valid[i, :len(y)] = True
+    print("dev AUC fp32 %.6f over %d impressions, scores rms %.3f max %.3f" % (auc32, len(dev_labels), float(np.sqrt((s32[valid] ** 2).mean())),
+                                                                             float(np.abs(s32[valid]).max())))
+    for tag, (auc, s) in res.items():
+        if tag == "fp32":
+            continue
+        flips, where = _rank_flips(s32, s, dev_labels)
+        err = float(np.abs(s - s32)[valid].max())
+        print("  %-34s AUC %.6f  gap %.2e  max |score - fp32| %.2e  rank flips %.1f in impressions %s" % (
+            tag, auc, abs(auc - auc32), err, flips, [(i, f, "of %d pairs" % n) for i, f, n in where][:8]))
+        if tag == "fp16 + fp16_inference":
+            assert abs(auc - auc32) < 4e-4, (tag, auc, auc32)          # opt-in: a few flips of near-tied candidates
+        else:
+            assert abs(auc - auc32) <= 1e-4 and err < 2e-5 * max(1.0, float(np.abs(s32[valid]).max())), (tag, auc, auc32, err)
+
+
+def test_fp16_mode_evaluates_in_bf16x3_unless_asked():
+    """config.precision = "fp16": passes that keep nothing for a backward are routed to the split-bf16 kernels (1e-6), training
+    passes to the fused fp16 kernels; config.fp16_inference = True puts inference on the fp16 kernels too."""
+    from pytorch_news_recommender_amd import _lib
+    shape = synth.Shape(n_words=500, word_embed_size=300, num_attention_heads=10, query_vector_dim=200, batch_size=4,
+                        history_len=50, n_candidates=5, n_words_title=30)
+    from tests.test_hip_parity import make_model
+    model = make_model(shape, synth.make_params(shape, seed=3), precision="fp16", fp16_inference=False)
+    eng = model.engine
+    assert eng._desc("news_encoder", 8, 30, training=True).precision == _lib.NRMS_PRECISION_FP16
+    assert eng._desc("news_encoder", 8, 30, training=False).precision == _lib.PRECISIONS["bf16x3"]
+    assert eng._desc("user_encoder", 4, 50, training=True).precision == _lib.PRECISIONS["bf16x3"]
+    model.config.fp16_inference = True
+    assert model.engine._desc("news_encoder", 8, 30, training=False).precision == _lib.NRMS_PRECISION_FP16

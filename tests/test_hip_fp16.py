@@ -20,10 +20,30 @@ SCORE_TOL = 1e-4          # north_star: click scores within 1e-4 of the referenc
 USER16 = [False, True]    # config.fp16_user_encoder
 
 
-def score_bar(o_scores, fp16_user=False):
-    """1e-4 absolute for scores of the reference's own scale (|score| <= 0.1 at initialisation, where north_star states its
-    bar); proportionally more where a synthetic shape produces larger scores (fp16 error is relative)."""
-    return (1.5e-4 if fp16_user else SCORE_TOL) * max(1.0, float(np.abs(o_scores).max()) / 0.1)
+def score_terms(aux, valid=None):
+    """What a score is made of: sum_f |cand_f user_f| per (user, candidate).  fp16 rounding is RELATIVE to these terms, not to
+    the score they sum to: MIND-shaped models (d = 300, H = 50, L = 30) at initialisation have terms of 0.6 ... 0.9 for scores
+    of rms 0.05; narrow synthetic shapes (d = 60, one-token titles) build a score of 0.2 from terms of 8."""
+    cand, user = np.asarray(aux["cand"]), np.asarray(aux["user"])
+    t = np.abs(cand * user[:, None, :]).sum(-1)
+    return float(t[valid].max() if valid is not None else t.max())
+
+
+def score_bar(o_scores, fp16_user=False, terms=None):
+    """north_star's bar is ABSOLUTE: every score within 1e-4 of the reference's.  It is asserted as such -- no scaling with the
+    score -- wherever the scores are in the range MIND-shaped models produce (|score| <= 0.4; v0 at initialisation <= 0.2,
+    nrms_v1 <= 0.36), i.e. in every test of the benchmarked geometry and of the reference fixtures.
+    FINDING of round 4 (the scaled bar of round 3 hid it): the fp16 mode's error is relative to the TERMS of a score,
+    sum_f |cand_f user_f| (score_terms) -- measured 8.5e-5 per unit of terms at d = 300 (7.6e-5 at the bench size, terms 0.9)
+    and up to 2.2e-4 per unit in narrow synthetic shapes (d = 60 ... 80, one-word titles, one-slot histories: no averaging over
+    tokens).  So the absolute 1e-4 is a property of MIND-shaped inputs, not of every shape the kernels accept: the shape fuzz
+    and the odd-shape tests, whose terms reach 3 ... 18, pass `terms` and are held to 3e-4 of them instead (kernel indexing is
+    what they test), never below 1e-4.  `fp16_user`: the documented non-default variant (user encoder in fp16 too), 1.5 x."""
+    k = 1.5 if fp16_user else 1.0
+    if terms is not None:
+        # (the fp16 user encoder adds its own four roundings: 6e-4 of the terms -- measured 4.8e-4 on the 8-wide `tiny` shape)
+        return max(k * SCORE_TOL, (6e-4 if fp16_user else 3e-4) * terms)
+    return k * SCORE_TOL * max(1.0, float(np.abs(o_scores).max()) / 0.4)
 VEC_TOL = 1.5e-3          # news / user vectors (norm ~ 1..10): 2^-11 relative per rounding
 
 
@@ -96,7 +116,8 @@ def test_fp16_forward_shapes_against_oracle(case, fp16_user):
     valid = batch["candidate_mask"] == 1
     err = float(np.abs(s - o_scores)[valid].max())
     print("fp16 %s (user fp16=%s): max |score - oracle| = %.3e (score scale %.3f)" % (case, fp16_user, err, float(np.abs(o_scores[valid]).max())))
-    assert err < score_bar(o_scores[valid], fp16_user)
+    terms = score_terms(aux, valid) if case not in ("bench_small",) else None     # MIND-shaped: the absolute bar
+    assert err < score_bar(o_scores[valid], fp16_user, terms), (err, terms)
     assert (s[~valid] == np.float32(-1e9)).all()
     # the encoders on their own
     B, H, L = batch["browsed_titles"].shape
@@ -240,11 +261,12 @@ def test_fp16_forward_backward_against_oracle(case, fp16_user):
         ke = model.engine.dropout_keep_mask(sv["seed"], 0, n_titles * L, p_drop).cpu().view(n_titles, L, d)
         kc = model.engine.dropout_keep_mask(sv["seed"], 1, n_titles * L, p_drop, fp16_ctx=True).cpu().numpy()
         keep = {"embed": ke, "ctx": torch.from_numpy(_padded_to_model_cols(kc, h, d // h)).view(n_titles, L, d)}
-    o_scores, o_loss, o_grads, _ = orc.loss_and_grads(params, batch, shape.num_attention_heads, p_drop=p_drop, keep=keep)
+    o_scores, o_loss, o_grads, aux = orc.loss_and_grads(params, batch, shape.num_attention_heads, p_drop=p_drop, keep=keep)
     valid = batch["candidate_mask"] == 1
     err = float(np.abs(scores - o_scores)[valid].max())
     print("fp16 train %s (user fp16=%s): max |score - oracle| = %.3e, |loss diff| %.2e" % (case, fp16_user, err, abs(loss - o_loss)))
-    assert err < score_bar(o_scores[valid], fp16_user)
+    terms = None if case in ("dropout_bench", "bench_small") else score_terms(aux, valid)      # MIND-shaped: the absolute bar
+    assert err < score_bar(o_scores[valid], fp16_user, terms), (err, terms)
     # all_padding: every title is the same vector, the true bias gradients are differences of equal terms (~1e-8)
     # while each term is ~0.1: what is left is the fp16 rounding of the terms, ~1e-4 absolute
     _grad_report(grads, o_grads, synth.param_names(), case, abs_floor=2e-4 if case == "all_padding" else GRAD_ABS)
@@ -303,3 +325,98 @@ def test_fp16_fused_train_steps_track_the_reference(golden_dir):
         assert diff.max() < 3.1e-3, n
         if not n.endswith(ILL_CONDITIONED):
             assert np.median(diff) < 2e-5 and float((diff > 2e-4).mean()) < 0.03, n
+
+
+def _finite(*ts):
+    return all(bool(torch.isfinite(t).all()) for t in ts)
+
+
+def test_fp16_gradient_overflow_is_counted_skipped_and_backed_off():
+    """the loss scale is picked from max |dout| alone; weights of unusual norm can push a derived fp16 tensor
+    (dS, dQKV, dX) past 65504, and an inf would travel into the table / weight gradients and into Adam's m and v for good.
+    Now: the guarded optimizer leaves non-finite elements out and counts them on the device, the count reaches the host
+    asynchronously, and the following steps run with more head room (desc.loss_scale = -n).
+    (a) forced: a fixed loss scale of 2^40 makes every fp16 gradient inf -- nothing becomes non-finite, the step is reported;
+    (b) natural: the news encoder's W_V scaled by 1e4 (V ~ 4 000) overflows the default head room; the back-off finds a scale
+        that fits within a few steps, parameters and moments stay finite throughout, and the gradients at that scale agree
+        with the exact fp32 mode's."""
+    import warnings
+    shape = synth.Shape(n_words=1000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=16, history_len=50, n_candidates=5, n_words_title=30)
+    params = synth.make_params(shape, seed=5)
+    tb = {k: torch.from_numpy(v).cuda() for k, v in synth.make_batch(shape, seed=6).items()}
+    model = make_model(shape, params, precision="fp16").train()
+    model.config.learning_rate = 1e-3
+    eng = model.engine
+    model.train_step(tb)
+    assert eng.poll_grad_overflow(block=True) == 0 and eng.grad_overflow_steps == 0
+    st = model._opt
+    wq = "news_encoder.multihead_self_attention.W_Q.weight"
+    before = model._layout.view(model._flat, wq).clone()
+    user_before = model._layout.view(model._flat, "user_encoder.multihead_self_attention.W_Q.weight").clone()
+    eng.loss_scale_override = 2.0 ** 40
+    model.train_step(tb)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert eng.poll_grad_overflow(block=True) == 2
+    assert eng.grad_overflow_steps == 1 and any("non-finite" in str(w.message) for w in rec)
+    assert _finite(model._flat, st["m"], st["v"])
+    assert torch.equal(model._layout.view(model._flat, wq), before)          # its gradient was inf everywhere: left alone
+    assert not torch.equal(model._layout.view(model._flat, "user_encoder.multihead_self_attention.W_Q.weight"), user_before)
+    eng.loss_scale_override = None
+    eng.loss_scale_backoff = 0
+    # the autograd path (caller's own optimizer): non-finite elements become zeros, counted
+    eng.loss_scale_override = 2.0 ** 40
+    model.zero_grad()
+    s = model({k: v for k, v in tb.items()})
+    torch.nn.functional.cross_entropy(s, torch.zeros(len(s), dtype=torch.long, device=s.device)).backward()
+    assert all(_finite(p.grad) for p in model.parameters())
+    assert not model.news_encoder.multihead_self_attention.W_Q.weight.grad.any()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert eng.poll_grad_overflow(block=True) == 2 and eng.grad_overflow_steps == 2
+    eng.loss_scale_override = None
+    eng.loss_scale_backoff = 0
+
+    # (b) natural overflow
+    wv = "news_encoder.multihead_self_attention.W_V.weight"
+    p2 = dict(params)
+    p2[wv] = params[wv] * 1e4
+    m2 = make_model(shape, p2, precision="fp16").train()
+    m2.config.learning_rate = 1e-6
+    e2 = m2.engine
+    seen, clean_at = 0, None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(14):
+            m2.train_step(tb)
+            e2.poll_grad_overflow(block=True)
+            assert _finite(m2._flat, m2._opt["m"], m2._opt["v"]), i
+            if e2.grad_overflow_steps == seen and seen > 0:
+                clean_at = i
+                break
+            seen = e2.grad_overflow_steps
+    print("natural overflow: %d overflowing steps, clean at step %s with back-off 2^-%d" % (seen, clean_at, e2.loss_scale_backoff))
+    assert seen >= 1 and clean_at is not None
+    # (c) what a back-off costs: ORDINARY weights with six more powers of two of head room (max |dout| into [1, 2)) against the
+    # exact fp32 mode -- the fp16 tensors have 2^20 below the default target before they flush, so the gradients still meet the
+    # mode's bar.  (At the weights of (b) itself such a comparison says nothing: news vectors of norm 4 000 give the user
+    # encoder logits of 1e7, its attention is one-hot and flips with the last bit of ANY arithmetic.)
+    m3 = make_model(shape, params, precision="fp16").train()
+    g = {}
+    for prec, backoff in (("fp16", 6), ("fp32", 0)):
+        m3.config.precision = prec
+        eng3 = m3.engine
+        eng3.loss_scale_backoff = backoff
+        sc = eng3.forward(m3._flat, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=True)
+        _, dce = eng3.ce_loss(sc, grad_scale=1.0 / shape.batch_size)
+        g[prec] = torch.zeros_like(m3._flat)
+        eng3.backward(m3._flat, g[prec], dce)
+    assert _finite(g["fp16"])
+    for name in (wv, "news_encoder.word_embedding.0.weight", "news_encoder.multihead_self_attention.W_Q.weight",
+                 "news_encoder.additive_attention.linear.weight"):
+        a, b = m3._layout.view(g["fp16"], name).double(), m3._layout.view(g["fp32"], name).double()
+        rel = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+        print("   fp16 with 2^-6 head room vs fp32 grad %-60s scale %.2e  max err %.1e of scale" % (name, float(b.abs().max()), rel))
+        # (the additive weight's gradient is 1e-6 at initialisation -- 3e-3 ... 4e-3 of its scale at the default head room, DESIGN 2)
+        assert rel < (1.5e-2 if "additive_attention" in name else 6e-3), (name, rel)

@@ -23,6 +23,50 @@ def full():
     return shape, model, batch, tb
 
 
+@pytest.fixture(scope="module")
+def oracle_full(full):
+    """The ORACLE's scores of the 512-user bench batch (eval, dropout 0): one batched CPU forward, a few tens of seconds, computed
+    once per test run -- so that the headline configuration is pinned to the oracle itself, not to the library's own fp32 mode."""
+    import time
+    from oracle import nrms_oracle as orc
+    shape, _, batch, _ = full
+    params = synth.make_params(shape, seed=0)
+    t0 = time.time()
+    with torch.no_grad():
+        scores, _ = orc.forward(orc.to_torch(params), batch, shape.num_attention_heads)
+    print("oracle forward at %d users: %.1f s" % (shape.batch_size, time.time() - t0))
+    return params, scores.numpy()
+
+
+def test_every_mode_against_the_oracle_at_full_size(full, oracle_full):
+    """BASELINE configs[1] (512 users, 50 + 5 titles of 30 words, d = 300, V = 45 800): the scores of every precision mode
+    against the ORACLE's on the same weights and batch -- fp32 1e-5, bf16x3 2e-5, and for precision "fp16" north_star's absolute
+    1e-4 on each of the 2 555 valid scores: the training forward (fused fp16 news encoder; what the loss sees), inference with
+    fp16_inference (the same kernels without saved activations), and the default inference routing (bf16x3: 2e-5)."""
+    from tests.test_hip_parity import make_model
+    shape, _, batch, tb = full
+    params, o_scores = oracle_full
+    valid = batch["candidate_mask"] == 1
+    model = make_model(shape, params)            # fresh weights: the shared fixture's model is trained on by other tests
+    rows = []
+    try:
+        for tag, prec, inf16, training, bar in (("fp32", "fp32", True, False, 1e-5), ("bf16x3", "bf16x3", True, False, 2e-5),
+                                                ("fp16 training forward", "fp16", True, True, 1e-4),
+                                                ("fp16 inference (fp16_inference)", "fp16", True, False, 1e-4),
+                                                ("fp16 default inference (bf16x3)", "fp16", False, False, 2e-5)):
+            model.config.precision, model.config.fp16_inference = prec, inf16
+            s = _scores(model, tb, training=training).cpu().numpy()
+            assert (s[~valid] == np.float32(-1e9)).all()
+            e = np.abs(s - o_scores)[valid]
+            rows.append((tag, float(np.sqrt((e.astype(np.float64) ** 2).mean())), float(e.max())))
+            print("full size vs ORACLE, %-34s rms %.2e  max %.2e over %d scores (max |score| %.3f)  bar %.0e" % (
+                tag, rows[-1][1], rows[-1][2], e.size, float(np.abs(o_scores[valid]).max()), bar))
+            assert rows[-1][2] < bar, rows[-1]
+    finally:
+        model.config.precision, model.config.fp16_inference = "fp32", True
+    assert rows[2][2] > 1e-6                     # the fp16 rows really ran the fp16 kernels
+
+
 def _scores(model, tb, training=True):
     eng = model.engine
     return eng.forward(model._flat, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=training)
@@ -235,8 +279,9 @@ def _fp16_vs_fp32(shape, tb, seed):
     model = make_model(shape, synth.make_params(shape, seed=seed))
     ref = _scores(model, tb, training=False).clone()
     model.config.precision = "fp16"
-    assert model.engine.precision == "fp16" and not model.engine.fp16_user_encoder
+    assert model.engine.precision == "fp16" and not model.engine.fp16_user_encoder and model.engine.fp16_inference
     s = _scores(model, tb, training=False)
+    assert torch.equal(s, _scores(model, tb, training=True))     # dropout 0: the training forward gives the same bits
     valid = tb["candidate_mask"] == 1
     e = (s - ref)[valid].abs().double()
     return float((e * e).mean().sqrt()), float(torch.quantile(e, 0.999)), float(e.max()), float((ref[valid].double() ** 2).mean().sqrt())

@@ -73,10 +73,12 @@ def _run(case, precision):
         return
     err = float(np.abs(scores - o_scores)[valid].max())
     if precision == "fp16":
-        # fp16 error is relative to what a score is made of: sum_f |cand_f user_f| (for MIND-shaped models about the score
-        # itself; for a one-token title or a 24-wide model the terms cancel and a score of 0.2 is built from terms of 1)
+        # fp16 error is relative to what a score is made of, sum_f |cand_f user_f| (tests/test_hip_fp16.py::score_bar): the fuzz's
+        # narrow shapes build a score of 0.2 from terms of 8 -- 3e-4 of the terms (round 3 allowed 1e-3), never below 1e-4
         terms = float(np.abs(aux["cand"] * aux["user"][:, None, :]).sum(-1)[valid].max())
-        assert err < max(score_bar(o_scores[valid], case["fp16_user"]), 1e-3 * terms), (case, err, terms)
+        print("FUZZ16 err %.3e bar %.3e terms %.3f max|score| %.3f d %d h %d user16 %s" % (
+            err, score_bar(o_scores[valid], case["fp16_user"]), terms, float(np.abs(o_scores[valid]).max()), case["d"], case["h"], case["fp16_user"]))
+        assert err < score_bar(o_scores[valid], case["fp16_user"], terms), (case, err, terms)
         # gradients: 8e-3 of each tensor's scale -- twice the bar of the MIND-shaped tests: at these widths (d, q from 60,
         # batches of 1 to 7 users) a gradient element sums a few hundred products instead of a few hundred thousand and the
         # fp16 roundings average out less -- plus a floor of 1e-4 of the largest tensor's scale for the cancelling sums
@@ -130,7 +132,7 @@ def test_fuzz_v1_fp16(case):
     from oracle import nrms_oracle as orc
     from pytorch_news_recommender_amd import _lib
     from tests.test_hip_v1 import fwd_bwd, make_v1
-    from tests.test_hip_fp16 import score_bar
+    from tests.test_hip_v1_fp16 import v1_bar as score_bar          # the opt-in v1 fp16 news encoder: its own stated bar (2e-4)
     shape = synth.Shape(n_words=211, word_embed_size=case["d"], num_attention_heads=case["hu"], query_vector_dim=case["q"],
                         batch_size=case["B"], history_len=case["H"], n_candidates=case["C"], n_words_title=case["L"])
     params = synth.make_params_v1(shape, seed=case["seed"])
@@ -162,7 +164,9 @@ def test_fuzz_v1_fp16(case):
         return
     err = float(np.abs(scores - o_scores)[valid].max())
     terms = float(np.abs(aux["cand"] * aux["user"][:, None, :]).sum(-1)[valid].max())
-    assert err < max(score_bar(o_scores[valid]), 1e-3 * terms), (case, err, terms)
+    print("FUZZV1 err %.3e bar %.3e terms %.3f max|score| %.3f d %d ht %d" % (
+        err, score_bar(o_scores[valid]), terms, float(np.abs(o_scores[valid]).max()), case["d"], case["ht"]))
+    assert err < max(score_bar(o_scores[valid]), 3e-4 * terms), (case, err, terms)
     back = {v: k for k, v in zip(params.keys(), v0.keys())}
     floor = 1e-4 * max(float(np.abs(v).max()) for v in o_grads.values()) + 2e-6
     for n, ref in o_grads.items():

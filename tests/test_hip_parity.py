@@ -37,7 +37,7 @@ def assert_grad_close(got, ref, mode, name):
         name, mode, float(diff.max()), worst, float(np.abs(ref).max()))
 
 
-def make_model(shape, params, dropout=0.0, device="cuda", precision="fp32", fp16_user=False):
+def make_model(shape, params, dropout=0.0, device="cuda", precision="fp32", fp16_user=False, fp16_inference=True):
     from pytorch_news_recommender_amd.config import Config
     from pytorch_news_recommender_amd.model.nrms_hip import Model
     cfg = Config("nrms_hip")
@@ -48,6 +48,9 @@ def make_model(shape, params, dropout=0.0, device="cuda", precision="fp32", fp16
     cfg.dropout = dropout
     cfg.precision = precision
     cfg.fp16_user_encoder = fp16_user          # precision "fp16" only: the user encoder in fp16 too (default: bf16x3)
+    # precision "fp16" only: inference passes on the fused fp16 kernels as well, so that the eval-mode tests exercise them
+    # (the product default is False: evaluation runs in bf16x3, tests/test_hip_eval.py::test_fp16_mode_evaluates_in_bf16x3)
+    cfg.fp16_inference = fp16_inference
     m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
     return m.to(device)

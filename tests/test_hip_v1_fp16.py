@@ -5,7 +5,6 @@ import pytest
 import torch
 
 from pytorch_news_recommender_amd import _lib, synth
-from tests.test_hip_fp16 import score_bar
 from tests.test_hip_v1 import make_v1
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +23,14 @@ V1_SHAPES = {
     "dk50_h4": (synth.Shape(n_words=700, word_embed_size=200, num_attention_heads=4, query_vector_dim=100,
                             batch_size=4, history_len=9, n_candidates=4, n_words_title=13), 4, 1),
 }
+
+
+# The opt-in fused fp16 news encoder of nrms_v1 at 512 users (measured max 1.56e-4): NOT inside north_star's 1e-4, stated as such
+V1_FP16_OPT_IN_BAR = 2e-4
+
+
+def v1_bar(o_scores):
+    return V1_FP16_OPT_IN_BAR * max(1.0, float(np.abs(o_scores).max()) / 0.4)
 
 
 def _news_precision(model, n, L, training):
@@ -51,7 +58,7 @@ def test_v1_fp16_forward_against_oracle(case):
     print("v1 fp16 %s: max |news vector - oracle| = %.3e (max |v| %.2f), max |score - oracle| = %.3e" %
           (case, verr, float(np.abs(o_nv).max()), err))
     assert verr < 1.5e-3 * max(1.0, float(np.abs(o_nv).max()))
-    assert err < score_bar(o_scores.numpy())
+    assert err < v1_bar(o_scores.numpy())
 
 
 def test_v1_fp16_forward_replays_its_dropout_mask():
@@ -79,7 +86,7 @@ def test_v1_fp16_forward_replays_its_dropout_mask():
                                   news_heads=title_heads, embed_dropout=False)
     err = float(np.abs(s - o_scores.numpy()).max())
     print("v1 fp16 dropout replay: max |score - oracle| = %.3e" % err)
-    assert err < score_bar(o_scores.numpy())
+    assert err < v1_bar(o_scores.numpy())
 
 
 # ---- training: csrc/fused16_v1_bwd.hip --------------------------------------------------------------------------------
@@ -123,7 +130,7 @@ def test_v1_fp16_forward_backward_against_oracle(case, p_drop):
     valid = batch["candidate_mask"] == 1
     err = float(np.abs(scores - o_scores)[valid].max())
     print("v1 fp16 train %s p=%.1f: max |score - oracle| = %.3e, |loss diff| %.2e" % (case, p_drop, err, abs(loss - o_loss)))
-    assert err < score_bar(o_scores[valid])
+    assert err < v1_bar(o_scores[valid])
     back = {v: k for k, v in zip(params.keys(), v0.keys())}
     _v1_grad_report(grads, o_grads, back, case)
     assert not grads[back["news_encoder.word_embedding.0.weight"]][0].any()
@@ -212,10 +219,11 @@ def test_v1_fp16_at_the_benchmarked_size():
     print("v1 full size fp16 vs fp32 over %d scores of rms %.3f (max %.3f): rms %.2e, max %.2e, %.2f %% of the scores above 1e-4" % (
         e.numel(), srms, smax, rms, emax, 100.0 * float((e > 1e-4).double().mean())))
     # The v1 value path has seven fp16 roundings where v0's has four (x, W_V, V, P + the head concatenation, W_O, the projection's
-    # output): sqrt(7 / 4) = 1.3 x v0's RELATIVE error (4.6e-4 of the score rms against 3.3e-4), on scores that are 1.5 x larger at
-    # this initialisation (rms 0.09, max 0.3) -- so the ABSOLUTE 1e-4 of north_star, stated on scores below 0.1, is exceeded by about
-    # 1 % of a 512-user batch's scores; what is asserted is the fp16 tests' bar (1e-4 per 0.1 of score scale) and the relative rms
-    assert emax < score_bar(ref[valid].cpu().numpy()) and 1e-7 < rms < 6e-4 * srms
+    # output) on scores 1.5 x larger at this initialisation (rms 0.09, max 0.36): about 2 % of a 512-user batch's scores end up
+    # further than north_star's ABSOLUTE 1e-4 from fp32 (max 1.56e-4) -- which is why this kernel family is OPT-IN for nrms_v1
+    # (config.fp16_v1_news_encoder; the default keeps v1's news encoder in bf16x3, test below) and held here to its own stated
+    # bound: 2e-4 absolute, relative rms below 6e-4
+    assert emax < V1_FP16_OPT_IN_BAR and 1e-7 < rms < 6e-4 * srms
     g16 = torch.zeros_like(flat)
     scores()
     eng.backward(flat, g16, dce)
@@ -322,3 +330,41 @@ def test_fp16_backward_without_the_kept_forward_scratch_rebuilds_the_same_lists(
         grads.append(g)
     assert float(grads[0].abs().max()) > 0
     assert torch.equal(grads[0], grads[1])
+
+
+def test_v1_default_routing_against_the_oracle_at_the_benchmarked_size():
+    """nrms_v1 with config.precision = "fp16" and nothing else set -- what bench.py's nrms_v1 leg leads with: the news encoder
+    (six heads of 50, W_O) stays on the split-bf16 kernels because its fused fp16 form misses the absolute 1e-4 (above), so the
+    whole model is bf16x3.  Scores of the 512-user bench batch against the ORACLE's (one batched CPU forward): 2e-5 in the
+    training forward and in inference; the opt-in fp16 news encoder is measured beside it against the same oracle scores."""
+    import time
+    from oracle import nrms_oracle as orc
+    shape = synth.Shape(n_words=synth.BENCH.n_words, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=512, history_len=50, n_candidates=5, n_words_title=20)
+    params = synth.make_params_v1(shape, seed=0)
+    batch = synth.make_batch(shape, seed=1, mask_some_candidates=True)
+    tb = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    t0 = time.time()
+    with torch.no_grad():
+        o_scores, _ = orc.forward(orc.to_torch(orc.v1_to_v0_names(params)), batch, shape.num_attention_heads, news_heads=6,
+                                  embed_dropout=False)
+    o_scores = o_scores.numpy()
+    print("oracle v1 forward at 512 users: %.1f s" % (time.time() - t0))
+    valid = batch["candidate_mask"] == 1
+    model = make_v1(shape, params, 6, precision="fp16", fp16_news=False, fp16_inference=False)
+    BF = _lib.PRECISIONS["bf16x3"]
+    assert _news_precision(model, 8, 20, True) == BF and _news_precision(model, 8, 20, False) == BF
+    flat = model._flat
+    for training in (True, False):
+        s = model.engine.forward(flat, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=training).cpu().numpy()
+        err = float(np.abs(s - o_scores)[valid].max())
+        print("v1 default routing (bf16x3) vs ORACLE, training=%s: max |score diff| %.2e over %d scores (max |score| %.3f)" % (
+            training, err, int(valid.sum()), float(np.abs(o_scores[valid]).max())))
+        assert err < 2e-5
+    model.config.fp16_v1_news_encoder = True
+    assert _news_precision(model, 8, 20, True) == _lib.NRMS_PRECISION_FP16
+    s = model.engine.forward(flat, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=True).cpu().numpy()
+    e = np.abs(s - o_scores)[valid]
+    print("v1 OPT-IN fp16 news encoder vs ORACLE: rms %.2e max %.2e, %.2f %% of the scores beyond 1e-4" % (
+        float(np.sqrt((e.astype(np.float64) ** 2).mean())), float(e.max()), 100.0 * float((e > 1e-4).mean())))
+    assert float(e.max()) < V1_FP16_OPT_IN_BAR
