@@ -52,7 +52,7 @@ def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news, fp16_user=
     Q|K|V projection / d(w_qkv) / dX on the non-padding token rows, attention on the titles with a real token, the
     additive projection on every token.  bytes = every tensor the kernel must read or write once."""
     H, C, L = shape.history_len, shape.n_candidates, shape.n_words_title
-    d, q = shape.word_embed_size, shape.query_vector_dim
+    d, q, h = shape.word_embed_size, shape.query_vector_dim, shape.num_attention_heads
     Mn, Mu = B * (H + C) * L, B * H                       # token rows: news encoder, user encoder
     Nn = B * (H + C)
     ap = allpad_frac if compact else 0.0
@@ -82,9 +82,14 @@ def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news, fp16_user=
             w["fused64_bwd16_pool"] = ("mfma", add_u, 2.0 * Mu * (2 * 320 + 2 * 224))
             w["fused64_bwd16_attn"] = ("mfma", 2.0 * att_u, 2.0 * Mu * (320 + 320 + 960))
         else:
-            # user encoder in bf16x3 (the default of the fp16 mode): the unfused fp32-storage kernels on its 3 % of the flops
-            # (its TN / dX GEMMs share the dwqkv_bwd / dx_bwd / dwadd_bwd timers with the news encoder's fp16 GEMMs)
+            # user encoder in bf16x3 (the default of the fp16 mode): ONE fused split-bf16 kernel per direction (csrc/user64.hip;
+            # algorithmic bytes: x in, ctx / T out, the Q|K|V + context fragments out; backward: those in, ds + dQKV out) and, as
+            # before, its TN / dX GEMMs on the dwqkv_bwd / dx_bwd / dwadd_bwd timers next to the news encoder's fp16 GEMMs.
+            # The unfused chain's timers stay listed for engine.fused_user_encoder = False
             Mdu, Mqu = 4.0 * Mu * d, 4.0 * Mu * q
+            frag = B * (h * 2 * 12 * 1024 + 2 * 20 * 2048)
+            w["user64_fwd"] = ("mfma", qkv_u + att_u + add_u, 2 * Mdu + Mqu + frag)
+            w["user64_bwd"] = ("mfma", add_u + 2.0 * att_u, Mqu + frag + 3 * Mdu)
             w["qkv_proj_fwd"] = ("mfma", qkv_u, 4.0 * Mdu)
             w["addattn_fwd"] = ("mfma", add_u, Mdu + Mqu)
             w["dctx_bwd"] = ("mfma", add_u, Mqu + Mdu)
@@ -111,7 +116,7 @@ def kernel_work(shape, B, live_frac, compact, allpad_frac, fp16_news, fp16_user=
     return w
 
 
-OTHER_TIMERS = ("tn_reduce", "red16", "prep16", "title_order", "cast16", "split_planes", "click", "ce_loss", "transpose", "colsum",
+OTHER_TIMERS = ("user64_prep", "grad_guard", "tn_reduce", "red16", "prep16", "title_order", "cast16", "split_planes", "click", "ce_loss", "transpose", "colsum",
                 "permute_rows", "compact_rows", "sanitize_ids", "fill_pad_rows", "padsum")
 
 
@@ -566,7 +571,7 @@ def main():
         # which arithmetic each timer's kernels run in (fp16 mode: the user encoder's kernels are bf16x3)
         kprec = {k: args.precision for k in work}
         if fp16_news and not args.fp16_user_encoder:
-            for k in ("qkv_proj_fwd", "addattn_fwd", "dctx_bwd", "attn_fwd", "attn_bwd", "addattn_bwd_rows"):
+            for k in ("user64_fwd", "user64_bwd", "qkv_proj_fwd", "addattn_fwd", "dctx_bwd", "attn_fwd", "attn_bwd", "addattn_bwd_rows"):
                 kprec[k] = "bf16x3"
         kernels = {}
         for name, (bound, fl, by) in work.items():

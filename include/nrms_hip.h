@@ -86,6 +86,14 @@ extern "C" {
  * and title lists the forward built there (live rows, row positions, the three title classes) instead of rebuilding them
  * from the ids (five small launches).  Without the flag nothing in acts.scratch is read by the backward. */
 #define NRMS_FLAG_FWD_SCRATCH_KEPT 4
+/* User encoder (vocab == 0), NRMS_PRECISION_BF16X3, 33 <= seq_len <= 64, d_model <= 300, even d_k <= 32, n_heads <= 10,
+ * q_dim <= 224, no output projection, no mask, no dropout: the whole pass runs as ONE kernel per direction (csrc/user64.hip: a
+ * wave per 32-row half of a history, Q / K / V / probabilities / tanh in registers, every product in split-bf16) instead of the
+ * projection GEMM -> attention -> additive-attention chain; the weight-gradient and dX GEMMs of the backward are unchanged.
+ * Under the flag acts.qkv is NOT [M, 3d] floats but nrms_encoder_fused_qkv_bytes(desc) bytes of operand fragments (internal
+ * layout, written by the forward, read by the backward); acts.ctx, acts.t, acts.w keep their meaning (and may all be NULL in
+ * inference).  Set on both nrms_encoder_fwd and nrms_encoder_bwd of a pass, or on neither; NRMS_EINVAL for any other shape. */
+#define NRMS_FLAG_FUSED_SEQ64 8
 
 /* One self-attention + additive-pooling encoder pass over n_seq sequences of seq_len rows.
  * vocab > 0  : news encoder -- input is `ids` [n_seq, seq_len] int64, rows gathered from
@@ -179,6 +187,8 @@ typedef struct nrms_encoder_acts {
  * model/nrms_v1.py:15-105,128-162,208-211.
  * out: [n_seq, d].  Exactly one of ids / x is used (by desc->vocab). */
 size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc);
+/* Size of acts.qkv under NRMS_FLAG_FUSED_SEQ64 (0 if the descriptor is not eligible for it). */
+size_t nrms_encoder_fused_qkv_bytes(const nrms_encoder_desc* desc);
 int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w,
                      const int64_t* ids, const float* x, const uint8_t* mask /* [n_seq, seq_len] or NULL */,
                      const nrms_encoder_acts* acts, float* out, void* stream);

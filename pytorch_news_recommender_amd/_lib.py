@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("NRMS_HIP_LIB") or os.path.join(PKG, "libnrms_hip.so")
 NRMS_FLAG_PAD_ROW_ZERO = 1
 NRMS_FLAG_DEFER_WQKV = 2
 NRMS_FLAG_FWD_SCRATCH_KEPT = 4
+NRMS_FLAG_FUSED_SEQ64 = 8
 NRMS_PRECISION_FP32 = 0
 NRMS_PRECISION_BF16X3 = 1
 NRMS_PRECISION_BF16 = 2
@@ -62,6 +63,7 @@ SIGNATURES = {
                                    C.c_void_p, C.POINTER(EncoderActs), C.c_void_p, C.c_void_p]),
     "nrms_encoder_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "nrms_encoder_fwd_scratch_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
+    "nrms_encoder_fused_qkv_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "nrms_encoder_bwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(EncoderActs), C.c_void_p, C.POINTER(EncoderGrads), C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libnrms_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "embed.hip", "attention.hip", "pool.hip", "wide.hip", "fused16.hip", "fused16_v1.hip", "fused16_bwd.hip", "fused16_v1_bwd.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "embed.hip", "attention.hip", "pool.hip", "wide.hip", "fused16.hip", "fused16_v1.hip", "fused16_bwd.hip", "fused16_v1_bwd.hip", "user64.hip", "capi.hip"]
 HEADERS = ["common.h", "gemm.h", "fused16.h", "fused16_bwd.h", "fused16_v1.h", os.path.join("..", "..", "include", "nrms_hip.h")]
 ARCH = "gfx950"
 
@@ -40,6 +40,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     headers = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("NRMS_HIPCC_EXTRA", "").split()      # diagnostic builds only (e.g. -DNRMS_U64_EXPERIMENTS)
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

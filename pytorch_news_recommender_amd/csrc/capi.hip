@@ -145,7 +145,15 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
                      "%s: precision fp16 supports neither masks nor p_drop_attn (use bf16x3)", who);
     }
     NRMS_REQUIRE((d->mask_mode & ~3) == 0, "%s: mask_mode=%d", who, d->mask_mode);
-    NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV | NRMS_FLAG_FWD_SCRATCH_KEPT)) == 0, "%s: unknown flags 0x%x", who, d->flags);
+    NRMS_REQUIRE((d->flags & ~(NRMS_FLAG_PAD_ROW_ZERO | NRMS_FLAG_DEFER_WQKV | NRMS_FLAG_FWD_SCRATCH_KEPT | NRMS_FLAG_FUSED_SEQ64)) == 0,
+                 "%s: unknown flags 0x%x", who, d->flags);
+    if (d->flags & NRMS_FLAG_FUSED_SEQ64) {
+        const char* why = nullptr;
+        NRMS_REQUIRE(d->vocab == 0 && d->precision == NRMS_PRECISION_BF16X3 && !d->use_output_proj && d->mask_mode == 0 &&
+                     d->p_drop_ctx == 0.f && d->p_drop_attn == 0.f,
+                     "%s: NRMS_FLAG_FUSED_SEQ64 covers the user encoder (vocab == 0) in bf16x3 without output projection, mask or dropout", who);
+        NRMS_REQUIRE(user64_supported(d->seq_len, d->d_model, d->n_heads, d->q_dim, &why), "%s: NRMS_FLAG_FUSED_SEQ64 needs %s", who, why);
+    }
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
     return NRMS_OK;
 }
@@ -174,7 +182,7 @@ static size_t wplane_bytes(const nrms_encoder_desc* d) {
 }
 
 struct BwdWorkspace {
-    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, live, pos, n_live, cscr, padsum, sscr, total;   // byte offsets
+    size_t dctx, dqkv, dattn, ds, wqkv_t, wadd_t, wo_t, tn_partial, dq_partial, wplanes, live, pos, n_live, cscr, padsum, sscr, u64planes, total;   // byte offsets
 };
 
 static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
@@ -193,7 +201,9 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     const size_t p2 = gemm_tn_workspace_floats((int)M, (int)q, (int)dm, nullptr);
     const size_t p3 = d->use_output_proj ? gemm_tn_workspace_floats((int)M, (int)dm, (int)dm, nullptr) : 0;
     w.tn_partial = take(p1 > p2 ? (p1 > p3 ? p1 : p3) : (p2 > p3 ? p2 : p3));
-    w.dq_partial = take((size_t)(wide_additive(d) ? d->n_seq : addattn_bwd_rows_waves(d->n_seq)) * q);
+    const bool fused64 = (d->flags & NRMS_FLAG_FUSED_SEQ64) != 0;
+    w.dq_partial = take(std::max((size_t)(wide_additive(d) ? d->n_seq : addattn_bwd_rows_waves(d->n_seq)) * q,
+                                 fused64 ? user64_dq_partial_floats(d->n_seq) : (size_t)0));
     w.wplanes = take(wplane_bytes(d) / sizeof(float));
     const bool pz = d->vocab > 0 && (d->flags & NRMS_FLAG_PAD_ROW_ZERO) != 0;
     w.live = take(d->vocab > 0 ? M : 0);          // int32 positions of the non-padding tokens (news encoder)
@@ -202,6 +212,7 @@ static BwdWorkspace bwd_layout(const nrms_encoder_desc* d) {
     w.cscr = take(d->vocab > 0 ? compact_scratch_ints((long)M) : 0);
     w.padsum = take(pz ? attention_padsum_floats() : 0);
     w.sscr = take(d->vocab > 0 ? scatter_grouped_scratch_ints((long)M, d->vocab) : 0);
+    w.u64planes = take(fused64 ? user64_bwd_planes_bytes(d->n_heads) / sizeof(float) + 1 : 0);
     w.total = off;
     return w;
 }
@@ -223,6 +234,7 @@ static FwdScratch fwd_scratch(const nrms_encoder_desc* d) {
     f.n_live = f.live + (skip_pad_rows(d) ? align_up((size_t)d->n_seq * d->seq_len * sizeof(int), 256) : 0);
     f.cscr = f.n_live + (skip_pad_rows(d) ? 256 : 0);
     f.total = f.cscr + (skip_pad_rows(d) ? align_up(compact_scratch_ints((long)d->n_seq * d->seq_len) * sizeof(int), 256) : 0);
+    if (d->flags & NRMS_FLAG_FUSED_SEQ64) f.total = std::max(f.total, align_up(user64_fwd_planes_bytes(d->n_heads), 256));
     return f;
 }
 
@@ -448,6 +460,16 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     }
     NRMS_REQUIRE(w && acts && out, "encoder_fwd: null argument");
     NRMS_REQUIRE(w->w_qkv && w->b_qkv && w->w_add && w->b_add && w->q_vec, "encoder_fwd: null weight");
+    if (desc->flags & NRMS_FLAG_FUSED_SEQ64) {
+        // the user encoder as one kernel (csrc/user64.hip); acts.qkv holds operand fragments (nrms_encoder_fused_qkv_bytes)
+        NRMS_REQUIRE(x != nullptr && acts->qkv != nullptr && acts->scratch != nullptr, "encoder_fwd(fused): x, acts.qkv and acts.scratch are required");
+        const bool train = acts->ctx != nullptr && acts->t != nullptr && acts->w != nullptr;
+        if (desc->n_seq == 0) return NRMS_OK;
+        rc = fused_bwd16_join((hipStream_t)stream);
+        if (rc) return rc;
+        return launch_user64_fwd(desc->n_seq, desc->seq_len, desc->d_model, desc->n_heads, desc->q_dim, x, w->w_qkv, w->b_qkv, w->w_add,
+                                 w->b_add, w->q_vec, acts->scratch, acts->ctx, acts->t, acts->w, acts->qkv, out, train, (hipStream_t)stream);
+    }
     NRMS_REQUIRE(acts->qkv && acts->ctx, "encoder_fwd: acts.qkv / acts.ctx are required");
     const bool gather = desc->vocab > 0, wo = desc->use_output_proj != 0;
     NRMS_REQUIRE(gather ? (ids != nullptr && w->table != nullptr) : (x != nullptr),
@@ -540,6 +562,11 @@ extern "C" size_t nrms_encoder_fwd_scratch_bytes(const nrms_encoder_desc* desc) 
     if (validate_desc(desc, "encoder_fwd_scratch_bytes")) return 0;
     if (desc->precision == NRMS_PRECISION_FP16) return fwd16_scratch(desc).total;
     return fwd_scratch(desc).total;
+}
+
+extern "C" size_t nrms_encoder_fused_qkv_bytes(const nrms_encoder_desc* desc) {
+    if (desc == nullptr || !(desc->flags & NRMS_FLAG_FUSED_SEQ64) || validate_desc(desc, "encoder_fused_qkv_bytes")) return 0;
+    return user64_qkv_bytes(desc->n_seq, desc->n_heads);
 }
 
 extern "C" size_t nrms_encoder_bwd_workspace_bytes(const nrms_encoder_desc* desc) {
@@ -685,14 +712,22 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         return side ? side_order(ss, i, s, s2, "encoder_bwd") : NRMS_OK;
     };
 
-    // 1. pooling rows: ds, d(q_vec)
-    if (wide_additive(desc))
-        rc = launch_addattn_rows_bwd_wide(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
-                                          pmask, s);
-    else
-        rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
-                                     pmask, s);
-    if (rc) return rc;
+    const bool fused64 = (desc->flags & NRMS_FLAG_FUSED_SEQ64) != 0;
+    if (fused64) {
+        // steps 1, 2 and 4 as ONE kernel (csrc/user64.hip): pooling backward, d(ctx), attention backward -> ds, d(q_vec), dQKV
+        rc = launch_user64_bwd(desc->n_seq, S, d, desc->n_heads, q, w->w_add, w->q_vec, base + L.u64planes, dout, acts->t, acts->w,
+                               acts->qkv, ds, dq_partial, grads->q_vec, dqkv, s);
+        if (rc) return rc;
+    } else {
+        // 1. pooling rows: ds, d(q_vec)
+        if (wide_additive(desc))
+            rc = launch_addattn_rows_bwd_wide(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
+                                              pmask, s);
+        else
+            rc = launch_addattn_bwd_rows(desc->n_seq, S, d, q, acts->ctx, dout, acts->w, acts->t, ds, dq_partial, grads->q_vec,
+                                         pmask, s);
+        if (rc) return rc;
+    }
     // 3. d(w_add), d(b_add) = dZ^T [ctx | 1]: needs ds only -- on the helper stream, beside everything below
     rc = fork(0);
     if (rc) return rc;
@@ -704,20 +739,22 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         rc = tn_gemm(desc, t, s2, "dwadd_bwd");
         if (rc) return rc;
     }
-    // 2. d(ctx) = dZ Wa + w_s dout, then through the context-dropout mask in the GEMM's coalesced
-    //    epilogue (one Philox call per float4) -- the attention backward then carries no RNG work.
-    rc = launch_transpose(w->w_add, wadd_t, q, d, s);
-    if (rc) return rc;
-    {
-        NTArgs g{};
-        g.M = M; g.N = d; g.K = q; g.rows_per_tile = NT_BM;
-        g.ds = ds; g.qv = w->q_vec; g.T = acts->t;
-        g.W = wadd_t; g.C = dctx; g.ldc = d;
-        g.wrow = acts->w; g.dout = dout; g.S = S;
-        g.drop = drop_c;
-        rc = nt_gemm(desc, A_DZ, E_DCTX, g, wplanes, s, "dctx_bwd");
+    if (!fused64) {
+        // 2. d(ctx) = dZ Wa + w_s dout, then through the context-dropout mask in the GEMM's coalesced
+        //    epilogue (one Philox call per float4) -- the attention backward then carries no RNG work.
+        rc = launch_transpose(w->w_add, wadd_t, q, d, s);
         if (rc) return rc;
-    }
+        {
+            NTArgs g{};
+            g.M = M; g.N = d; g.K = q; g.rows_per_tile = NT_BM;
+            g.ds = ds; g.qv = w->q_vec; g.T = acts->t;
+            g.W = wadd_t; g.C = dctx; g.ldc = d;
+            g.wrow = acts->w; g.dout = dout; g.S = S;
+            g.drop = drop_c;
+            rc = nt_gemm(desc, A_DZ, E_DCTX, g, wplanes, s, "dctx_bwd");
+            if (rc) return rc;
+        }
+}
     const float* dattn_in = dctx;
     if (wo) {
         // 3b. output projection: d(W_O), d(b_O) = dC^T [attn | 1] (helper stream: reads d(ctx));  d(attn) = dC W_O
@@ -758,7 +795,9 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
     }
     // 4. attention backward
     const Dropout pdrop_attn = make_dropout(desc->seed, desc->p_drop_attn);
-    if (wide_attention(desc))
+    if (fused64)
+        rc = NRMS_OK;                               // (dQKV is there already)
+    else if (wide_attention(desc))
         rc = launch_attention_wide(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, pdrop_attn, dattn_in, dqkv, amask, s);
     else
         rc = launch_attention(true, desc->n_seq, S, d, desc->n_heads, acts->qkv, nullptr, no_drop, dattn_in, dqkv, amask,

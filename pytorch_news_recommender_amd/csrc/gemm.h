@@ -395,6 +395,20 @@ size_t fused16v1_bwd_bytes(long M, int n_seq, int h);
 int launch_fused_bwd16v1(const Fused16Bwd& f, hipStream_t stream);
 int fused_bwd16_join(hipStream_t stream);
 
+// user64.hip: the split-bf16 user encoder (sequences of 33..64 rows) as one kernel per direction (NRMS_FLAG_FUSED_SEQ64)
+bool user64_supported(int S, int d, int h, int q, const char** why);
+size_t user64_qkv_bytes(int n_seq, int h);             // acts.qkv under the flag: operand fragments instead of [M, 3d] floats
+size_t user64_fwd_planes_bytes(int h);                 // forward weight planes (acts.scratch)
+size_t user64_bwd_planes_bytes(int h);                 // backward weight planes (workspace)
+size_t user64_dq_partial_floats(int n_seq);
+int launch_user64_fwd(int n_seq, int S, int d, int h, int q, const float* x, const float* w_qkv, const float* b_qkv,
+                      const float* w_add, const float* b_add, const float* q_vec, void* planes, float* ctx, float* t, float* w,
+                      void* qkv, float* out, bool train, hipStream_t stream);
+// leaves ds [M] and dqkv [M, 3d] (head-major) for the weight-gradient / dX GEMMs; d(q_vec) is accumulated
+int launch_user64_bwd(int n_seq, int S, int d, int h, int q, const float* w_add, const float* q_vec, void* planes, const float* dout,
+                      const float* t, const float* w, const void* qkv, float* ds, float* dq_partial, float* dq_vec, float* dqkv,
+                      hipStream_t stream);
+
 // embed.hip
 // dst[i] = src[i] if 0 <= src[i] < vocab else 0; *n_bad += ids replaced (dst may alias src)
 int launch_sanitize_ids(long n, const void* src, bool src_is_int32, int64_t* dst, int vocab, int* n_bad, hipStream_t stream);

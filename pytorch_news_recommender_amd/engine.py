@@ -125,6 +125,9 @@ class NRMSEngine:
         # in bf16x3 unless this is set (config.fp16_inference): evaluation scores then sit ~1e-6 from the reference and the
         # per-impression AUC cannot move by rank flips of near-tied candidates (round 3 measured 1.4e-4 on 1 024 impressions)
         self.fp16_inference = False
+        # the user encoder's bf16x3 passes (33..64-slot histories, d <= 300, heads <= 32 wide, no mask / W_O) as ONE kernel per
+        # direction (csrc/user64.hip, NRMS_FLAG_FUSED_SEQ64) instead of the GEMM -> attention -> additive chain; False = the chain
+        self.fused_user_encoder = True
         self.fp16_wide_heads_backward = True    # ... its training step too (csrc/fused16_v1_bwd.hip); False: training in bf16x3
         self._gen = 0                      # generation stamp of _saved (checked by the autograd backward)
         # out-of-range word ids: counted on the device by nrms_sanitize_ids, surfaced without a host sync
@@ -193,12 +196,18 @@ class NRMSEngine:
         prec = self.precision
         if prec == "fp16" and not self._fp16_ok(enc, seq_len, mask_mode, training):
             prec = "bf16x3"
-        return _lib.EncoderDesc(n_seq=n_seq, seq_len=seq_len, d_model=d.word_embed_size, n_heads=d.heads(enc),
+        flags = _lib.NRMS_FLAG_PAD_ROW_ZERO if (self.pad_row_zero and enc == "news_encoder") else 0
+        h = d.heads(enc)
+        if (enc == "user_encoder" and self.fused_user_encoder and prec == "bf16x3" and not d.output_proj and not mask_mode
+                and 32 < seq_len <= 64 and d.word_embed_size <= 300 and d.word_embed_size % h == 0
+                and (d.word_embed_size // h) <= 32 and (d.word_embed_size // h) % 2 == 0 and h <= 10 and d.query_vector_dim <= 224):
+            flags |= _lib.NRMS_FLAG_FUSED_SEQ64
+        return _lib.EncoderDesc(n_seq=n_seq, seq_len=seq_len, d_model=d.word_embed_size, n_heads=h,
                                 q_dim=d.query_vector_dim, vocab=d.n_words if enc == "news_encoder" else 0,
                                 p_drop_embed=float(p_embed), p_drop_ctx=float(p_ctx),
                                 precision=_lib.PRECISIONS[prec], use_output_proj=int(d.output_proj),
                                 mask_mode=int(mask_mode),
-                                flags=(_lib.NRMS_FLAG_PAD_ROW_ZERO if (self.pad_row_zero and enc == "news_encoder") else 0),
+                                flags=flags,
                                 seed=int(seed), loss_scale=float(self.loss_scale), p_drop_attn=0.0)
 
     def _ptrs(self, cls, flat, enc):
@@ -233,6 +242,17 @@ class NRMSEngine:
             dp = lambda z: None if z is None else z.data_ptr()
             return _lib.EncoderActs(x=dp(x), qkv=None, attn=dp(attn), ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
         x = self._buf(tag + ".x", M * d) if gather else None
+        if desc is not None and desc.flags & _lib.NRMS_FLAG_FUSED_SEQ64:
+            # acts.qkv = operand fragments of the fused user-encoder kernels (include/nrms_hip.h, NRMS_FLAG_FUSED_SEQ64)
+            nb = int(self.lib.nrms_encoder_fused_qkv_bytes(C.byref(desc)))
+            qkv = self._buf(tag + ".qkvf", (nb + 3) // 4)
+            ctx = self._buf(tag + ".ctx", M * d) if need_bwd else None
+            t = self._buf(tag + ".t", M * q) if need_bwd else None
+            w = self._buf(tag + ".w", M) if need_bwd else None
+            ns = int(self.lib.nrms_encoder_fwd_scratch_bytes(C.byref(desc)))
+            scratch = self._buf("fwd_scratch64", (ns + 3) // 4)
+            dp = lambda z: None if z is None else z.data_ptr()
+            return _lib.EncoderActs(x=None, qkv=dp(qkv), attn=None, ctx=dp(ctx), t=dp(t), w=dp(w), scratch=dp(scratch))
         qkv = self._buf(tag + ".qkv", M * 3 * d)
         attn = self._buf(tag + ".attn", M * d) if self.dims.output_proj else None
         ctx = self._buf(tag + ".ctx", M * d)

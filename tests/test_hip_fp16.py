@@ -337,7 +337,7 @@ def test_fp16_gradient_overflow_is_counted_skipped_and_backed_off():
     Now: the guarded optimizer leaves non-finite elements out and counts them on the device, the count reaches the host
     asynchronously, and the following steps run with more head room (desc.loss_scale = -n).
     (a) forced: a fixed loss scale of 2^40 makes every fp16 gradient inf -- nothing becomes non-finite, the step is reported;
-    (b) natural: the news encoder's W_V scaled by 1e4 (V ~ 4 000) overflows the default head room; the back-off finds a scale
+    (b) natural: the news encoder's W_V scaled by 3e4 (V ~ 12 000) overflows the default head room; the back-off finds a scale
         that fits within a few steps, parameters and moments stay finite throughout, and the gradients at that scale agree
         with the exact fp32 mode's."""
     import warnings
@@ -381,7 +381,7 @@ def test_fp16_gradient_overflow_is_counted_skipped_and_backed_off():
     # (b) natural overflow
     wv = "news_encoder.multihead_self_attention.W_V.weight"
     p2 = dict(params)
-    p2[wv] = params[wv] * 1e4
+    p2[wv] = params[wv] * 3e4
     m2 = make_model(shape, p2, precision="fp16").train()
     m2.config.learning_rate = 1e-6
     e2 = m2.engine
