@@ -602,7 +602,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import hbm_traffic
             sha = hbm_traffic.csrc_sha16()
-            tfile = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % args.precision)
+            tfile = os.path.join(ROOT, "profiles", "r04_%s_hbm_traffic.json" % args.precision)
             prof = None
             if os.path.exists(tfile) and not args.fp16_user_encoder:
                 try:

@@ -70,11 +70,14 @@ struct TileRing {
     __device__ __forceinline__ void load(int n) {
         if (n >= n_tiles) return;
         if (F16_DBG(dbg, 1)) return;
-        const _Float16* t = src + (long)n * (32 * F16_KP) + tid * 8;
+        // uniform base (scalar registers) + ONE 32-bit lane offset for all chunks: per-chunk 64-bit lane addresses were ten
+        // registers the backward kernels spilled and reloaded in front of every tile
+        const char* t = reinterpret_cast<const char*>(src) + (long)n * (32 * F16_KP * 2);
+        const unsigned off = (unsigned)tid * 16u;
 #pragma unroll
         for (int i = 0; i < F16_STG; ++i)
             if (F16_STG_EXACT || i + 1 < F16_STG || tid + F16_THREADS * i < 32 * F16_RC)
-                stg[i] = *reinterpret_cast<const h8*>(t + (long)F16_THREADS * 8 * i);
+                stg[i] = *reinterpret_cast<const h8*>(t + (long)F16_THREADS * 16 * i + off);
     }
     __device__ __forceinline__ void store(int n) {
         if (n >= n_tiles) return;

@@ -242,7 +242,7 @@ struct U64FwdArgs {
     unsigned long long* stamps;   // experiments only: s_memrealtime (100 MHz) of workgroup 0 at phase boundaries
 };
 #ifdef NRMS_U64_EXPERIMENTS
-#define U64_STAMP(a, i) do { if ((a).stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) (a).stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define U64_STAMP(a, i) do { if ((a).stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { (a).stamps[i] = __builtin_amdgcn_s_memrealtime(); (a).stamps[32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define U64_STAMP(a, i) do {} while (0)
 #endif
@@ -874,6 +874,7 @@ int launch_user64_fwd(int n_seq, int S, int d, int h, int q, const float* x, con
     a.stamps = g_stamps;
     if (g_stamps != nullptr && getenv("NRMS_U64_STAMPS") != nullptr) {
         (void)hipStreamSynchronize(stream);
+        fprintf(stderr, "[shader clock over the head loop: %.0f MHz]\n", (double)(g_stamps[32 + 2] - g_stamps[32 + 1]) / ((g_stamps[2] - g_stamps[1]) * 0.01));
         fprintf(stderr, "[user64_fwd stamps, us] prologue %.2f | tile0 %.2f | head1 (Q..V barrier %.2f, attention+stores %.2f) | heads total %.2f | zero+reload %.2f | additive %.2f | softmax+pool %.2f\n",
                 (g_stamps[1] - g_stamps[0]) * 0.01, 0.0, (g_stamps[8] - g_stamps[6]) * 0.01, (g_stamps[7] - g_stamps[8]) * 0.01,
                 (g_stamps[2] - g_stamps[1]) * 0.01, (g_stamps[3] - g_stamps[2]) * 0.01, (g_stamps[4] - g_stamps[3]) * 0.01, (g_stamps[5] - g_stamps[4]) * 0.01);

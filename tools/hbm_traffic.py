@@ -14,7 +14,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel symbol -> bench.py timer name
-TIMER_OF = [("fused_fwd16v1_kernel", "fused_fwd16"), ("fused_bwd16v1_attn_kernel", "fused_bwd16_attn"), ("gemm16_tn_kernel<true, 4", "dwo_bwd"),
+TIMER_OF = [("user64_fwd_kernel", "user64_fwd"), ("user64_bwd_kernel", "user64_bwd"), ("user64_prep_kernel", "user64_prep"),
+            ("fused_fwd16v1_kernel", "fused_fwd16"), ("fused_bwd16v1_attn_kernel", "fused_bwd16_attn"), ("gemm16_tn_kernel<true, 4", "dwo_bwd"),
             ("fused_fwd16p_kernel", "fused_fwd16"), ("fused_fwd16_kernel<true, 1>", "fused_fwd16"), ("fused_fwd16_kernel<true, 2>", "fused64_fwd16"),
             ("fused_bwd16_pool_kernel<1>", "fused_bwd16_pool"), ("fused_bwd16_pool_kernel<2>", "fused64_bwd16_pool"),
             ("fused_bwd16_attn_kernel<1>", "fused_bwd16_attn"), ("fused_bwd16_attn_kernel<2>", "fused64_bwd16_attn"),

@@ -23,6 +23,7 @@ if args.model == "v1":
     cfg.__nrms__()
     cfg.num_attention_heads, cfg.title_heads_num = 10, 6
     cfg.dropout, cfg.learning_rate, cfg.precision = 0.2, 1e-3, args.precision
+    cfg.fp16_v1_news_encoder = True        # the opt-in fused fp16 news encoder of nrms_v1 (csrc/fused16_v1*.hip): the kernels this profiles
     params = synth.make_params_v1(shape, seed=0)
     table = params["news_encoder.word_embedding.weight"]
 else:
