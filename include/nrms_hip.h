@@ -84,7 +84,10 @@ extern "C" {
 /* nrms_encoder_bwd, NRMS_PRECISION_FP16 news encoder: `acts.scratch` is still exactly what the nrms_encoder_fwd call of this
  * step left in it (the caller has not passed that buffer to another forward in between).  The backward then reads the token
  * and title lists the forward built there (live rows, row positions, the three title classes) instead of rebuilding them
- * from the ids (five small launches).  Without the flag nothing in acts.scratch is read by the backward. */
+ * from the ids (five small launches).  Without the flag nothing in acts.scratch is read by the backward.  The promise is
+ * checked on the host: the library remembers which forward (scratch, ids, n_seq, seq_len, ...) last built lists in a scratch
+ * buffer and forgets it when ANY nrms_encoder_fwd is handed that buffer again; a backward whose arguments do not match the
+ * record rebuilds the lists as if the flag were absent (correct results, five more launches). */
 #define NRMS_FLAG_FWD_SCRATCH_KEPT 4
 /* User encoder (vocab == 0), NRMS_PRECISION_BF16X3, 33 <= seq_len <= 64, d_model <= 300, even d_k <= 32, n_heads <= 10,
  * q_dim <= 224, no output projection, no mask, no dropout: the whole pass runs as ONE kernel per direction (csrc/user64.hip: a

@@ -256,6 +256,35 @@ static Fwd16Scratch fwd16_scratch(const nrms_encoder_desc* d) {
     return f;
 }
 
+// ---- NRMS_FLAG_FWD_SCRATCH_KEPT is a promise of the caller; the library checks it on the HOST.  Every nrms_encoder_fwd forgets
+// what it knew about the scratch buffer it is handed, and an fp16 news-encoder forward that builds token / title lists in it
+// records (scratch, ids, shape).  A backward with the flag uses the lists only if that record still matches its own arguments;
+// otherwise it rebuilds them from the ids, as without the flag -- a caller that reused the scratch for another forward, or
+// changed n_seq or the ids, gets correct gradients instead of out-of-bounds list entries.  (Memory the caller overwrote by other
+// means is beyond what a host-side record can see.)  One mutex-protected table per process, at most 64 entries.
+struct KeptRec { const void* scratch; const void* ids; int n_seq, seq_len, vocab, d_model, n_heads, use_wo; };
+static std::mutex g_kept_mu;
+static std::vector<KeptRec> g_kept;
+static void kept_forget(const void* scratch) {
+    if (scratch == nullptr) return;
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    for (size_t i = 0; i < g_kept.size(); ++i)
+        if (g_kept[i].scratch == scratch) { g_kept[i] = g_kept.back(); g_kept.pop_back(); break; }
+}
+static void kept_record(const nrms_encoder_desc* d, const void* scratch, const void* ids) {
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    if (g_kept.size() >= 64) g_kept.erase(g_kept.begin());
+    g_kept.push_back(KeptRec{scratch, ids, d->n_seq, d->seq_len, d->vocab, d->d_model, d->n_heads, d->use_output_proj});
+}
+static bool kept_matches(const nrms_encoder_desc* d, const void* scratch, const void* ids) {
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    for (const KeptRec& r : g_kept)
+        if (r.scratch == scratch)
+            return r.ids == ids && r.n_seq == d->n_seq && r.seq_len == d->seq_len && r.vocab == d->vocab && r.d_model == d->d_model &&
+                   r.n_heads == d->n_heads && r.use_wo == d->use_output_proj;
+    return false;
+}
+
 static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int64_t* ids, const float* x,
                          const nrms_encoder_acts* acts, float* out, hipStream_t s) {
     const bool gather = desc->vocab > 0;
@@ -321,7 +350,9 @@ static int encoder_fwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
         rc = launch_cast16(M, d, L.KP, x, acts->x, s);
         if (rc) return rc;
     }
-    return v1 ? launch_fused_fwd16v1(f, h, acts->attn, s) : launch_fused_fwd16(f, s);
+    rc = v1 ? launch_fused_fwd16v1(f, h, acts->attn, s) : launch_fused_fwd16(f, s);
+    if (rc == NRMS_OK && gather && skip_pad_rows(desc)) kept_record(desc, acts->scratch, ids);
+    return rc;
 }
 
 // ---- fp16 backward workspace: fused16_bwd_layout | live | pos | n_live | compaction scratch | order | order_cnt |
@@ -378,7 +409,8 @@ static int encoder_bwd16(const nrms_encoder_desc* desc, const nrms_encoder_weigh
     int* live = (int*)(base + L.live);
     int* n_live = (int*)(base + L.n_live);
     if (gather) {
-        const bool kept = (desc->flags & NRMS_FLAG_FWD_SCRATCH_KEPT) != 0 && skip_pad_rows(desc) && acts->scratch != nullptr;
+        const bool kept = (desc->flags & NRMS_FLAG_FWD_SCRATCH_KEPT) != 0 && skip_pad_rows(desc) && acts->scratch != nullptr &&
+                          kept_matches(desc, acts->scratch, ids);          // (a stale promise: rebuild, below)
         if (kept) {
             // the lists of this step's forward, where encoder_fwd16 left them
             const Fwd16Scratch fs = fwd16_scratch(desc);
@@ -451,6 +483,7 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
                                 void* stream) {
     int rc = validate_desc(desc, "encoder_fwd");
     if (rc) return rc;
+    if (acts != nullptr) kept_forget(acts->scratch);          // whatever lists an earlier forward left in this scratch are gone
     if (desc->precision == NRMS_PRECISION_FP16) {
         NRMS_REQUIRE(w && acts && out, "encoder_fwd: null argument");
         NRMS_REQUIRE(w->w_qkv && w->b_qkv && w->w_add && w->b_add && w->q_vec, "encoder_fwd: null weight");

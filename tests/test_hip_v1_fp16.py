@@ -332,6 +332,36 @@ def test_fp16_backward_without_the_kept_forward_scratch_rebuilds_the_same_lists(
     assert torch.equal(grads[0], grads[1])
 
 
+def test_a_stale_kept_scratch_promise_is_noticed_on_the_host():
+    """with NRMS_FLAG_FWD_SCRATCH_KEPT the backward took the token / title lists from acts.scratch unchecked; a caller
+    that had handed the same scratch to ANOTHER forward in between (other ids, another n_seq) got lists that index out of bounds.
+    The library now records on the host which forward built the lists of a scratch buffer, forgets it when any forward is given
+    that buffer again, and rebuilds the lists when the record does not match the backward's arguments: the gradients of a
+    training forward whose scratch was reused equal those of an undisturbed one, bit for bit."""
+    from tests.test_hip_parity import make_model
+    shape = synth.Shape(n_words=3000, word_embed_size=300, num_attention_heads=10, query_vector_dim=200,
+                        batch_size=8, history_len=20, n_candidates=5, n_words_title=30)
+    model = make_model(shape, synth.make_params(shape, seed=3), dropout=0.2, precision="fp16").train()
+    batch = synth.make_batch(shape, seed=4, ragged=True, min_title=1, all_pad_title=True)
+    eng, flat = model.engine, model._flat
+    bt, ct, cm = (torch.from_numpy(batch[k]).cuda() for k in ("browsed_titles", "candidate_titles", "candidate_mask"))
+    other = torch.from_numpy(synth.make_batch(shape, seed=9, ragged=True, min_title=1)["browsed_titles"]).cuda().reshape(-1, 30)[:37].contiguous()
+    grads = []
+    for disturb in (False, True):
+        s = eng.forward(flat, bt, ct, cm, training=True, p_drop=0.2, seed=77)
+        if disturb:
+            # another news-encoder forward on the SAME scratch memory (its own activation buffers: only the lists are clobbered)
+            eng._bufs["intruder.scratch16"] = eng._bufs["news.scratch16"]
+            eng.encode_titles(flat, other, save=True, tag="intruder", p_ctx=0.2, seed=5)
+        dsc = (torch.randn(s.shape, generator=torch.Generator().manual_seed(5)) * 1e-2).cuda()
+        g = torch.zeros_like(flat)
+        eng.backward(flat, g, dsc)
+        torch.cuda.synchronize()
+        grads.append(g)
+    assert float(grads[0].abs().max()) > 0
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_v1_default_routing_against_the_oracle_at_the_benchmarked_size():
     """nrms_v1 with config.precision = "fp16" and nothing else set -- what bench.py's nrms_v1 leg leads with: the news encoder
     (six heads of 50, W_O) stays on the split-bf16 kernels because its fused fp16 form misses the absolute 1e-4 (above), so the
