@@ -337,7 +337,7 @@ def test_fp16_gradient_overflow_is_counted_skipped_and_backed_off():
     Now: the guarded optimizer leaves non-finite elements out and counts them on the device, the count reaches the host
     asynchronously, and the following steps run with more head room (desc.loss_scale = -n).
     (a) forced: a fixed loss scale of 2^40 makes every fp16 gradient inf -- nothing becomes non-finite, the step is reported;
-    (b) natural: the news encoder's W_V scaled by 3e4 (V ~ 12 000) overflows the default head room; the back-off finds a scale
+    (b) natural: the news encoder's W_Q, W_K, W_V scaled by 3e3 overflow the default head room in dX; the back-off finds a scale
         that fits within a few steps, parameters and moments stay finite throughout, and the gradients at that scale agree
         with the exact fp32 mode's."""
     import warnings
@@ -378,20 +378,28 @@ def test_fp16_gradient_overflow_is_counted_skipped_and_backed_off():
     eng.loss_scale_override = None
     eng.loss_scale_backoff = 0
 
-    # (b) natural overflow
+    # (b) natural overflow: W_Q, W_K, W_V of the news encoder scaled by 3e3.  The attention becomes one-hot (fp32 softmax: fine),
+    # dV = P^T d(ctx) stays O(100) at the default scale, and dX = dQKV W' -- carried as loss-scaled fp16 -- reaches ~6e5 > 65504.
+    # The upstream gradient is given directly (with weights like these the CE gradient can be exactly zero).
     wv = "news_encoder.multihead_self_attention.W_V.weight"
     p2 = dict(params)
-    p2[wv] = params[wv] * 3e4
+    for nm in ("W_Q", "W_K", "W_V"):
+        p2["news_encoder.multihead_self_attention.%s.weight" % nm] = params["news_encoder.multihead_self_attention.%s.weight" % nm] * 3e3
     m2 = make_model(shape, p2, precision="fp16").train()
-    m2.config.learning_rate = 1e-6
-    e2 = m2.engine
+    e2, f2 = m2.engine, m2._flat
+    dsc = (torch.randn(shape.batch_size, shape.n_candidates, generator=torch.Generator().manual_seed(8)) * 1e-3).cuda()
+    mom, var = torch.zeros_like(f2), torch.zeros_like(f2)
     seen, clean_at = 0, None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for i in range(14):
-            m2.train_step(tb)
+            e2.forward(f2, tb["browsed_titles"], tb["candidate_titles"], tb["candidate_mask"], training=True)
+            g2 = torch.zeros_like(f2)
+            e2.backward(f2, g2, dsc)
+            e2.adam_step(f2, g2, mom, var, i + 1, lr=1e-7)          # guarded: precision fp16
+            e2.note_grad_check()
             e2.poll_grad_overflow(block=True)
-            assert _finite(m2._flat, m2._opt["m"], m2._opt["v"]), i
+            assert _finite(f2, mom, var), i
             if e2.grad_overflow_steps == seen and seen > 0:
                 clean_at = i
                 break
