@@ -312,6 +312,38 @@ int nrms_news_features_fwd(const nrms_news_features* f, float* out, void* stream
 int nrms_news_features_bwd(const nrms_news_features* f, const float* dout, float* d_title_vec, float* d_abst_vec,
                            float* d_cat_table, float* d_sub_table, void* stream);
 
+/* ---- Gather + additive-attention aggregate over variable-length segments (BASELINE configs 4-5) ----
+ *   out[s] = sum_{k in [seg_ptr[s], seg_ptr[s+1])} alpha_k x[idx[k]],   alpha = softmax over the segment of
+ *   q_vec . tanh(W_add x[idx[k]] + b_add)          -- AdditiveAttention (model/nrms_v0.py:100-126) over an index list.
+ * It is the aggregation step of a HieRec-style hierarchical interest model (clicked news pooled per sub-topic, sub-topic interests
+ * per topic, topic interests per user: each level is this call over a PARTITION of its rows) and of a user-news graph encoder
+ * (neighbour gather + attention aggregate: segments = adjacency lists, a row may be a member of many segments).  The reference
+ * holds no implementation of either (model/tanr.py is empty): the checker is a torch restatement of the formula
+ * (oracle/segpool_oracle.py) -- PARITY UNPINNED.  An empty segment yields a zero row. */
+#define NRMS_SEGPOOL_ROWS_UNIQUE 1   /* every row is a member of at most one segment: d(logit) and dx are then plain, bit-reproducible
+                                        stores; without the flag they are float atomics (summation order may vary) */
+typedef struct nrms_segpool_desc {
+    int64_t n_rows;       /* rows of x */
+    int64_t n_seg;        /* segments */
+    int64_t nnz;          /* members in all segments = seg_ptr[n_seg] */
+    int32_t d;            /* row width: multiple of 4, <= 1024 */
+    int32_t q;            /* width of the additive attention: multiple of 4, <= 512 */
+    int32_t precision;    /* NRMS_PRECISION_FP32 / _BF16X3 / _BF16: the arithmetic of the two projections (x W_add^T and dZ W_add, dZ^T x) */
+    int32_t flags;        /* NRMS_SEGPOOL_* */
+} nrms_segpool_desc;
+size_t nrms_segment_pool_workspace_bytes(const nrms_segpool_desc* desc);
+/* x [n_rows, d]; seg_ptr int32 [n_seg + 1] ascending from 0; idx int32 [nnz], every entry in [0, n_rows).  Saved for the backward:
+ * t [n_rows, q] = tanh(x W_add^T + b_add), alpha [nnz]; logit [n_rows] is scratch the caller provides.  out [n_seg, d]. */
+int nrms_segment_pool_fwd(const nrms_segpool_desc* desc, const float* x, const float* w_add, const float* b_add,
+                          const float* q_vec, const int32_t* seg_ptr, const int32_t* idx, float* t, float* logit, float* alpha,
+                          float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* dout [n_seg, d] -> dx [n_rows, d] (OVERWRITTEN: rows outside every segment get their projection gradient, i.e. zero);
+ * dw_add [q, d], db_add [q], dq_vec [q] are ACCUMULATED. */
+int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float* x, const float* w_add, const float* q_vec,
+                          const int32_t* seg_ptr, const int32_t* idx, const float* t, const float* alpha, const float* dout,
+                          float* dx, float* dw_add, float* db_add, float* dq_vec, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* The keep mask (1 = kept) the encoder kernels apply at a dropout site, for n_rows x d
  * elements: site 0 = embedding dropout (nrms_v0.py:137), site 1 = context dropout (:171-173), site 2 = attention
  * probabilities ([n_seq * n_heads * seq_len, seq_len], nrms_naml.py:36-39), site 3 = news feature rows (:175).

@@ -51,6 +51,14 @@ class EncoderActs(C.Structure):
                 ("t", C.c_void_p), ("w", C.c_void_p), ("scratch", C.c_void_p)]
 
 
+class SegPoolDesc(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_seg", C.c_int64), ("nnz", C.c_int64), ("d", C.c_int32), ("q", C.c_int32),
+                ("precision", C.c_int32), ("flags", C.c_int32)]
+
+
+NRMS_SEGPOOL_ROWS_UNIQUE = 1
+
+
 class NewsFeatures(C.Structure):
     _fields_ = [("n", C.c_int64), ("d_text", C.c_int32), ("d_cat", C.c_int32), ("n_cat", C.c_int32), ("n_sub", C.c_int32),
                 ("p_drop", C.c_float), ("seed", C.c_uint64), ("title_vec", C.c_void_p), ("abst_vec", C.c_void_p),
@@ -86,6 +94,9 @@ SIGNATURES = {
     "nrms_adam_step_guarded": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                          C.c_double, C.c_double, C.c_double, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "nrms_grad_guard": (C.c_int, [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrms_segment_pool_workspace_bytes": (C.c_size_t, [C.POINTER(SegPoolDesc)]),
+    "nrms_segment_pool_fwd": (C.c_int, [C.POINTER(SegPoolDesc)] + [C.c_void_p] * 10 + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nrms_segment_pool_bwd": (C.c_int, [C.POINTER(SegPoolDesc)] + [C.c_void_p] * 12 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "nrms_impression_auc": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "nrms_dropout_keep_mask": (C.c_int, [C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p,

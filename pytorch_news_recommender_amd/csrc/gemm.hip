@@ -74,6 +74,7 @@ int launch_gemm_nt(int amode, int emode, const NTArgs& a, hipStream_t stream, co
     if ((a.K & 3) != 0) { set_error("%s: K=%d must be a multiple of 4", name, a.K); return NRMS_EINVAL; }
     if (amode == A_PLAIN && emode == E_STORE) return launch_nt_mode<A_PLAIN, E_STORE>(a, stream, name);
     if (amode == A_DZ && emode == E_DCTX) return launch_nt_mode<A_DZ, E_DCTX>(a, stream, name);
+    if (amode == A_DZ && emode == E_STORE) return launch_nt_mode<A_DZ, E_STORE>(a, stream, name);      // segpool.hip: dx = dZ W_add
     set_error("%s: unsupported gemm_nt mode %d/%d", name, amode, emode);
     return NRMS_EINVAL;
 }

@@ -329,9 +329,11 @@ int launch_gemm_nt_bf16(int amode, int emode, int npass, const NTArgs& g_in, voi
     if (npass == 3) {
         if (amode == A_PLAIN && emode == E_STORE) return launch_bf_mode<A_PLAIN, E_STORE, 3>(a, stream, name);
         if (amode == A_DZ && emode == E_DCTX) return launch_bf_mode<A_DZ, E_DCTX, 3>(a, stream, name);
+        if (amode == A_DZ && emode == E_STORE) return launch_bf_mode<A_DZ, E_STORE, 3>(a, stream, name);
     } else {
         if (amode == A_PLAIN && emode == E_STORE) return launch_bf_mode<A_PLAIN, E_STORE, 1>(a, stream, name);
         if (amode == A_DZ && emode == E_DCTX) return launch_bf_mode<A_DZ, E_DCTX, 1>(a, stream, name);
+        if (amode == A_DZ && emode == E_STORE) return launch_bf_mode<A_DZ, E_STORE, 1>(a, stream, name);
     }
     set_error("%s: unsupported bf16 gemm mode %d/%d", name, amode, emode);
     return NRMS_EINVAL;
