@@ -344,6 +344,42 @@ int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float* x, const f
                           float* dx, float* dw_add, float* db_add, float* dq_vec, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* ---- Index side of a HieRec-style hierarchical interest model (BASELINE configs[3]; SURVEY f-4; PARITY UNPINNED: no reference
+ * implementation, checked against oracle/segpool_oracle.py).  A user's clicked news (H <= 64 history slots, `valid` = the
+ * batch dict's browsed_mask) are grouped by sub-topic id, the sub-topic groups by topic id, in order of first occurrence; every
+ * level's groups live in fixed per-user slots b * H + g.  nrms_hier_tree_build writes the three index lists
+ * nrms_segment_pool_fwd / _bwd aggregate over:
+ *   level 1: rows = history slots b * H + k;       l1_ptr [B * H + 1], l1_idx [B * H]: one segment per sub-topic group slot
+ *   level 2: rows = sub-topic group slots;         l2_ptr [B * H + 1], l2_idx [B * H]: one segment per topic group slot
+ *   level 3: rows = topic group slots;             l3_ptr [B + 1],     l3_idx [B * H]: one segment per user
+ * and per slot the ids and click counts (l1_sub, l1_top, l1_cnt, l2_top, l2_cnt: int32 [B * H]; count 0 = empty slot),
+ * n_valid [B].  Every level partitions its rows (NRMS_SEGPOOL_ROWS_UNIQUE). */
+size_t nrms_hier_tree_scratch_bytes(int32_t B, int32_t H);
+int nrms_hier_tree_build(int32_t B, int32_t H, const uint8_t* valid, const int64_t* topic, const int64_t* subtopic,
+                         int32_t* l1_ptr, int32_t* l1_idx, int32_t* l1_sub, int32_t* l1_top, int32_t* l1_cnt,
+                         int32_t* l2_ptr, int32_t* l2_idx, int32_t* l2_top, int32_t* l2_cnt, int32_t* l3_ptr,
+                         int32_t* l3_idx, int32_t* n_valid, void* scratch, size_t scratch_bytes, void* stream);
+/* interest of an occupied slot = its aggregate + the embedding of its (sub-)topic: u[slot] += table[id[slot]] where cnt[slot] > 0;
+ * backward: dtable[r] += sum of du over the occupied slots with id == r, in ascending slot order (no atomics). */
+int nrms_hier_add_embedding_fwd(int64_t n_slots, int32_t d, const int32_t* id, const int32_t* cnt, const float* table, float* u,
+                                void* stream);
+int nrms_hier_add_embedding_bwd(int64_t n_slots, int32_t d, int32_t n_ids, const int32_t* id, const int32_t* cnt,
+                                const float* du, float* dtable, void* stream);
+/* Hierarchical matching.  nrms_hier_match: for candidate (b, c) the user's sub-topic / topic group slot with the candidate's ids
+ * (-1: the user never clicked there) and the share of the user's clicks in it.  nrms_hier_score_fwd:
+ *   score = l_s f_s <n, u1[sub_slot]> + l_t f_t <n, u2[top_slot]> + (1 - l_s - l_t) <n, ug[b]>,  masked slots -1e9.
+ * _bwd: dcand, dug overwritten; du1, du2 [B * H, d] ACCUMULATED (zero them first); one wavefront per user, no atomics. */
+int nrms_hier_match(int32_t B, int32_t C, int32_t H, const int64_t* cand_topic, const int64_t* cand_subtopic,
+                    const int32_t* l1_sub, const int32_t* l1_cnt, const int32_t* l2_top, const int32_t* l2_cnt,
+                    const int32_t* n_valid, int32_t* sub_slot, float* sub_frac, int32_t* top_slot, float* top_frac, void* stream);
+int nrms_hier_score_fwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* u1, const float* u2, const float* ug,
+                        const int32_t* sub_slot, const float* sub_frac, const int32_t* top_slot, const float* top_frac,
+                        const uint8_t* mask, float lambda_sub, float lambda_top, float* scores, void* stream);
+int nrms_hier_score_bwd(int32_t B, int32_t C, int32_t d, const float* cand, const float* u1, const float* u2, const float* ug,
+                        const int32_t* sub_slot, const float* sub_frac, const int32_t* top_slot, const float* top_frac,
+                        const uint8_t* mask, float lambda_sub, float lambda_top, const float* dscores, float* dcand, float* du1,
+                        float* du2, float* dug, void* stream);
+
 /* The keep mask (1 = kept) the encoder kernels apply at a dropout site, for n_rows x d
  * elements: site 0 = embedding dropout (nrms_v0.py:137), site 1 = context dropout (:171-173), site 2 = attention
  * probabilities ([n_seq * n_heads * seq_len, seq_len], nrms_naml.py:36-39), site 3 = news feature rows (:175).

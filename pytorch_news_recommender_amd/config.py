@@ -61,6 +61,9 @@ class Config(object):
         # HIP path only: when embedding row 0 (padding_idx) is all zeros, skip the padding tokens in the
         # Q|K|V projection and its weight gradient (identical results; include/nrms_hip.h NRMS_FLAG_PAD_ROW_ZERO)
         self.skip_padding_tokens = True
+        # model "hierec" (model/hierec_hip.py; parity unpinned): weights of the sub-topic / topic terms of the hierarchical match
+        self.hierec_lambda_sub = 0.7
+        self.hierec_lambda_top = 0.15
 
     def __nrms__(self):
         self.news_feature_size = 800             # nrms_naml: 2 * word_embed_size + 2 * cate_embed_size (config.py:68)

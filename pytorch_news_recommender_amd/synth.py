@@ -334,3 +334,51 @@ def make_batch_naml(s: NamlShape, seed: int = 1, batch_size: int | None = None, 
             "browsed_subcateg_ids": c64(bs), "candidate_titles": c64(ct), "candidate_absts": c64(ca),
             "candidate_categ_ids": c64(cc), "candidate_subcateg_ids": c64(cs), "candidate_mask": cmask,
             "browsed_lens": hist_len.astype(np.int64), "browsed_mask": live.astype(np.uint8)}
+
+
+# ---- HieRec-style hierarchical interest model (model/hierec_hip.py; BASELINE configs[3]; parity unpinned) ----------------------
+def make_params_hierec(shape: Shape, n_sub: int = 294, n_top: int = 19, seed: int = 0):
+    """The NRMS news encoder's parameters (make_params) + sub-topic / topic embedding tables (N(0, 0.1^2), zero padding row)
+    + the three levels' additive attentions (xavier-uniform, U(+-1/sqrt fan_in), U(-0.1, 0.1))."""
+    base = make_params(shape, seed=seed)
+    out = {k: v for k, v in base.items() if k.startswith("news_encoder.")}
+    rng = np.random.default_rng(seed + 1000)
+    d, q = shape.word_embed_size, shape.query_vector_dim
+    for name, n in (("subtopic_embedding.weight", n_sub), ("topic_embedding.weight", n_top)):
+        t = rng.normal(0.0, 0.1, size=(n, d))
+        t[0] = 0.0
+        out[name] = t.astype(np.float32)
+    for lv in ("subtopic_attention", "topic_attention", "user_attention"):
+        a = np.sqrt(6.0 / (d + q))
+        out[lv + ".linear.weight"] = rng.uniform(-a, a, size=(q, d)).astype(np.float32)
+        out[lv + ".linear.bias"] = rng.uniform(-1, 1, size=(q,)).astype(np.float32) / np.float32(np.sqrt(d))
+        out[lv + ".attention_query_vector"] = rng.uniform(-0.1, 0.1, size=(q,)).astype(np.float32)
+    return out
+
+
+def make_batch_hierec(shape: Shape, n_sub: int = 294, n_top: int = 19, seed: int = 1, batch_size: int | None = None,
+                      empty_history_user: bool = False, mask_some_candidates: bool = False, consistent_topics: bool = True,
+                      zipf: float = 1.2):
+    """make_batch + the category keys of data_handler.py:236-250.  Sub-topics are drawn with a Zipf-like skew (a few sub-topics
+    hold most clicks, as in MIND) and, with consistent_topics, each sub-topic belongs to one topic; padding slots carry id 0."""
+    b = make_batch(shape, seed=seed, batch_size=batch_size, empty_history_user=empty_history_user,
+                   mask_some_candidates=mask_some_candidates)
+    rng = np.random.default_rng(seed + 77)
+    B, H = b["browsed_titles"].shape[:2]
+    Cn = b["candidate_titles"].shape[1]
+    w = 1.0 / np.arange(1, n_sub) ** zipf
+    w /= w.sum()
+    owner = rng.integers(1, n_top, size=n_sub)
+
+    def draw(shape_):
+        s = rng.choice(np.arange(1, n_sub), size=shape_, p=w)
+        t = owner[s] if consistent_topics else rng.integers(1, n_top, size=shape_)
+        return s.astype(np.int64), t.astype(np.int64)
+
+    bs, btp = draw((B, H))
+    cs, ctp = draw((B, Cn))
+    valid = np.asarray(b["browsed_mask"]).astype(bool)
+    b["browsed_subcateg_ids"] = np.where(valid, bs, 0)
+    b["browsed_categ_ids"] = np.where(valid, btp, 0)
+    b["candidate_subcateg_ids"], b["candidate_categ_ids"] = cs, ctp
+    return b
