@@ -303,6 +303,49 @@ def naml_leg(dev, B):
             "workload": "B=%d, H=50, C=5, title 20 + abstract 40 words, d=300, news_feature_size=800" % B}
 
 
+def hierec_leg(dev, B):
+    """SURVEY f-4 / BASELINE configs[3]: one train step of the HieRec-style hierarchical interest model (model/hierec_hip.py) at
+    MIND shapes -- the headline's news encoder over B * 55 titles (fp16 mode), then three gather + additive-attention aggregates
+    over index lists built on the device (clicks -> sub-topic interests -> topic interests -> user) and hierarchical matching.
+    PARITY UNPINNED: the reference holds no implementation of this model (model/tanr.py is empty); the numbers are checked
+    against oracle/segpool_oracle.py only (tests/test_hip_hierec.py)."""
+    from pytorch_news_recommender_amd.model.hierec_hip import Model as HieRec
+    n_sub, n_top = 285 + 1, 18 + 1                    # MIND-large: 18 categories, 285 sub-categories (+ the padding id)
+    shape = synth.Shape(n_words=synth.BENCH.n_words, word_embed_size=300, num_attention_heads=10, query_vector_dim=200, batch_size=B,
+                        history_len=50, n_candidates=5, n_words_title=30)
+    cfg = Config("hierec")
+    cfg.__nrms__()
+    cfg.dropout, cfg.learning_rate, cfg.precision = 0.2, 1e-3, "fp16"
+    cfg.subcategory_nums, cfg.category_nums = n_sub, n_top
+    params = synth.make_params_hierec(shape, n_sub, n_top, seed=0)
+    m = HieRec(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev).train()
+    batch = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.make_batch_hierec(shape, n_sub, n_top, seed=1, batch_size=B).items()}
+    for _ in range(10):
+        m.train_step(batch)
+    n = 30
+    t = timed(lambda: m.train_step(batch), n)
+    eng = m.engine
+    eng.timing(True)
+    eng.timing_reset()
+    k = 5
+    for _ in range(k):
+        m.train_step(batch)
+    torch.cuda.synchronize()
+    parts = {}
+    for name in ("hier_tree", "hier_match", "hier_addemb", "hier_embgrad", "hier_score_fwd", "hier_score_bwd", "segpool_logit",
+                 "segpool_fwd", "segpool_da", "segpool_dq", "segpool_scatter", "segpool_proj_fwd", "segpool_dwadd", "segpool_dx"):
+        ms, cnt = eng.timing_read(name)
+        parts[name] = round(ms / k, 4)
+    eng.timing(False)
+    tree_ms = sum(parts.values())
+    return {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n, "precision": "fp16 news encoder, bf16x3 aggregates",
+            "interest_tree_kernels_ms_per_step": parts, "interest_tree_ms_per_step": round(tree_ms, 4),
+            "parity": "UNPINNED: no reference implementation (model/tanr.py is empty); checked against oracle/segpool_oracle.py",
+            "workload": "B=%d, H=50, C=5, title 30 words, d=300, 285 sub-topics / 18 topics (MIND-large), dropout 0.2" % B}
+
+
 def v1_leg(dev, B):
     """SURVEY a-3' / f-3: one nrms_v1 train step (model/nrms_v1.py: W_O, per-encoder heads, candidate mask; like the
     reference's forward, nrms_v1.py:286, the model applies no attention mask -- the masked primitives are tested apart) with
@@ -720,9 +763,9 @@ def main():
         except Exception as e:
             modes["error"] = repr(e)
         out["modes"] = modes
-        log("secondary legs: variants (nrms_naml, nrms_v1)")
+        log("secondary legs: variants (nrms_naml, nrms_v1, hierec)")
         try:
-            out["variants"] = {"nrms_naml": naml_leg(dev, B), "nrms_v1": v1_leg(dev, B)}
+            out["variants"] = {"nrms_naml": naml_leg(dev, B), "nrms_v1": v1_leg(dev, B), "hierec": hierec_leg(dev, B)}
         except Exception as e:       # secondary leg only
             out["variants"] = {"error": repr(e)}
         log("secondary legs: evaluation path")

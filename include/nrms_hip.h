@@ -360,11 +360,13 @@ int nrms_hier_tree_build(int32_t B, int32_t H, const uint8_t* valid, const int64
                          int32_t* l2_ptr, int32_t* l2_idx, int32_t* l2_top, int32_t* l2_cnt, int32_t* l3_ptr,
                          int32_t* l3_idx, int32_t* n_valid, void* scratch, size_t scratch_bytes, void* stream);
 /* interest of an occupied slot = its aggregate + the embedding of its (sub-)topic: u[slot] += table[id[slot]] where cnt[slot] > 0;
- * backward: dtable[r] += sum of du over the occupied slots with id == r, in ascending slot order (no atomics). */
+ * backward: dtable[r] += sum of du over the occupied slots with id == r, in a fixed order (per-chunk partial sums in `workspace`,
+ * then the chunks in ascending order; no atomics). */
 int nrms_hier_add_embedding_fwd(int64_t n_slots, int32_t d, const int32_t* id, const int32_t* cnt, const float* table, float* u,
                                 void* stream);
+size_t nrms_hier_add_embedding_bwd_workspace_bytes(int64_t n_slots, int32_t d, int32_t n_ids);
 int nrms_hier_add_embedding_bwd(int64_t n_slots, int32_t d, int32_t n_ids, const int32_t* id, const int32_t* cnt,
-                                const float* du, float* dtable, void* stream);
+                                const float* du, float* dtable, void* workspace, size_t workspace_bytes, void* stream);
 /* Hierarchical matching.  nrms_hier_match: for candidate (b, c) the user's sub-topic / topic group slot with the candidate's ids
  * (-1: the user never clicked there) and the share of the user's clicks in it.  nrms_hier_score_fwd:
  *   score = l_s f_s <n, u1[sub_slot]> + l_t f_t <n, u2[top_slot]> + (1 - l_s - l_t) <n, ug[b]>,  masked slots -1e9.

@@ -184,14 +184,17 @@ __global__ __launch_bounds__(256) void hier_addemb_kernel(long n_slots, int d4, 
     }
 }
 
-// dtable[r][:] += sum over the occupied slots with id == r of du[slot][:], slots in ascending order (no atomics): one workgroup
-// per table row; a wave scans 64 slots at a time by ballot
-__global__ __launch_bounds__(256) void hier_embgrad_kernel(long n_slots, int d, const int* id, const int* cnt, const float* du, float* dtable) {
+// dtable[r][:] += sum over the occupied slots with id == r of du[slot][:], in a fixed order (no atomics), two kernels:
+//   partial[c][r][:] = the sum over the slots of chunk c, ascending (one workgroup per (row, chunk); a wave scans 64 slots by ballot)
+//   dtable[r][:]    += sum over c ascending of partial[c][r][:]
+__global__ __launch_bounds__(256) void hier_embgrad_kernel(long n_slots, long chunk, int d, const int* id, const int* cnt, const float* du, float* partial) {
     const int r = blockIdx.x;
+    const long c0 = (long)blockIdx.y * chunk;
+    const long c1 = c0 + chunk < n_slots ? c0 + chunk : n_slots;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};            // columns threadIdx.x + 256 j  (d <= 1024)
-    for (long s0 = 0; s0 < n_slots; s0 += 64) {
+    for (long s0 = c0; s0 < c1; s0 += 64) {
         const long s = s0 + (threadIdx.x & 63);
-        const bool hit = s < n_slots && cnt[s] > 0 && id[s] == r;
+        const bool hit = s < c1 && cnt[s] > 0 && id[s] == r;
         unsigned long long m = __ballot(hit);        // (the same in every wave: all waves read the same 64 slots)
         while (m != 0ull) {
             const int k = __ffsll((long long)m) - 1;
@@ -201,8 +204,25 @@ __global__ __launch_bounds__(256) void hier_embgrad_kernel(long n_slots, int d, 
             m &= m - 1ull;
         }
     }
+    float* out = partial + ((long)blockIdx.y * gridDim.x + r) * d;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = threadIdx.x + 256 * j; if (c < d) dtable[(long)r * d + c] += acc[j]; }
+    for (int j = 0; j < 4; ++j) { const int c = threadIdx.x + 256 * j; if (c < d) out[c] = acc[j]; }
+}
+
+__global__ __launch_bounds__(256) void hier_embgrad_reduce_kernel(long n_elems, int n_chunks, const float* partial, float* dtable) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_elems) return;
+    float acc = 0.f;
+    for (int c = 0; c < n_chunks; ++c) acc += partial[(long)c * n_elems + i];
+    dtable[i] += acc;
+}
+
+static int embgrad_chunks(long n_slots, int n_ids) {
+    long c = 8192 / (n_ids > 0 ? n_ids : 1);
+    c = c < 8 ? 8 : (c > 128 ? 128 : c);
+    const long most = (n_slots + 63) / 64;           // at least 64 slots per chunk
+    if (c > most) c = most > 0 ? most : 1;
+    return (int)c;
 }
 
 // candidate (b, c) -> the user's sub-topic / topic group slot it falls into (-1: none) and the share of the user's clicks there
@@ -332,14 +352,25 @@ extern "C" int nrms_hier_add_embedding_fwd(int64_t n_slots, int32_t d, const int
     return check_launch("hier_add_embedding_fwd");
 }
 
+extern "C" size_t nrms_hier_add_embedding_bwd_workspace_bytes(int64_t n_slots, int32_t d, int32_t n_ids) {
+    if (n_slots <= 0 || d <= 0 || n_ids <= 0) return 0;
+    return (size_t)embgrad_chunks(n_slots, n_ids) * n_ids * d * sizeof(float);
+}
+
 extern "C" int nrms_hier_add_embedding_bwd(int64_t n_slots, int32_t d, int32_t n_ids, const int32_t* id, const int32_t* cnt,
-                                           const float* du, float* dtable, void* stream) {
-    NRMS_REQUIRE(n_slots >= 0 && d > 0 && d <= 1024 && n_ids > 0, "hier_add_embedding_bwd: n_slots=%ld d=%d n_ids=%d", (long)n_slots, d, n_ids);
+                                           const float* du, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+    NRMS_REQUIRE(n_slots >= 0 && d > 0 && d <= 1024 && n_ids > 0 && n_ids <= 65535, "hier_add_embedding_bwd: n_slots=%ld d=%d n_ids=%d", (long)n_slots, d, n_ids);
     if (n_slots == 0) return NRMS_OK;
     NRMS_REQUIRE(id && cnt && du && dtable, "hier_add_embedding_bwd: null argument");
+    const int nc = embgrad_chunks(n_slots, n_ids);
+    const size_t need = (size_t)nc * n_ids * d * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) { set_error("hier_add_embedding_bwd: workspace %zu < required %zu bytes", workspace_bytes, need); return NRMS_EWORKSPACE; }
+    const long chunk = ((n_slots + nc - 1) / nc + 63) / 64 * 64;
     hipStream_t s = (hipStream_t)stream;
     TimingScope ts("hier_embgrad", s);
-    hipLaunchKernelGGL(hier_embgrad_kernel, dim3(n_ids), dim3(256), 0, s, (long)n_slots, d, id, cnt, du, dtable);
+    hipLaunchKernelGGL(hier_embgrad_kernel, dim3(n_ids, nc), dim3(256), 0, s, (long)n_slots, chunk, d, id, cnt, du, (float*)workspace);
+    const long ne = (long)n_ids * d;
+    hipLaunchKernelGGL(hier_embgrad_reduce_kernel, dim3(cdiv(ne, 256)), dim3(256), 0, s, ne, nc, (const float*)workspace, dtable);
     return check_launch("hier_add_embedding_bwd");
 }
 

@@ -180,15 +180,26 @@ __global__ __launch_bounds__(64 * SEG_WPB) void seg_scatter_kernel(long n_seg, i
     }
 }
 
-// partial[b][n] = sum over the 256 rows of block b of da[r] T[r][n]   (then launch_colsum_add: fixed order)
-constexpr int SEGQ_ROWS = 256;
+// partial[b][n] = sum over the 64 rows of block b of da[r] T[r][n]   (then launch_colsum_add: fixed order)
+constexpr int SEGQ_ROWS = 64;
 __global__ __launch_bounds__(256) void seg_dq_kernel(long n_rows, int q, const float* da, const float* T, float* partial) {
+    __shared__ float sda[SEGQ_ROWS];
     const long r0 = (long)blockIdx.x * SEGQ_ROWS;
-    const long r1 = r0 + SEGQ_ROWS < n_rows ? r0 + SEGQ_ROWS : n_rows;
+    const int nr = (int)(r0 + SEGQ_ROWS < n_rows ? SEGQ_ROWS : n_rows - r0);
+    if (threadIdx.x < SEGQ_ROWS) sda[threadIdx.x] = threadIdx.x < nr ? da[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
     for (int n = threadIdx.x; n < q; n += 256) {
-        float acc = 0.f;
-        for (long r = r0; r < r1; ++r) acc += da[r] * T[r * q + n];
-        partial[(long)blockIdx.x * q + n] = acc;
+        const float* t = T + r0 * q + n;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = 0;
+        for (; r + 4 <= nr; r += 4) {
+            a0 += sda[r] * t[(long)r * q];
+            a1 += sda[r + 1] * t[(long)(r + 1) * q];
+            a2 += sda[r + 2] * t[(long)(r + 2) * q];
+            a3 += sda[r + 3] * t[(long)(r + 3) * q];
+        }
+        for (; r < nr; ++r) a0 += sda[r] * t[(long)r * q];
+        partial[(long)blockIdx.x * q + n] = (a0 + a1) + (a2 + a3);
     }
 }
 

@@ -201,12 +201,16 @@ class HieRecEngine(NRMSEngine):
             return pools[i].backward(f(lv + ".linear.weight"), f(lv + ".attention_query_vector"), dout, g(lv + ".linear.weight"),
                                      g(lv + ".linear.bias"), g(lv + ".attention_query_vector"))
 
+        eb = max(int(self.lib.nrms_hier_add_embedding_bwd_workspace_bytes(C.c_int64(n), d, k)) for k in (self.n_top, self.n_sub))
+        ews = self._buf("hier_embgrad_ws", (eb + 3) // 4 + 1)
         du2 += level(2, dug)                                   # user level -> topic interests
         _lib.check(self.lib.nrms_hier_add_embedding_bwd(C.c_int64(n), d, self.n_top, _lib.ptr(t["l2_top"]), _lib.ptr(t["l2_cnt"]), _lib.ptr(du2),
-                                                        _lib.ptr(g("topic_embedding.weight")), _stream()), "add_embedding_bwd")
+                                                        _lib.ptr(g("topic_embedding.weight")), _lib.ptr(ews), C.c_size_t(ews.numel() * 4),
+                                                        _stream()), "add_embedding_bwd")
         du1 += level(1, du2)                                   # topic level -> sub-topic interests
         _lib.check(self.lib.nrms_hier_add_embedding_bwd(C.c_int64(n), d, self.n_sub, _lib.ptr(t["l1_sub"]), _lib.ptr(t["l1_cnt"]), _lib.ptr(du1),
-                                                        _lib.ptr(g("subtopic_embedding.weight")), _stream()), "add_embedding_bwd")
+                                                        _lib.ptr(g("subtopic_embedding.weight")), _lib.ptr(ews), C.c_size_t(ews.numel() * 4),
+                                                        _stream()), "add_embedding_bwd")
         dnv[:n].copy_(level(0, du1))                           # sub-topic level -> news vectors of the history
         # ---- news encoder (the NRMS engine's own backward, model/nrms_v0.py:154-176)
         desc_n = self._desc("news_encoder", N, L, sv["p"], sv["p"], sv["seed"], training=True)

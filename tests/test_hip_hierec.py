@@ -172,7 +172,8 @@ def test_scores_and_every_gradient_against_the_oracle(case, precision):
             ref[0] = 0
             g[0] = 0
         rel = 2e-2 if fp16 else 1e-3
-        bound = rel * np.abs(ref) + (rel * 0.5) * float(np.abs(ref).max()) + 2e-6 * gscale + 1e-9
+        # (d(W_K.bias) is identically zero in exact arithmetic -- softmax is shift-invariant -- so its bound is the noise term)
+        bound = rel * np.abs(ref) + (rel * 0.5) * float(np.abs(ref).max()) + (1e-4 if fp16 else 2e-6) * gscale + 1e-9
         bad = float((np.abs(g - ref) - bound).max())
         print("      %-58s err %.2e  scale %.2e" % (n, float(np.abs(g - ref).max()), float(np.abs(ref).max())))
         assert bad <= 0.0, (case, precision, n, float(np.abs(g - ref).max()), float(np.abs(ref).max()))
