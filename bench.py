@@ -346,6 +346,48 @@ def hierec_leg(dev, B):
             "workload": "B=%d, H=50, C=5, title 30 words, d=300, 285 sub-topics / 18 topics (MIND-large), dropout 0.2" % B}
 
 
+def graph_leg(dev, B):
+    """SURVEY f-4 / BASELINE configs[4]: one train step of the user-news graph encoder (model/graph_hip.py) -- the headline's news
+    encoder over B * 55 titles (fp16 mode), then the news layer (every slot gathers up to 8 sampled neighbour news of the batch's
+    induced sub-graph and aggregates them by additive attention) and the user layer (a user's clicked slots), dot-product scores.
+    One rank's share of a data-parallel job: users and their sampled sub-graphs shard across GPUs, gradients all-reduce.
+    PARITY UNPINNED: the reference holds no graph model; checked against oracle/segpool_oracle.py (tests/test_hip_graph.py)."""
+    from pytorch_news_recommender_amd.model.graph_hip import Model as Graph
+    K = 8
+    shape = synth.Shape(n_words=synth.BENCH.n_words, word_embed_size=300, num_attention_heads=10, query_vector_dim=200, batch_size=B,
+                        history_len=50, n_candidates=5, n_words_title=30)
+    cfg = Config("graph")
+    cfg.__nrms__()
+    cfg.dropout, cfg.learning_rate, cfg.precision = 0.2, 1e-3, "fp16"
+    params = synth.make_params_graph(shape, seed=0)
+    m = Graph(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.to(dev).train()
+    batch = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.make_batch_graph(shape, K, seed=1, batch_size=B).items()}
+    for _ in range(10):
+        m.train_step(batch)
+    n = 30
+    t = timed(lambda: m.train_step(batch), n)
+    eng = m.engine
+    eng.timing(True)
+    eng.timing_reset()
+    k = 5
+    for _ in range(k):
+        m.train_step(batch)
+    torch.cuda.synchronize()
+    parts = {}
+    for name in ("csr_build", "segpool_logit", "segpool_fwd", "segpool_da", "segpool_dq", "segpool_scatter", "segpool_proj_fwd", "segpool_dwadd",
+                 "segpool_dx"):
+        ms, cnt = eng.timing_read(name)
+        parts[name] = round(ms / k, 4)
+    eng.timing(False)
+    nnz = int(((batch["neighbor_rows"] >= 0).sum() + batch["browsed_mask"].sum()).item())
+    return {"users_per_s": B * n / t, "ms_per_step": t / n * 1e3, "steps": n, "precision": "fp16 news encoder, bf16x3 aggregates",
+            "aggregation_kernels_ms_per_step": parts, "aggregation_ms_per_step": round(sum(parts.values()), 4), "list_entries": nnz,
+            "parity": "UNPINNED: no reference implementation; checked against oracle/segpool_oracle.py",
+            "workload": "B=%d, H=50, C=5, title 30 words, d=300, up to %d sampled neighbours per news slot (induced sub-graph), dropout 0.2" % (B, K)}
+
+
 def v1_leg(dev, B):
     """SURVEY a-3' / f-3: one nrms_v1 train step (model/nrms_v1.py: W_O, per-encoder heads, candidate mask; like the
     reference's forward, nrms_v1.py:286, the model applies no attention mask -- the masked primitives are tested apart) with
@@ -763,9 +805,9 @@ def main():
         except Exception as e:
             modes["error"] = repr(e)
         out["modes"] = modes
-        log("secondary legs: variants (nrms_naml, nrms_v1, hierec)")
+        log("secondary legs: variants (nrms_naml, nrms_v1, hierec, graph)")
         try:
-            out["variants"] = {"nrms_naml": naml_leg(dev, B), "nrms_v1": v1_leg(dev, B), "hierec": hierec_leg(dev, B)}
+            out["variants"] = {"nrms_naml": naml_leg(dev, B), "nrms_v1": v1_leg(dev, B), "hierec": hierec_leg(dev, B), "graph": graph_leg(dev, B)}
         except Exception as e:       # secondary leg only
             out["variants"] = {"error": repr(e)}
         log("secondary legs: evaluation path")

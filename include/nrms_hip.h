@@ -344,6 +344,13 @@ int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float* x, const f
                           float* dx, float* dw_add, float* db_add, float* dq_vec, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* Index lists from padded neighbour lists (a sampled sub-graph as [n_seg, K] int64 with -1 for "no neighbour"): entries inside
+ * [0, n_rows) are kept in their order.  seg_ptr [n_seg + 1], idx [capacity n_seg * K]; pass nnz = n_seg * K (a capacity) in the
+ * nrms_segpool_desc -- the lists' real length is seg_ptr[n_seg], on the device.  Without NRMS_SEGPOOL_ROWS_UNIQUE (a row listed
+ * by several segments, as in a graph) the backward adds a row's contributions with float atomics: results are reproducible to
+ * rounding only. */
+int nrms_csr_from_padded(int64_t n_seg, int32_t K, const int64_t* lists, int64_t n_rows, int32_t* seg_ptr, int32_t* idx, void* stream);
+
 /* ---- Index side of a HieRec-style hierarchical interest model (BASELINE configs[3]; SURVEY f-4; PARITY UNPINNED: no reference
  * implementation, checked against oracle/segpool_oracle.py).  A user's clicked news (H <= 64 history slots, `valid` = the
  * batch dict's browsed_mask) are grouped by sub-topic id, the sub-topic groups by topic id, in order of first occurrence; every

@@ -100,6 +100,7 @@ SIGNATURES = {
     "nrms_hier_tree_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "nrms_hier_tree_build": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 16 + [C.c_size_t, C.c_void_p]),
     "nrms_hier_add_embedding_fwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrms_csr_from_padded": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_hier_add_embedding_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "nrms_hier_add_embedding_bwd": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_size_t, C.c_void_p]),

@@ -203,6 +203,44 @@ __global__ __launch_bounds__(256) void seg_dq_kernel(long n_rows, int q, const f
     }
 }
 
+// ---- index lists from padded neighbour lists: lists [n_seg, K] int64, an entry outside [0, n_rows) = no neighbour (e.g. -1)
+//      -> seg_ptr [n_seg + 1], idx (a list's live entries in their order).  Three launches: count -> one-workgroup scan -> emit.
+__global__ __launch_bounds__(256) void csr_count_kernel(long n_seg, int K, const int64_t* lists, long n_rows, int* seg_ptr) {
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) seg_ptr[0] = 0;
+    if (s >= n_seg) return;
+    int c = 0;
+    for (int k = 0; k < K; ++k) { const int64_t v = lists[s * K + k]; c += (v >= 0 && v < n_rows) ? 1 : 0; }
+    seg_ptr[s + 1] = c;
+}
+
+// in-place inclusive scan of p[1 .. n]: thread t owns the contiguous chunk [t * chunk, (t + 1) * chunk)
+__global__ __launch_bounds__(1024) void csr_scan_kernel(long n, int* p) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const long chunk = (n + 1023) / 1024;
+    const long i0 = 1 + t * chunk, i1 = (i0 + chunk < n + 1) ? i0 + chunk : n + 1;
+    int sum = 0;
+    for (long i = i0; i < i1; ++i) sum += p[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                     // Hillis-Steele over the 1024 chunk sums
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;                                 // exclusive prefix of this chunk
+    for (long i = i0; i < i1; ++i) { run += p[i]; p[i] = run; }
+}
+
+__global__ __launch_bounds__(256) void csr_emit_kernel(long n_seg, int K, const int64_t* lists, long n_rows, const int* seg_ptr, int* idx) {
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_seg) return;
+    int o = seg_ptr[s];
+    for (int k = 0; k < K; ++k) { const int64_t v = lists[s * K + k]; if (v >= 0 && v < n_rows) idx[o++] = (int)v; }
+}
+
 struct SegWs { size_t wplanes, da, dal, wadd_t, tn_partial, dq_partial, total; };
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 static SegWs seg_layout(const nrms_segpool_desc* d) {
@@ -347,4 +385,20 @@ extern "C" int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float*
         rc = check_launch("segpool_scatter");
     }
     return rc;
+}
+
+extern "C" int nrms_csr_from_padded(int64_t n_seg, int32_t K, const int64_t* lists, int64_t n_rows, int32_t* seg_ptr, int32_t* idx,
+                                    void* stream) {
+    NRMS_REQUIRE(n_seg >= 0 && K > 0 && n_rows >= 0 && n_rows < (1L << 31) && n_seg * (long)K < (1L << 31),
+                 "csr_from_padded: n_seg=%ld K=%d n_rows=%ld", (long)n_seg, K, (long)n_rows);
+    NRMS_REQUIRE(seg_ptr != nullptr, "csr_from_padded: null seg_ptr");
+    NRMS_REQUIRE(n_seg == 0 || (lists && idx), "csr_from_padded: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    TimingScope ts("csr_build", s);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(cdiv(n_seg > 0 ? n_seg : 1, 256)), dim3(256), 0, s, (long)n_seg, K, lists, (long)n_rows, seg_ptr);
+    if (n_seg > 0) {
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, (long)n_seg, seg_ptr);
+        hipLaunchKernelGGL(csr_emit_kernel, dim3(cdiv(n_seg, 256)), dim3(256), 0, s, (long)n_seg, K, lists, (long)n_rows, seg_ptr, idx);
+    }
+    return check_launch("csr_from_padded");
 }

@@ -7,7 +7,7 @@ from importlib import import_module
 import torch
 import torch.nn as nn
 
-ALIASES = {"nrms_v0": "nrms_hip", "nrms": "nrms_hip", "nrms_v1": "nrms_v1_hip", "nrms_naml": "nrms_naml_hip", "hierec": "hierec_hip"}
+ALIASES = {"nrms_v0": "nrms_hip", "nrms": "nrms_hip", "nrms_v1": "nrms_v1_hip", "nrms_naml": "nrms_naml_hip", "hierec": "hierec_hip", "gnn": "graph_hip", "graph": "graph_hip"}
 
 
 class Model(nn.Module):

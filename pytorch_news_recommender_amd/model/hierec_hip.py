@@ -24,7 +24,6 @@ from __future__ import annotations
 
 import ctypes as C
 
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -32,49 +31,18 @@ from .. import _lib
 from ..engine import ModelDims, NRMSEngine, _stream
 from ..segpool import SegmentPool
 from . import nrms_hip
+from ._flat_model import AdditiveParams, FlatHipModel, FlatLayout2, additive_entries
 
 LEVELS = ("subtopic_attention", "topic_attention", "user_attention")
 
 
-class HierLayout:
-    """Flat parameter buffer: [ table | news encoder (nrms_v0 names) | E_sub | E_top | three additive-attention modules ]."""
-
-    def __init__(self, dims: ModelDims, n_sub: int, n_top: int):
-        V, d, q = dims.n_words, dims.word_embed_size, dims.query_vector_dim
-        self.dims = dims
-        self.entries, self.blocks = {}, {"news_encoder": {}}
-        off = 0
-
-        def add(name, shape, enc=None, role=None):
-            nonlocal off
-            n = int(np.prod(shape))
-            self.entries[name] = (off, tuple(shape), n)
-            if enc is not None:
-                self.blocks[enc][role] = off
-            off += n
-
-        a = "news_encoder.multihead_self_attention."
-        add("news_encoder.word_embedding.0.weight", (V, d), "news_encoder", "table")
-        for nm, r in zip(("W_Q", "W_K", "W_V"), ("wq", "wk", "wv")):
-            add(a + nm + ".weight", (d, d), "news_encoder", r)
-        for nm, r in zip(("W_Q", "W_K", "W_V"), ("bq", "bk", "bv")):
-            add(a + nm + ".bias", (d,), "news_encoder", r)
-        add("news_encoder.additive_attention.linear.weight", (q, d), "news_encoder", "wa")
-        add("news_encoder.additive_attention.linear.bias", (q,), "news_encoder", "ba")
-        add("news_encoder.additive_attention.attention_query_vector", (q,), "news_encoder", "qv")
-        add("subtopic_embedding.weight", (n_sub, d))
-        add("topic_embedding.weight", (n_top, d))
-        for lv in LEVELS:
-            add(lv + ".linear.weight", (q, d))
-            add(lv + ".linear.bias", (q,))
-            add(lv + ".attention_query_vector", (q,))
-        self.total = off
-        self.names = list(self.entries)
-        self.table = 0
-
-    def view(self, flat, name):
-        off, shp, n = self.entries[name]
-        return flat[off:off + n].view(shp)
+def hier_layout(dims: ModelDims, n_sub: int, n_top: int):
+    """[ table | news encoder (nrms_v0 names) | E_sub | E_top | three additive-attention modules ]"""
+    d, q = dims.word_embed_size, dims.query_vector_dim
+    extra = [("subtopic_embedding.weight", (n_sub, d)), ("topic_embedding.weight", (n_top, d))]
+    for lv in LEVELS:
+        extra += additive_entries(lv, q, d)
+    return FlatLayout2(dims, extra)
 
 
 class HieRecEngine(NRMSEngine):
@@ -226,39 +194,11 @@ class HieRecEngine(NRMSEngine):
             table_grad_ready()
 
 
-class _AdditiveParams(nn.Module):
-    def __init__(self, q, d):
-        super().__init__()
-        self.linear = nn.Linear(d, q)
-        self.attention_query_vector = nn.Parameter(torch.empty(q).uniform_(-0.1, 0.1))
-
-
-class _HierFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, model, batch, p_drop, seed, *params):
-        ctx.model = model
-        scores = model._engine.forward(model._flat, batch, training=True, p_drop=p_drop, seed=seed)
-        ctx.gen = model._engine._saved["gen"]
-        return scores
-
-    @staticmethod
-    def backward(ctx, dscores):
-        model = ctx.model
-        gflat = torch.zeros_like(model._flat)
-        model._engine.backward(model._flat, gflat, dscores, gen=ctx.gen)
-        if model._engine.precision == "fp16":
-            model._engine.grad_guard(gflat)
-            model._engine.note_grad_check()
-        return (None, None, None, None) + tuple(model._layout.view(gflat, n) for n in model._names)
-
-
-KEYS = ("browsed_titles", "browsed_categ_ids", "browsed_subcateg_ids", "browsed_mask", "candidate_titles", "candidate_categ_ids",
-        "candidate_subcateg_ids", "candidate_mask")
-
-
-class Model(nn.Module):
+class Model(FlatHipModel):
     """HieRec-style hierarchical interest model: ``Model(config)``, ``forward(batch) -> scores [B, C]`` (the reference's plugin
     contract, ``model/__init__.py:22-23,38``)."""
+    KEYS = ("browsed_titles", "browsed_categ_ids", "browsed_subcateg_ids", "browsed_mask", "candidate_titles", "candidate_categ_ids",
+            "candidate_subcateg_ids", "candidate_mask")
 
     def __init__(self, config, pretrained_word_embedding=None):
         super().__init__()
@@ -269,98 +209,17 @@ class Model(nn.Module):
         self.news_encoder = nrms_hip._NewsEncoderParams(config, table)
         self.subtopic_embedding = nn.Embedding(int(config.subcategory_nums), d, padding_idx=0)
         self.topic_embedding = nn.Embedding(int(config.category_nums), d, padding_idx=0)
-        self.subtopic_attention = _AdditiveParams(q, d)
-        self.topic_attention = _AdditiveParams(q, d)
-        self.user_attention = _AdditiveParams(q, d)
+        self.subtopic_attention = AdditiveParams(q, d)
+        self.topic_attention = AdditiveParams(q, d)
+        self.user_attention = AdditiveParams(q, d)
         self._dims = ModelDims(n_words=int(V), word_embed_size=int(d), num_attention_heads=int(config.num_attention_heads), query_vector_dim=q)
-        self._layout = HierLayout(self._dims, int(config.subcategory_nums), int(config.category_nums))
-        self._names = self._layout.names
-        named = dict(self.named_parameters())
-        assert sorted(named) == sorted(self._names), (sorted(set(named) ^ set(self._names)))
-        self._flat = self._engine = self._opt = None
-        self._pad_zero = None
-        self._calls = 0
-        self._flatten(table.device)
+        self._finish(hier_layout(self._dims, int(config.subcategory_nums), int(config.category_nums)), table.device)
 
-    def _flatten(self, device):
-        named = dict(self.named_parameters())
-        flat = torch.empty(self._layout.total, dtype=torch.float32, device=device)
-        for n in self._names:
-            v = self._layout.view(flat, n)
-            v.copy_(named[n].data)
-            named[n].data = v
-        self._flat, self._opt, self._pad_zero = flat, None, None
+    def _make_engine(self, device, precision):
+        return HieRecEngine(self._dims, self._layout, device, precision, self.config.subcategory_nums, self.config.category_nums,
+                            getattr(self.config, "hierec_lambda_sub", 0.7), getattr(self.config, "hierec_lambda_top", 0.15))
 
-    def _prepare(self):
-        dev = next(self.parameters()).device
-        named = dict(self.named_parameters())
-        base = self._flat.data_ptr()
-        if any(named[n].data_ptr() != base + 4 * self._layout.entries[n][0] or named[n].device != self._flat.device for n in self._names):
-            self._flatten(dev)
-        if self._flat.device.type != "cuda":
-            raise _lib.NrmsError("HieRec HIP model parameters are on %s: move the model to a GPU (there is no CPU fallback)" % self._flat.device)
-        prec = getattr(self.config, "precision", "fp32")
-        if self._engine is None or self._engine.device != self._flat.device:
-            self._engine = HieRecEngine(self._dims, self._layout, self._flat.device, prec, self.config.subcategory_nums, self.config.category_nums,
-                                        getattr(self.config, "hierec_lambda_sub", 0.7), getattr(self.config, "hierec_lambda_top", 0.15))
-        elif self._engine.precision != prec:
-            self._engine.set_precision(prec)
-        if self._pad_zero is None:
-            self._pad_zero = bool((self._layout.view(self._flat, "news_encoder.word_embedding.0.weight")[0] == 0).all().item())
-        self._engine.fp16_inference = bool(getattr(self.config, "fp16_inference", False))
-        self._engine.pad_row_zero = self._pad_zero and bool(getattr(self.config, "skip_padding_tokens", True))
-        return self._flat.device
-
-    def _next_seed(self):
-        self._calls += 1
-        return (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
-
-    def _device_batch(self, batch, dev):
-        out = {}
-        for k in KEYS:
-            v = batch.get(k) if hasattr(batch, "get") else batch[k]
-            if v is None:
-                if k == "candidate_mask":
-                    continue
-                raise KeyError("hierec: the batch dict lacks %r" % k)
-            out[k] = torch.as_tensor(v).to(dev, non_blocking=True)
-        return out
-
-    def forward(self, batch):
-        dev = self._prepare()
-        b = self._device_batch(batch, dev)
-        p_drop = float(self.config.dropout) if self.training else 0.0
-        seed = self._next_seed() if p_drop > 0 else 0
-        params = [dict(self.named_parameters())[n] for n in self._names]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _HierFunction.apply(self, b, p_drop, seed, *params)
-        return self._engine.forward(self._flat, b, training=False, p_drop=p_drop, seed=seed)
-
-    def train_step(self, batch, lr=None, betas=(0.9, 0.999), eps=1e-8):
-        """forward + CE(label 0) + backward + Adam on flat buffers (the build's own loop; same math as train_eval.py:111-127).
-        Returns the loss SUM over the batch as a device scalar."""
-        dev = self._prepare()
-        eng = self._engine
-        b = self._device_batch(batch, dev)
-        if self._opt is None:
-            self._opt = dict(step=0, g=torch.zeros_like(self._flat), m=torch.zeros_like(self._flat), v=torch.zeros_like(self._flat))
-        st = self._opt
-        p_drop = float(self.config.dropout) if self.training else 0.0
-        seed = self._next_seed() if p_drop > 0 else 0
-        scores = eng.forward(self._flat, b, training=True, p_drop=p_drop, seed=seed)
-        loss_sum, dscores = eng.ce_loss(scores, grad_scale=1.0 / scores.shape[0])
-        st["g"].zero_()
-        eng.backward(self._flat, st["g"], dscores)
+    def _zero_frozen_rows(self, gflat):
         # padding_idx = 0 of the two embedding tables: row 0 takes no gradient (nn.Embedding semantics)
-        self._layout.view(st["g"], "subtopic_embedding.weight")[0].zero_()
-        self._layout.view(st["g"], "topic_embedding.weight")[0].zero_()
-        st["step"] += 1
-        eng.adam_step(self._flat, st["g"], st["m"], st["v"], st["step"], lr=float(self.config.learning_rate if lr is None else lr), betas=betas, eps=eps)
-        if eng.precision == "fp16":
-            eng.note_grad_check()
-        return loss_sum
-
-    @property
-    def engine(self):
-        self._prepare()
-        return self._engine
+        self._layout.view(gflat, "subtopic_embedding.weight")[0].zero_()
+        self._layout.view(gflat, "topic_embedding.weight")[0].zero_()

@@ -382,3 +382,39 @@ def make_batch_hierec(shape: Shape, n_sub: int = 294, n_top: int = 19, seed: int
     b["browsed_categ_ids"] = np.where(valid, btp, 0)
     b["candidate_subcateg_ids"], b["candidate_categ_ids"] = cs, ctp
     return b
+
+
+# ---- user-news graph encoder (model/graph_hip.py; BASELINE configs[4]; parity unpinned) ---------------------------------------
+def make_params_graph(shape: Shape, seed: int = 0):
+    """The NRMS news encoder's parameters (make_params) + the two aggregators' additive attentions."""
+    base = make_params(shape, seed=seed)
+    out = {k: v for k, v in base.items() if k.startswith("news_encoder.")}
+    rng = np.random.default_rng(seed + 2000)
+    d, q = shape.word_embed_size, shape.query_vector_dim
+    for lv in ("neighbor_attention", "user_attention"):
+        a = np.sqrt(6.0 / (d + q))
+        out[lv + ".linear.weight"] = rng.uniform(-a, a, size=(q, d)).astype(np.float32)
+        out[lv + ".linear.bias"] = rng.uniform(-1, 1, size=(q,)).astype(np.float32) / np.float32(np.sqrt(d))
+        out[lv + ".attention_query_vector"] = rng.uniform(-0.1, 0.1, size=(q,)).astype(np.float32)
+    return out
+
+
+def make_batch_graph(shape: Shape, n_neighbors: int = 8, seed: int = 1, batch_size: int | None = None, empty_history_user: bool = False,
+                     mask_some_candidates: bool = False, zipf: float = 1.1):
+    """make_batch + ``neighbor_rows`` [B * (H + C), K]: a sampled sub-graph induced on the batch's own news slots.  A slot has
+    0 .. K neighbours (a prefix of its row, -1 after it), drawn with a Zipf-like skew over the slots (a few popular news are
+    everybody's neighbour, as in a click graph); one row carries an out-of-range entry in the middle of its list."""
+    b = make_batch(shape, seed=seed, batch_size=batch_size, empty_history_user=empty_history_user, mask_some_candidates=mask_some_candidates)
+    rng = np.random.default_rng(seed + 99)
+    B, H = b["browsed_titles"].shape[:2]
+    N = B * (H + b["candidate_titles"].shape[1])
+    w = 1.0 / np.arange(1, N + 1) ** zipf
+    w /= w.sum()
+    popular = rng.permutation(N)
+    nbr = popular[rng.choice(N, size=(N, n_neighbors), p=w)].astype(np.int64)
+    cnt = rng.integers(0, n_neighbors + 1, size=(N,))
+    nbr = np.where(np.arange(n_neighbors)[None, :] < cnt[:, None], nbr, -1)
+    if N > 3 and n_neighbors > 2:
+        nbr[3, :] = [5 % N, -1] + [7 % N] * (n_neighbors - 2)
+    b["neighbor_rows"] = nbr
+    return b

@@ -1,0 +1,151 @@
+"""User-news graph encoder (model/graph_hip.py; SURVEY section 8 row f-4, BASELINE configs[4]) against oracle/segpool_oracle.py.
+PARITY UNPINNED: the reference holds no graph model (README.md:3 names Adressa, no code), so the oracle restates the
+specification in the model's docstring on top of the reference's additive attention (nrms_v0.py:100-126); these tests pin that
+the HIP path computes that specification -- index lists, scores, every gradient, one Adam step with a gradient all-reduce hook."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_news_recommender_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_graph(shape, params, precision="fp32", device="cuda"):
+    from pytorch_news_recommender_amd.config import Config
+    from pytorch_news_recommender_amd.model.graph_hip import Model
+    cfg = Config("graph")
+    cfg.__nrms__()
+    cfg.word_embed_size, cfg.num_attention_heads, cfg.query_vector_dim = shape.word_embed_size, shape.num_attention_heads, shape.query_vector_dim
+    cfg.dropout, cfg.precision = 0.0, precision
+    m = Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    return m.to(device)
+
+
+def tbatch(batch):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("n_seg,K,n_rows", [(1, 1, 1), (7, 3, 5), (1000, 8, 1000), (70001, 5, 300), (0, 4, 10)])
+def test_index_lists_from_padded_neighbour_lists(n_seg, K, n_rows):
+    lib = _lib.load()
+    rng = np.random.default_rng(n_seg + K)
+    lists = rng.integers(-2, n_rows + 2, size=(n_seg, K), dtype=np.int64)          # entries outside [0, n_rows): no neighbour
+    dl = torch.from_numpy(lists).cuda()
+    ptr = torch.full((n_seg + 1,), -9, dtype=torch.int32, device="cuda")
+    idx = torch.full((max(n_seg * K, 1),), -9, dtype=torch.int32, device="cuda")
+    _lib.check(lib.nrms_csr_from_padded(C.c_int64(n_seg), K, _lib.ptr(dl), C.c_int64(n_rows), _lib.ptr(ptr), _lib.ptr(idx), _stream()), "csr")
+    ptr, idx = ptr.cpu().numpy(), idx.cpu().numpy()
+    ok = (lists >= 0) & (lists < n_rows)
+    want_ptr = np.concatenate([[0], np.cumsum(ok.sum(1))]).astype(np.int32)
+    assert np.array_equal(ptr, want_ptr)
+    assert np.array_equal(idx[:want_ptr[-1]], lists[ok].astype(np.int32))          # row-major order = list order
+
+
+CASES = {
+    # B, H, C, L, d, heads, q, K, kwargs of make_batch_graph
+    "small": (6, 12, 4, 8, 64, 4, 32, 5, dict()),
+    "empty_user_masked_cands": (5, 20, 5, 6, 64, 4, 32, 8, dict(empty_history_user=True, mask_some_candidates=True)),
+    "one_neighbour_h40": (3, 40, 3, 5, 40, 2, 16, 1, dict()),
+    "mind_dims": (4, 50, 5, 30, 300, 10, 200, 8, dict()),
+}
+
+
+def _setup(case):
+    B, H, Cn, L, d, h, q, K, kw = CASES[case]
+    shape = synth.Shape(n_words=200, word_embed_size=d, num_attention_heads=h, query_vector_dim=q, batch_size=B, history_len=H,
+                        n_candidates=Cn, n_words_title=L)
+    return shape, synth.make_params_graph(shape, seed=3), synth.make_batch_graph(shape, K, seed=4, **kw)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16"])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_scores_and_every_gradient_against_the_oracle(case, precision):
+    from oracle import nrms_oracle as orc
+    from oracle import segpool_oracle as so
+    shape, params, batch = _setup(case)
+    B, Cn, h = shape.batch_size, shape.n_candidates, shape.num_attention_heads
+    dscores = (np.random.default_rng(5).standard_normal((B, Cn)) * 0.1).astype(np.float32)
+    pt = orc.to_torch(params, requires_grad=True)
+    s = so.graph_forward(pt, batch, h)
+    live_t = torch.as_tensor(batch["candidate_mask"]) != 0
+    (torch.where(live_t, s, torch.zeros_like(s)) * torch.from_numpy(dscores)).sum().backward()
+    o_scores = s.detach().numpy()
+    model = make_graph(shape, params, precision=precision).train()
+    model.zero_grad()
+    scores = model(tbatch(batch))
+    scores.backward(torch.from_numpy(dscores).cuda())
+    got = scores.detach().cpu().numpy()
+    live = batch["candidate_mask"] != 0
+    assert np.all(got[~live] == np.float32(-1e9))
+    err, scale = float(np.abs(got - o_scores)[live].max()), float(np.abs(o_scores[live]).max())
+    fp16 = precision == "fp16"
+    print("graph %-24s %-6s scores err %.2e (scale %.2f)" % (case, precision, err, scale))
+    assert err <= (3e-4 if fp16 else 2e-5) * max(1.0, scale)
+    named = dict(model.named_parameters())
+    gscale = max(float(np.abs(v.grad.numpy()).max()) for k, v in pt.items() if not k.endswith("word_embedding.0.weight"))
+    for n, v in pt.items():
+        ref = v.grad.numpy()
+        g = named[n].grad.detach().cpu().numpy()
+        rel = 2e-2 if fp16 else 1e-3
+        # (d(W_K.bias) is identically zero in exact arithmetic -- softmax is shift-invariant -- so its bound is the noise term)
+        bound = rel * np.abs(ref) + (rel * 0.5) * float(np.abs(ref).max()) + (1e-4 if fp16 else 2e-6) * gscale + 1e-9
+        print("      %-58s err %.2e  scale %.2e" % (n, float(np.abs(g - ref).max()), float(np.abs(ref).max())))
+        assert float((np.abs(g - ref) - bound).max()) <= 0.0, (case, precision, n, float(np.abs(g - ref).max()), float(np.abs(ref).max()))
+    model.eval()
+    with torch.no_grad():
+        inf = model(tbatch(batch)).cpu().numpy()
+    assert float(np.abs(inf - got)[live].max()) <= (3e-4 if fp16 else 1e-6) * max(1.0, scale)
+
+
+def test_train_step_with_an_all_reduce_hook_matches_an_oracle_adam_step():
+    """One fused train step on half of the users with an all-reduce hook that adds the other half's gradient (what RCCL's sum
+    over two data-parallel ranks delivers) = one oracle Adam step on the whole batch."""
+    from oracle import nrms_oracle as orc
+    from oracle import segpool_oracle as so
+    shape, params, batch = _setup("small")
+    B, H, Cn, h = shape.batch_size, shape.history_len, shape.n_candidates, shape.num_attention_heads
+    half = B // 2
+
+    def part(lo, hi):                      # a rank's shard: its users, and their sub-graph in the shard's own row numbering
+        nb = batch["neighbor_rows"]
+        rows = np.concatenate([np.arange(lo * H, hi * H), B * H + np.arange(lo * Cn, hi * Cn)])
+        new = -np.ones(B * (H + Cn), dtype=np.int64)
+        new[rows] = np.arange(len(rows))
+        sub = nb[rows]
+        sub = np.where(sub >= 0, new[np.clip(sub, 0, None)], -1)           # neighbours outside the shard are dropped
+        out = {k: v[lo:hi] for k, v in batch.items() if k != "neighbor_rows"}
+        out["neighbor_rows"] = sub
+        return out
+
+    shards = [part(0, half), part(half, B)]
+    pt = orc.to_torch(params, requires_grad=True)
+    loss = sum(orc.loss_fn(so.graph_forward(pt, sh, h)) * sh["browsed_titles"].shape[0] for sh in shards) / B
+    loss.backward()
+    want = {}
+    for k, v in pt.items():
+        g = v.grad.numpy().copy()
+        if k.endswith("word_embedding.0.weight"):
+            g[0] = 0
+        want[k] = v.detach().numpy().copy()
+        orc.adam_step(want[k], g, np.zeros_like(g), np.zeros_like(g), 1, lr=1e-3)
+    # "rank 1": its gradient of the global mean loss, through the autograd form
+    other = make_graph(shape, params, precision="fp32").train()
+    other.zero_grad()
+    s1 = other(tbatch(shards[1]))
+    (torch.nn.functional.cross_entropy(s1, torch.zeros(len(s1), dtype=torch.long, device="cuda"), reduction="sum") / B).backward()
+    g_other = torch.cat([dict(other.named_parameters())[n].grad.reshape(-1) for n in other._names])
+    model = make_graph(shape, params, precision="fp32").train()
+    model.train_step(tbatch(shards[0]), lr=1e-3, world_size=2, global_batch=B, all_reduce=lambda g: g.add_(g_other))
+    torch.cuda.synchronize()
+    for k, v in model.named_parameters():
+        got = v.detach().cpu().numpy()
+        moved = np.abs(want[k] - params[k]) > 0.5e-3
+        assert float(np.abs(got - want[k])[moved].max(initial=0.0)) < 3e-5, k

@@ -209,7 +209,7 @@ def test_train_step_matches_an_oracle_adam_step_and_is_bit_reproducible():
         ls = model.train_step(tbatch(batch), lr=1e-3)
         torch.cuda.synchronize()
         outs.append((float(ls.item()) / B, {k: v.detach().cpu().numpy().copy() for k, v in model.named_parameters()}))
-    assert outs[0][0] == pytest.approx(float(loss), rel=1e-5)
+    assert outs[0][0] == pytest.approx(float(loss.detach()), rel=1e-5)
     assert outs[0][0] == outs[1][0]
     for k in want:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
