@@ -376,8 +376,8 @@ def graph_leg(dev, B):
         m.train_step(batch)
     torch.cuda.synchronize()
     parts = {}
-    for name in ("csr_build", "segpool_logit", "segpool_fwd", "segpool_da", "segpool_dq", "segpool_scatter", "segpool_proj_fwd", "segpool_dwadd",
-                 "segpool_dx"):
+    for name in ("csr_build", "segpool_logit", "segpool_fwd", "segpool_da", "segpool_rowlists", "segpool_dq", "segpool_scatter", "segpool_proj_fwd",
+                 "segpool_dwadd", "segpool_dx"):
         ms, cnt = eng.timing_read(name)
         parts[name] = round(ms / k, 4)
     eng.timing(False)

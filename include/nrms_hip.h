@@ -320,8 +320,9 @@ int nrms_news_features_bwd(const nrms_news_features* f, const float* dout, float
  * (neighbour gather + attention aggregate: segments = adjacency lists, a row may be a member of many segments).  The reference
  * holds no implementation of either (model/tanr.py is empty): the checker is a torch restatement of the formula
  * (oracle/segpool_oracle.py) -- PARITY UNPINNED.  An empty segment yields a zero row. */
-#define NRMS_SEGPOOL_ROWS_UNIQUE 1   /* every row is a member of at most one segment: d(logit) and dx are then plain, bit-reproducible
-                                        stores; without the flag they are float atomics (summation order may vary) */
+#define NRMS_SEGPOOL_ROWS_UNIQUE 1   /* every row is a member of at most one segment: d(logit) and dx are then plain stores by the
+                                        segment's wave; without the flag the backward sorts the list entries by row (stable) and
+                                        adds a row's shares in ascending list position -- bit-reproducible either way */
 typedef struct nrms_segpool_desc {
     int64_t n_rows;       /* rows of x */
     int64_t n_seg;        /* segments */
@@ -347,8 +348,8 @@ int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float* x, const f
 /* Index lists from padded neighbour lists (a sampled sub-graph as [n_seg, K] int64 with -1 for "no neighbour"): entries inside
  * [0, n_rows) are kept in their order.  seg_ptr [n_seg + 1], idx [capacity n_seg * K]; pass nnz = n_seg * K (a capacity) in the
  * nrms_segpool_desc -- the lists' real length is seg_ptr[n_seg], on the device.  Without NRMS_SEGPOOL_ROWS_UNIQUE (a row listed
- * by several segments, as in a graph) the backward adds a row's contributions with float atomics: results are reproducible to
- * rounding only. */
+ * by several segments, as in a graph) the backward sorts the list entries by row (stable) and adds a row's contributions in
+ * ascending list position: no atomics, the same bits on every run. */
 int nrms_csr_from_padded(int64_t n_seg, int32_t K, const int64_t* lists, int64_t n_rows, int32_t* seg_ptr, int32_t* idx, void* stream);
 
 /* ---- Index side of a HieRec-style hierarchical interest model (BASELINE configs[3]; SURVEY f-4; PARITY UNPINNED: no reference

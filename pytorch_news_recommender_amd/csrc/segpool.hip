@@ -14,11 +14,18 @@
 // (coalesced 16-byte row reads, four members in flight), softmax by wave reductions, weighted row sum in registers.
 //   forward : T = tanh(x W^T + b) [rows, q], logit = T q_vec [rows]      (NT GEMM + seg_logit)
 //             alpha [nnz], out [n_seg, d]                                 (seg_pool_fwd)
-//   backward: d(alpha_k) = <dout_s, x_k>, d(logit) by the softmax rule    (seg_da: plain stores when the segments partition the
-//             rows, float atomics otherwise), d(q_vec) = sum_r d(logit_r) T_r (fixed-order partial sums),
+//   backward: d(alpha_k) = <dout_s, x_k>, d(logit) by the softmax rule    (seg_da), d(q_vec) = sum_r d(logit_r) T_r (fixed-order
+//             partial sums),
 //             d(W_add), d(b_add) = dZ^T [x | 1] and dx = dZ W_add with dZ = d(logit) q_vec (1 - T^2)   (the TN / NT GEMMs' dZ loaders),
 //             dx[idx_k] += alpha_k dout_s                                  (seg_scatter)
+//   A row listed by several segments (a graph: no NRMS_SEGPOOL_ROWS_UNIQUE) collects its members' shares in a FIXED order, without
+//   atomics: the list entries are sorted by row (stable radix sort, rocPRIM: the one library call of this file -- index
+//   preparation, not arithmetic), and a workgroup per row adds its entries in ascending list position (seg_row_da, seg_row_gather).
 #include <algorithm>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "gemm.h"
 
@@ -103,11 +110,11 @@ __global__ __launch_bounds__(64 * SEG_WPB) void seg_pool_fwd_kernel(long n_seg, 
     }
 }
 
-// d(logit) of every member: da_k = alpha_k (<dout_s, x_k> - sum_j alpha_j <dout_s, x_j>), into da_row[idx_k]
-// (UNIQUE: a row has one membership at most -> plain store; otherwise atomic add into the zeroed buffer).  dal [nnz]: scratch.
+// d(logit) of every member: da_k = alpha_k (<dout_s, x_k> - sum_j alpha_j <dout_s, x_j>).  UNIQUE (a row has one membership at
+// most): stored to da_row[idx_k].  Otherwise: left per entry in dal[k] with seg_of[k] = s, for the per-row sums below.
 template <bool UNIQUE>
 __global__ __launch_bounds__(64 * SEG_WPB) void seg_da_kernel(long n_seg, int d, const float* x, const int* seg_ptr, const int* idx,
-                                                              const float* alpha, const float* dout, float* dal, float* da_row) {
+                                                              const float* alpha, const float* dout, float* dal, float* da_row, int* seg_of) {
     const int lane = threadIdx.x & 63;
     const long s = (long)blockIdx.x * SEG_WPB + (threadIdx.x >> 6);
     if (s >= n_seg) return;
@@ -141,12 +148,121 @@ __global__ __launch_bounds__(64 * SEG_WPB) void seg_da_kernel(long n_seg, int d,
     for (int k = p0 + lane; k < p1; k += 64) {
         const float da = alpha[k] * (dal[k] - sumad);
         if (UNIQUE) da_row[idx[k]] = da;
-        else atomicAdd(da_row + idx[k], da);
+        else { dal[k] = da; seg_of[k] = (int)s; }
     }
 }
 
-// dx[idx_k][:] += alpha_k dout_s[:]
-template <bool UNIQUE>
+// ---- rows listed by several segments: the entries of a row, in ascending list position (tval, bounded by tptr)
+__global__ __launch_bounds__(256) void seg_tkey_kernel(long cap, const int* idx, const int* nnz_dev, int n_rows, int* key, int* val) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= cap) return;
+    key[e] = e < *nnz_dev ? idx[e] : n_rows;         // (capacity beyond the lists' real length sorts to the end)
+    val[e] = (int)e;
+}
+
+// tptr[r] = first position of the sorted keys that is >= r, r = 0 .. n_rows
+__global__ __launch_bounds__(256) void seg_tptr_kernel(long cap, int n_rows, const int* key_sorted, int* tptr) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r > n_rows) return;
+    long lo = 0, hi = cap;
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (key_sorted[mid] < r) lo = mid + 1; else hi = mid; }
+    tptr[r] = (int)lo;
+}
+
+// da_row[r] = sum of its entries' d(logit), lanes striding the row's list, then the wave reduction: a fixed order
+__global__ __launch_bounds__(64 * SEG_WPB) void seg_row_da_kernel(long n_rows, const int* tptr, const int* tval, const float* dal, float* da_row) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * SEG_WPB + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int p0 = tptr[r], p1 = tptr[r + 1];
+    float acc = 0.f;
+    for (int j = p0 + lane; j < p1; j += 64) acc += dal[tval[j]];
+    acc = wave_sum(acc);
+    if (lane == 0) da_row[r] = acc;
+}
+
+// dx[r][:] += sum over the row's entries e (ascending list position) of alpha_e dout[seg_of[e]][:], as a segmented reduction over
+// the SORTED entries so that a row everybody lists (a popular news of a click graph holds 10 % of all entries) is not one
+// wave's serial loop: a wave walks a span of 64 sorted positions; a row whose entries all lie inside the span is finished there
+// (single writer); a row that crosses span boundaries leaves one partial sum per span (slot 0: its run starts at the span's
+// first position, slot 1: later) and seg_row_combine adds them in span order.
+constexpr int SEG_SPAN = 64;
+__global__ __launch_bounds__(64 * SEG_WPB) void seg_span_gather_kernel(long n_spans, int n_rows, int d, const int* key_sorted, const int* tval,
+                                                                       const int* tptr, const int* seg_of, const float* alpha, const float* dout,
+                                                                       float* partial, float* dx) {
+    const int lane = threadIdx.x & 63;
+    const long span = (long)blockIdx.x * SEG_WPB + (threadIdx.x >> 6);
+    if (span >= n_spans) return;
+    const long pos = span * SEG_SPAN + lane;
+    const int row_l = key_sorted[pos];                                  // (the arrays hold n_spans * 64 entries: the capacity is padded)
+    const int e_l = tval[pos];
+    const bool live_l = row_l < n_rows;
+    const float a_l = live_l ? alpha[e_l] : 0.f;
+    const int s_l = live_l ? seg_of[e_l] : 0;
+    const int d4 = d >> 2;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int run_start = 0;
+    for (int j = 0; j < SEG_SPAN; ++j) {
+        const int row = __shfl(row_l, j, 64);
+        if (row >= n_rows) break;                                       // sorted: the rest is padding
+        const float a = __shfl(a_l, j, 64);
+        const float* src = dout + (long)__shfl(s_l, j, 64) * d;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int c = lane + 64 * c4;
+            if (c < d4) acc[c4] += *reinterpret_cast<const f32x4*>(src + 4 * c) * a;
+        }
+        const int next = j + 1 < SEG_SPAN ? __shfl(row_l, j + 1, 64) : -1;
+        if (next != row) {                                              // the run [run_start, j] of `row` ends here
+            const int p0 = tptr[row], p1 = tptr[row + 1];
+            const bool owned = p0 / SEG_SPAN == (p1 - 1) / SEG_SPAN;
+            float* o = owned ? dx + (long)row * d : partial + (span * 2 + (run_start == 0 ? 0 : 1)) * d;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int c = lane + 64 * c4;
+                if (c < d4) {
+                    f32x4 v = acc[c4];
+                    if (owned) v += *reinterpret_cast<const f32x4*>(o + 4 * c);
+                    *reinterpret_cast<f32x4*>(o + 4 * c) = v;
+                    acc[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            run_start = j + 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * SEG_WPB) void seg_row_combine_kernel(long n_rows, int d, const int* tptr, const float* partial, float* dx) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * SEG_WPB + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int p0 = tptr[r], p1 = tptr[r + 1];
+    if (p1 <= p0) return;
+    const int sa = p0 / SEG_SPAN, sb = (p1 - 1) / SEG_SPAN;
+    if (sa == sb) return;                                               // finished by its span
+    const int d4 = d >> 2;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = sa; i <= sb; ++i) {
+        const float* src = partial + ((long)i * 2 + ((i == sa && p0 != sa * SEG_SPAN) ? 1 : 0)) * d;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int c = lane + 64 * c4;
+            if (c < d4) acc[c4] += *reinterpret_cast<const f32x4*>(src + 4 * c);
+        }
+    }
+    float* o = dx + r * d;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        const int c = lane + 64 * c4;
+        if (c < d4) *reinterpret_cast<f32x4*>(o + 4 * c) = *reinterpret_cast<const f32x4*>(o + 4 * c) + acc[c4];
+    }
+}
+
+// dx[idx_k][:] += alpha_k dout_s[:]   (segments that partition the rows: a row is written by one wave)
 __global__ __launch_bounds__(64 * SEG_WPB) void seg_scatter_kernel(long n_seg, int d, const int* seg_ptr, const int* idx, const float* alpha,
                                                                    const float* dout, float* dx) {
     const int lane = threadIdx.x & 63;
@@ -167,14 +283,9 @@ __global__ __launch_bounds__(64 * SEG_WPB) void seg_scatter_kernel(long n_seg, i
         for (int j = 0; j < 4; ++j) {
             const int c = lane + 64 * j;
             if (c < d4) {
-                if (UNIQUE) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-                    v += dv[j] * a;
-                    *reinterpret_cast<f32x4*>(xr + 4 * c) = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(xr + 4 * c + e, a * dv[j][e]);
-                }
+                f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+                v += dv[j] * a;
+                *reinterpret_cast<f32x4*>(xr + 4 * c) = v;
             }
         }
     }
@@ -241,7 +352,8 @@ __global__ __launch_bounds__(256) void csr_emit_kernel(long n_seg, int K, const 
     for (int k = 0; k < K; ++k) { const int64_t v = lists[s * K + k]; if (v >= 0 && v < n_rows) idx[o++] = (int)v; }
 }
 
-struct SegWs { size_t wplanes, da, dal, wadd_t, tn_partial, dq_partial, total; };
+struct SegWs { size_t wplanes, da, dal, wadd_t, tn_partial, dq_partial, seg_of, key, val, key2, val2, tptr, spart, sort_tmp, sort_tmp_bytes, total; long cap; };
+static int key_bits(long n_rows) { int b = 1; while ((1L << b) <= n_rows) ++b; return b; }
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 static SegWs seg_layout(const nrms_segpool_desc* d) {
     SegWs w;
@@ -254,6 +366,20 @@ static SegWs seg_layout(const nrms_segpool_desc* d) {
     w.wadd_t = take((size_t)d->q * d->d * 4);
     w.tn_partial = take(gemm_tn_workspace_floats((int)d->n_rows, d->q, d->d, nullptr) * 4);
     w.dq_partial = take((size_t)cdiv(d->n_rows > 0 ? d->n_rows : 1, SEGQ_ROWS) * d->q * 4);
+    w.seg_of = w.key = w.val = w.key2 = w.val2 = w.tptr = w.spart = w.sort_tmp = w.sort_tmp_bytes = 0;
+    w.cap = 0;
+    if ((d->flags & NRMS_SEGPOOL_ROWS_UNIQUE) == 0 && d->nnz > 0) {
+        w.cap = (d->nnz + SEG_SPAN - 1) / SEG_SPAN * SEG_SPAN;          // sorted arrays in whole spans (the padding sorts to the end)
+        const size_t e = (size_t)w.cap * 4;
+        w.seg_of = take(e); w.key = take(e); w.val = take(e); w.key2 = take(e); w.val2 = take(e);
+        w.tptr = take(((size_t)d->n_rows + 1) * 4);
+        w.spart = take((size_t)(w.cap / SEG_SPAN) * 2 * d->d * 4);
+        size_t tb = 0;
+        (void)rocprim::radix_sort_pairs(nullptr, tb, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr, (size_t)w.cap, 0,
+                                        key_bits(d->n_rows), (hipStream_t)0);
+        w.sort_tmp_bytes = tb;
+        w.sort_tmp = take(tb);
+    }
     w.total = off;
     return w;
 }
@@ -330,7 +456,9 @@ extern "C" int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float*
     hipStream_t s = (hipStream_t)stream;
     const int d = desc->d, q = desc->q;
     const bool unique = (desc->flags & NRMS_SEGPOOL_ROWS_UNIQUE) != 0;
+    const bool by_row = !unique && desc->nnz > 0 && desc->n_seg > 0;
     char* base = (char*)workspace;
+    int* seg_of = (int*)(base + L.seg_of); int* tval = (int*)(base + L.val2); int* tptr = (int*)(base + L.tptr);
     float* da = (float*)(base + L.da);
     float* dal = (float*)(base + L.dal);
     float* wadd_t = (float*)(base + L.wadd_t);
@@ -339,9 +467,26 @@ extern "C" int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float*
     const dim3 sgrid(cdiv(desc->n_seg > 0 ? desc->n_seg : 1, SEG_WPB)), sblk(64 * SEG_WPB);
     if (desc->n_seg > 0) {
         TimingScope ts("segpool_da", s);
-        if (unique) hipLaunchKernelGGL(seg_da_kernel<true>, sgrid, sblk, 0, s, (long)desc->n_seg, d, x, seg_ptr, idx, alpha, dout, dal, da);
-        else hipLaunchKernelGGL(seg_da_kernel<false>, sgrid, sblk, 0, s, (long)desc->n_seg, d, x, seg_ptr, idx, alpha, dout, dal, da);
+        if (unique) hipLaunchKernelGGL(seg_da_kernel<true>, sgrid, sblk, 0, s, (long)desc->n_seg, d, x, seg_ptr, idx, alpha, dout, dal, da, (int*)nullptr);
+        else hipLaunchKernelGGL(seg_da_kernel<false>, sgrid, sblk, 0, s, (long)desc->n_seg, d, x, seg_ptr, idx, alpha, dout, dal, da, seg_of);
         rc = check_launch("segpool_da");
+        if (rc) return rc;
+    }
+    if (by_row) {
+        // the entries of every row, in ascending list position: stable sort of (row, entry) pairs, then the rows' bounds
+        TimingScope ts("segpool_rowlists", s);
+        const long cap = L.cap;
+        int* key = (int*)(base + L.key); int* val = (int*)(base + L.val); int* key2 = (int*)(base + L.key2);
+        hipLaunchKernelGGL(seg_tkey_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, s, cap, idx, seg_ptr + desc->n_seg, (int)desc->n_rows, key, val);
+        size_t tb = L.sort_tmp_bytes;
+        if (rocprim::radix_sort_pairs(base + L.sort_tmp, tb, (const int*)key, key2, (const int*)val, tval, (size_t)cap, 0, key_bits(desc->n_rows), s) != hipSuccess) {
+            set_error("segment_pool_bwd: radix_sort_pairs failed");
+            return NRMS_ELAUNCH;
+        }
+        hipLaunchKernelGGL(seg_tptr_kernel, dim3(cdiv(desc->n_rows + 1, 256)), dim3(256), 0, s, cap, (int)desc->n_rows, (const int*)key2, tptr);
+        hipLaunchKernelGGL(seg_row_da_kernel, dim3(cdiv(desc->n_rows, SEG_WPB)), dim3(64 * SEG_WPB), 0, s, (long)desc->n_rows, (const int*)tptr, (const int*)tval,
+                           (const float*)dal, da);
+        rc = check_launch("segpool_rowlists");
         if (rc) return rc;
     }
     // d(q_vec) += sum_r da_r T_r
@@ -380,8 +525,15 @@ extern "C" int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float*
     }
     if (desc->n_seg > 0) {
         TimingScope ts("segpool_scatter", s);
-        if (unique) hipLaunchKernelGGL(seg_scatter_kernel<true>, sgrid, sblk, 0, s, (long)desc->n_seg, d, seg_ptr, idx, alpha, dout, dx);
-        else hipLaunchKernelGGL(seg_scatter_kernel<false>, sgrid, sblk, 0, s, (long)desc->n_seg, d, seg_ptr, idx, alpha, dout, dx);
+        if (unique) hipLaunchKernelGGL(seg_scatter_kernel, sgrid, sblk, 0, s, (long)desc->n_seg, d, seg_ptr, idx, alpha, dout, dx);
+        else if (by_row) {
+            const long n_spans = L.cap / SEG_SPAN;
+            float* spart = (float*)(base + L.spart);
+            hipLaunchKernelGGL(seg_span_gather_kernel, dim3(cdiv(n_spans, SEG_WPB)), dim3(64 * SEG_WPB), 0, s, n_spans, (int)desc->n_rows, d,
+                               (const int*)(base + L.key2), (const int*)tval, (const int*)tptr, (const int*)seg_of, alpha, dout, spart, dx);
+            hipLaunchKernelGGL(seg_row_combine_kernel, dim3(cdiv(desc->n_rows, SEG_WPB)), dim3(64 * SEG_WPB), 0, s, (long)desc->n_rows, d, (const int*)tptr,
+                               (const float*)spart, dx);
+        }
         rc = check_launch("segpool_scatter");
     }
     return rc;

@@ -63,24 +63,31 @@ def test_segment_pool_forward_and_gradients_against_the_oracle(case, precision):
         assert bool((diff <= bound).all()), (case, precision, name, float(diff.max()), float(ref.abs().max()))
 
 
-def test_partition_mode_is_bit_reproducible_and_validation():
-    import ctypes as C
-    from pytorch_news_recommender_amd import _lib
+@pytest.mark.parametrize("partition", [True, False], ids=["partition", "shared_rows"])
+def test_both_modes_are_bit_reproducible(partition):
+    """Segments that partition the rows (plain stores) and rows listed by many segments (entries sorted by row, added in list order):
+    the same bits on every run, whatever order the hardware schedules the waves in."""
     from pytorch_news_recommender_amd.segpool import SegmentPool
-    x, w, b, qv, ptr, idx = _case(500, 70, 300, 200, seed=11, partition=True)
+    x, w, b, qv, ptr, idx = _case(500, 70, 300, 200, seed=11, partition=partition)
     dev = torch.device("cuda")
     tx, tw, tb, tq, tp, ti = (torch.from_numpy(a).to(dev) for a in (x, w, b, qv, ptr, idx))
     dout = torch.randn(70, 300, generator=torch.Generator().manual_seed(3)).to(dev)
     res = []
-    for _ in range(2):
-        op = SegmentPool(300, 200, "bf16x3", rows_unique=True)
+    for _ in range(3):
+        op = SegmentPool(300, 200, "bf16x3", rows_unique=partition)
         out = op.forward(tx, tw, tb, tq, tp, ti).clone()
         dw, db, dq = torch.zeros_like(tw), torch.zeros_like(tb), torch.zeros_like(tq)
         dx = op.backward(tw, tq, dout, dw, db, dq)
         torch.cuda.synchronize()
         res.append((out, dx.clone(), dw, db, dq))
-    for a, c in zip(res[0], res[1]):
-        assert torch.equal(a, c)
+    for other in res[1:]:
+        for a, c in zip(res[0], other):
+            assert torch.equal(a, c)
+
+
+def test_descriptor_validation():
+    import ctypes as C
+    from pytorch_news_recommender_amd import _lib
     lib = _lib.load()
     for kw in (dict(d=301), dict(q=6), dict(d=2048), dict(precision=_lib.NRMS_PRECISION_FP16), dict(flags=8), dict(n_rows=-1)):
         args = dict(n_rows=10, n_seg=2, nnz=4, d=300, q=200, precision=_lib.NRMS_PRECISION_BF16X3, flags=0)
