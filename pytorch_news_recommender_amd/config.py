@@ -64,6 +64,8 @@ class Config(object):
         # model "hierec" (model/hierec_hip.py; parity unpinned): weights of the sub-topic / topic terms of the hierarchical match
         self.hierec_lambda_sub = 0.7
         self.hierec_lambda_top = 0.15
+        # model "graph" (model/graph_hip.py; parity unpinned): neighbours sampled per news slot when the batch carries no neighbor_rows
+        self.graph_neighbors = 8
 
     def __nrms__(self):
         self.news_feature_size = 800             # nrms_naml: 2 * word_embed_size + 2 * cate_embed_size (config.py:68)

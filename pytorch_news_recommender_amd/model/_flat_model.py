@@ -135,7 +135,8 @@ class FlatHipModel(nn.Module):
 
     def _next_seed(self):
         self._calls += 1
-        return (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        # (_rank_salt: set by run_v0 per data-parallel rank, so that the ranks draw different dropout masks)
+        return (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03 + getattr(self, "_rank_salt", 0)) & 0xFFFFFFFFFFFFFFFF
 
     def _device_batch(self, batch, dev):
         out = {}

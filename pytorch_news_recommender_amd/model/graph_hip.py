@@ -18,8 +18,9 @@ Specification (n_r = NRMS news encoder of slot r's title, ``nrms_v0.py:154-176``
   user layer:  h_b = AddPool({g_r : r a history slot of b with browsed_mask = 1}; user_attention)  (no click: 0)
   score(b, c) = <g_cand(b, c), h_b>                                                               (``nrms_v0.py:205-216``)
 Both aggregations are ``nrms_segment_pool_fwd / _bwd`` (csrc/segpool.hip) over index lists built on the device by
-``nrms_csr_from_padded``; a news row is listed by many segments, so the news layer's backward adds with float atomics
-(reproducible to rounding, include/nrms_hip.h).  No CPU fallback.
+``nrms_csr_from_padded``; a news row is listed by many segments, so the news layer's backward sorts the list entries by row and
+adds a row's shares in list order (no atomics: bit-reproducible, include/nrms_hip.h).  A batch without ``neighbor_rows`` (the
+reference's loader knows no graph) gets them from ``graph_sampler.induced_neighbor_rows``.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -157,3 +158,14 @@ class Model(FlatHipModel):
 
     def _make_engine(self, device, precision):
         return GraphEngine(self._dims, self._layout, device, precision)
+
+    def _device_batch(self, batch, dev):
+        if (batch.get("neighbor_rows") if hasattr(batch, "get") else None) is None:
+            # a loader that knows no graph (data_handler.MyDataset): sample the neighbours from the click graph induced on this batch
+            from ..graph_sampler import induced_neighbor_rows
+            self._sampled = getattr(self, "_sampled", 0) + 1
+            cpu = lambda v: torch.as_tensor(v).cpu().numpy()
+            batch = dict(batch)
+            batch["neighbor_rows"] = induced_neighbor_rows(cpu(batch["browsed_titles"]), cpu(batch["browsed_mask"]), cpu(batch["candidate_titles"]),
+                                                           int(getattr(self.config, "graph_neighbors", 8)), seed=self._sampled)
+        return super()._device_batch(batch, dev)

@@ -149,3 +149,23 @@ def test_train_step_with_an_all_reduce_hook_matches_an_oracle_adam_step():
         got = v.detach().cpu().numpy()
         moved = np.abs(want[k] - params[k]) > 0.5e-3
         assert float(np.abs(got - want[k])[moved].max(initial=0.0)) < 3e-5, k
+
+
+@pytest.mark.parametrize("name,key", [("hierec", "model.subtopic_attention.linear.weight"), ("graph", "model.neighbor_attention.linear.weight")])
+def test_run_v0_entry_point(name, key, tmp_path, monkeypatch):
+    """The reference's entry contract (run_v0.py --model <name> -> model.Model(config, args) -> model.<name>) on the synthetic
+    corpus through data_handler's own batch dicts (category ids for hierec; the graph encoder samples its neighbours from the
+    batch, graph_sampler.py): training steps, a dev evaluation, a checkpoint under the wrapper's ``model.`` prefix."""
+    import os
+    from pytorch_news_recommender_amd import run_v0
+    monkeypatch.chdir(tmp_path)
+    hist = run_v0.main(["--model", name, "--dataset", "synthetic", "--epochs", "1", "--synthetic_users", "192", "--batch_size", "32",
+                        "--max_batches", "5", "--num_workers", "0", "--description", "T", "--data_path", str(tmp_path / "data_processed"),
+                        "--save_path", str(tmp_path / "save")])
+    assert len(hist["losses"]) == 5 and np.isfinite(hist["losses"]).all()
+    assert hist["aucs"] and 0.0 < hist["aucs"][-1][1] < 1.0
+    # (a checkpoint is written when the dev AUC passes the reference's 0.56, train_eval.py:59 -- five steps may not get there)
+    save = tmp_path / "save"
+    for f in ([f for f in os.listdir(save) if f.endswith(".ckpt")] if save.exists() else []):
+        sd = torch.load(os.path.join(save, f), map_location="cpu", weights_only=True)
+        assert key in sd and "model.news_encoder.word_embedding.0.weight" in sd

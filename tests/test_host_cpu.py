@@ -523,3 +523,37 @@ def test_test_with_pick_best_raises_when_there_is_no_checkpoint(tmp_path):
     open(os.path.join(cfg.save_path, "T01-01_00.00_nrms_hip_epoch5_iter_10_auc_0.412.ckpt"), "w").close()   # below 0.5: not a candidate
     with pytest.raises(FileNotFoundError, match="no checkpoint"):
         train_eval.test(cfg, model=None, data_iter=[], pick_best=True)
+
+
+def test_graph_sampler_draws_co_clicked_news_of_the_batch():
+    """graph_sampler.induced_neighbor_rows (the graph encoder's neighbor_rows key, SURVEY f-4 -- no reference counterpart): a
+    neighbour is a real click of a user who also clicked the slot's news, never the same news, -1 where nobody clicked it."""
+    from pytorch_news_recommender_amd import synth
+    from pytorch_news_recommender_amd.graph_sampler import induced_neighbor_rows
+    shape = synth.Shape(n_words=12, word_embed_size=8, num_attention_heads=2, query_vector_dim=4, batch_size=40, history_len=9,
+                        n_candidates=4, n_words_title=2)
+    b = synth.make_batch(shape, seed=3, min_title=1, empty_history_user=True)         # 11 x 11 possible titles: many repeats
+    bt, bm, ct = b["browsed_titles"], b["browsed_mask"].astype(bool), b["candidate_titles"]
+    B, H, C, K = 40, 9, 4, 6
+    nb = induced_neighbor_rows(bt, bm, ct, K, seed=5)
+    assert nb.shape == (B * (H + C), K) and nb.dtype == np.int64
+    assert np.array_equal(nb, induced_neighbor_rows(bt, bm, ct, K, seed=5))          # a function of the seed
+    titles = np.concatenate([bt.reshape(B * H, -1), ct.reshape(B * C, -1)], 0)
+    clicked = {}                                                                      # title -> users who clicked it
+    for u in range(B):
+        for k in range(H):
+            if bm[u, k]:
+                clicked.setdefault(tuple(bt[u, k]), set()).add(u)
+    n_some = 0
+    for r in range(B * (H + C)):
+        users = clicked.get(tuple(titles[r]), set())
+        for v in nb[r]:
+            if v < 0:
+                continue
+            n_some += 1
+            assert 0 <= v < B * H and bm.reshape(-1)[v]                               # a real click ...
+            assert v // H in users                                                    # ... of a user who clicked this slot's news
+            assert tuple(titles[v]) != tuple(titles[r])                               # ... and another news
+        if not users:
+            assert (nb[r] < 0).all()
+    assert n_some > B * H
