@@ -133,6 +133,10 @@ typedef struct nrms_encoder_desc {
                               nrms_v1); not combinable with NRMS_PRECISION_FP16.  With NRMS_FLAG_PAD_ROW_ZERO an
                               all-padding sequence keeps a closed form: context of query i = b_v x (kept keys of i) /
                               (seq_len (1 - p)) */
+    const int32_t* seq_index; /* optional (device) [n_seq]: the call holds a COMPACTED batch and sequence r is sequence
+                              seq_index[r] of the full one -- the attention-probability dropout then draws the full batch's
+                              decisions (counters by seq_index[r], not r).  fp32 / bf16x3 / bf16 chain only, no embedding or
+                              context dropout; null = 0 .. n_seq - 1.  See nrms_sequence_partition / nrms_encoder_empty_fwd */
 } nrms_encoder_desc;
 
 /* Parameters, in the reference's own tensor layout ([out,in] Linear weights).
@@ -351,6 +355,25 @@ int nrms_segment_pool_bwd(const nrms_segpool_desc* desc, const float* x, const f
  * by several segments, as in a graph) the backward sorts the list entries by row (stable) and adds a row's contributions in
  * ascending list position: no atomics, the same bits on every run. */
 int nrms_csr_from_padded(int64_t n_seg, int32_t K, const int64_t* lists, int64_t n_rows, int32_t* seg_ptr, int32_t* idx, void* stream);
+
+/* ---- All-padding sequences of the output-projection topology in closed form (csrc/empty_seq.hip; nrms_naml's word-level
+ * encoder, model/nrms_naml.py:42-100,121-177: 41 % of a MIND-shaped batch's title / abstract slots are history padding).  With a
+ * zero padding row every Q | K | V row of such a sequence is the bias, so attention row i is b_v scaled per head by
+ * c_ih = (kept keys of query i) / (seq_len (1 - p_drop_attn)), and W_O, the additive attention and their gradients collapse to
+ * products with n_heads + 1 vectors that depend on the weights only.  The caller splits its sequences with nrms_sequence_partition
+ * (order[0 .. counts[0]) = sequences with a real token, order[n_seq .. n_seq + counts[1]) = all-padding ones; counts holds
+ * nrms_sequence_partition_count_ints(n_seq) ints, device), runs nrms_encoder_fwd / _bwd on the first list's sequences (gathered,
+ * desc.seq_index = that list) and these two calls on the second: desc.n_seq = counts[1], seq_index = the second list, out / dout
+ * [desc.n_seq, d_model] compact.  Same desc rules as the chain (use_output_proj = 1, no mask, no embedding / context dropout;
+ * seq_len <= 64, n_heads <= 8, d_model <= 512, q_dim <= 256); gradients are ACCUMULATED into grads (w_add, b_add, q_vec, w_o, b_o,
+ * and the V third of b_qkv; every other gradient of such a sequence is exactly zero), per-wave partial sums in a fixed order. */
+size_t nrms_sequence_partition_count_ints(int32_t n_seq);
+int nrms_sequence_partition(const int64_t* ids, int32_t n_seq, int32_t seq_len, int32_t* order /* [2 * n_seq] */, int32_t* counts, void* stream);
+size_t nrms_encoder_empty_workspace_bytes(const nrms_encoder_desc* desc);
+int nrms_encoder_empty_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int32_t* seq_index, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int nrms_encoder_empty_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int32_t* seq_index, const float* dout,
+                           const nrms_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Index side of a HieRec-style hierarchical interest model (BASELINE configs[3]; SURVEY f-4; PARITY UNPINNED: no reference
  * implementation, checked against oracle/segpool_oracle.py).  A user's clicked news (H <= 64 history slots, `valid` = the

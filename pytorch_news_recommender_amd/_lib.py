@@ -33,7 +33,7 @@ class EncoderDesc(C.Structure):
                 ("n_heads", C.c_int32), ("q_dim", C.c_int32), ("vocab", C.c_int32),
                 ("p_drop_embed", C.c_float), ("p_drop_ctx", C.c_float), ("precision", C.c_int32),
                 ("use_output_proj", C.c_int32), ("mask_mode", C.c_int32), ("flags", C.c_int32),
-                ("seed", C.c_uint64), ("loss_scale", C.c_float), ("p_drop_attn", C.c_float)]
+                ("seed", C.c_uint64), ("loss_scale", C.c_float), ("p_drop_attn", C.c_float), ("seq_index", C.c_void_p)]
 
 
 class EncoderWeights(C.Structure):
@@ -100,6 +100,12 @@ SIGNATURES = {
     "nrms_hier_tree_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "nrms_hier_tree_build": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 16 + [C.c_size_t, C.c_void_p]),
     "nrms_hier_add_embedding_fwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrms_sequence_partition_count_ints": (C.c_size_t, [C.c_int32]),
+    "nrms_sequence_partition": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrms_encoder_empty_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
+    "nrms_encoder_empty_fwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nrms_encoder_empty_bwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.POINTER(EncoderGrads), C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
     "nrms_csr_from_padded": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_hier_add_embedding_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "nrms_hier_add_embedding_bwd": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libnrms_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "embed.hip", "attention.hip", "pool.hip", "wide.hip", "fused16.hip", "fused16_v1.hip", "fused16_bwd.hip", "fused16_v1_bwd.hip", "user64.hip", "segpool.hip", "hier.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "embed.hip", "attention.hip", "pool.hip", "wide.hip", "fused16.hip", "fused16_v1.hip", "fused16_bwd.hip", "fused16_v1_bwd.hip", "user64.hip", "segpool.hip", "hier.hip", "empty_seq.hip", "capi.hip"]
 HEADERS = ["common.h", "gemm.h", "fused16.h", "fused16_bwd.h", "fused16_v1.h", os.path.join("..", "..", "include", "nrms_hip.h")]
 ARCH = "gfx950"
 

@@ -293,7 +293,7 @@ template <int NS>
 __device__ __forceinline__ void prob_dropout(f32x16 (&xt)[NS][NS], const Dropout& pd, long unit, int S, int l32, int hh) {
 #pragma unroll
     for (int it = 0; it < NS; ++it) {
-        const uint64_t row0 = (uint64_t)((unit * S + it * 32 + l32) * S);
+        const uint64_t row0 = (uint64_t)((pd.unit_of(unit) * S + it * 32 + l32) * S);
 #pragma unroll
         for (int jt = 0; jt < NS; ++jt)
 #pragma unroll
@@ -494,7 +494,7 @@ __device__ __forceinline__ void softmax_col(f32x16 (&st)[NS], float scale, int S
 template <int NS>
 __device__ __forceinline__ uint32_t prob_keep_bits_col(const Dropout& pd, long unit, int S, int it, int l32, int hh) {
     static_assert(NS <= 2, "32 mask bits");
-    const uint64_t row0 = (uint64_t)((unit * S + it * 32 + l32) * S);
+    const uint64_t row0 = (uint64_t)((pd.unit_of(unit) * S + it * 32 + l32) * S);
     uint32_t bits = 0;
 #pragma unroll
     for (int jt = 0; jt < NS; ++jt)

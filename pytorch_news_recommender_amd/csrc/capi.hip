@@ -155,6 +155,11 @@ static int validate_desc(const nrms_encoder_desc* d, const char* who) {
         NRMS_REQUIRE(user64_supported(d->seq_len, d->d_model, d->n_heads, d->q_dim, &why), "%s: NRMS_FLAG_FUSED_SEQ64 needs %s", who, why);
     }
     NRMS_REQUIRE((long)d->n_seq * d->seq_len < (1L << 31), "%s: n_seq*seq_len overflows int32", who);
+    if (d->seq_index != nullptr)
+        NRMS_REQUIRE(d->precision != NRMS_PRECISION_FP16 && (d->flags & NRMS_FLAG_FUSED_SEQ64) == 0 && !wide_attention(d) &&
+                     d->p_drop_embed == 0.f && d->p_drop_ctx == 0.f,
+                     "%s: seq_index renumbers the counters of the attention-probability dropout only (fp32 / bf16x3 / bf16, d_k <= 64 even, "
+                     "no embedding or context dropout)", who);
     return NRMS_OK;
 }
 
@@ -559,7 +564,8 @@ extern "C" int nrms_encoder_fwd(const nrms_encoder_desc* desc, const nrms_encode
     if (rc) return rc;
     // v0: the attention kernel writes ctx through the context dropout.  v1: it writes the raw head
     // concatenation, the output projection follows and carries the dropout in its epilogue.
-    const Dropout pdrop_attn = make_dropout(desc->seed, desc->p_drop_attn);
+    Dropout pdrop_attn = make_dropout(desc->seed, desc->p_drop_attn);
+    pdrop_attn.seq_index = desc->seq_index; pdrop_attn.seq_h = desc->n_heads;
     if (wide_attention(desc))
         rc = launch_attention_wide(false, desc->n_seq, S, d, desc->n_heads, acts->qkv, wo ? acts->attn : acts->ctx,
                                    pdrop_attn, nullptr, nullptr, amask, s);
@@ -827,7 +833,8 @@ extern "C" int nrms_encoder_bwd(const nrms_encoder_desc* desc, const nrms_encode
         if (rc) return rc;
     }
     // 4. attention backward
-    const Dropout pdrop_attn = make_dropout(desc->seed, desc->p_drop_attn);
+    Dropout pdrop_attn = make_dropout(desc->seed, desc->p_drop_attn);
+    pdrop_attn.seq_index = desc->seq_index; pdrop_attn.seq_h = desc->n_heads;
     if (fused64)
         rc = NRMS_OK;                               // (dQKV is there already)
     else if (wide_attention(desc))
@@ -938,6 +945,16 @@ extern "C" int nrms_sanitize_ids_i32(const int32_t* src, int64_t* dst, int64_t n
     NRMS_REQUIRE(n >= 0 && vocab > 0, "sanitize_ids_i32: n=%ld vocab=%d", (long)n, vocab);
     NRMS_REQUIRE(n == 0 || (src && dst && n_bad), "sanitize_ids_i32: null argument");
     return launch_sanitize_ids((long)n, src, true, dst, vocab, n_bad, (hipStream_t)stream);
+}
+
+extern "C" size_t nrms_sequence_partition_count_ints(int32_t n_seq) { return n_seq >= 0 ? title_order_cnt_ints(n_seq) : 0; }
+
+extern "C" int nrms_sequence_partition(const int64_t* ids, int32_t n_seq, int32_t seq_len, int32_t* order, int32_t* counts, void* stream) {
+    NRMS_REQUIRE(n_seq >= 0 && seq_len >= 1 && seq_len <= 64, "sequence_partition: n_seq=%d seq_len=%d", n_seq, seq_len);
+    NRMS_REQUIRE(counts != nullptr, "sequence_partition: null counts");
+    if (n_seq == 0) return hipMemsetAsync(counts, 0, 2 * sizeof(int), (hipStream_t)stream) == hipSuccess ? NRMS_OK : NRMS_ELAUNCH;
+    NRMS_REQUIRE(ids && order, "sequence_partition: null argument");
+    return launch_title_order(n_seq, seq_len, ids, order, counts, (hipStream_t)stream, 2);
 }
 
 extern "C" int nrms_title_dedup(const int64_t* ids, int64_t n_titles, int32_t seq_len, int32_t* table, int64_t table_size,

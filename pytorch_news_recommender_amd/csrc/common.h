@@ -139,6 +139,15 @@ struct Dropout {
     uint32_t thresh;     // 0 => disabled
     float inv_keep;
     uint32_t thresh16;   // the same probability for the 16-bit-field scheme (dropout_scale8)
+    // site 2 (attention probabilities) of a COMPACTED batch (nrms_encoder_desc::seq_index): sequence r of the call counts as
+    // sequence seq_index[r] of the full batch, so the decisions are those of the uncompacted call
+    const int* seq_index;
+    int seq_h;           // heads per sequence (unit = seq * h + head)
+    __device__ __forceinline__ long unit_of(long unit) const {
+        if (seq_index == nullptr) return unit;
+        const long seq = unit / seq_h;
+        return (long)seq_index[seq] * seq_h + (unit - seq * seq_h);
+    }
 };
 
 inline Dropout make_dropout(uint64_t seed, float p) {
@@ -147,6 +156,8 @@ inline Dropout make_dropout(uint64_t seed, float p) {
     d.thresh = drop_threshold(p);
     d.thresh16 = drop_threshold16(p);
     d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    d.seq_index = nullptr;
+    d.seq_h = 1;
     return d;
 }
 

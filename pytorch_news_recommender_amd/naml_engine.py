@@ -119,6 +119,9 @@ class NamlEngine(NRMSEngine):
         self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._bad_event = None
         self._news_cache = None
+        # all-padding title / abstract sequences (history padding slots: 41 % of a MIND-shaped batch) in closed form
+        # (nrms_encoder_empty_fwd / _bwd) while the kernel chain runs on the others, compacted; needs a zero padding row
+        self.closed_form_empty = True
 
     def set_precision(self, precision):
         """fp32 or bf16x3 projections; the fused fp16 kernels have no W_O / attention-probability dropout, so "fp16"
@@ -157,17 +160,98 @@ class NamlEngine(NRMSEngine):
         return self.layout.entries[name][0]
 
     # ---- pieces --------------------------------------------------------------------------------------------------
-    def encode_text(self, flat, ids, tag, p_attn=0.0, seed=0, out=None):
-        """ids [N, L] (validated) -> [N, d]: embedding, MHSA with W_O, additive attention (nrms_naml.py:152-158)."""
+    def _split_ok(self, L):
+        d = self.dims
+        return (self.closed_form_empty and self.pad_row_zero and L <= 64 and d.heads("news_encoder") <= 8 and d.word_embed_size <= 512
+                and d.q("news_encoder") <= 256 and d.word_embed_size // d.heads("news_encoder") <= 64
+                and (d.word_embed_size // d.heads("news_encoder")) % 2 == 0)
+
+    def partition(self, ids, tag):
+        """Device lists of the sequences with a real token / the all-padding ones (nrms_sequence_partition): (order, counts)."""
         N, L = ids.shape
+        order = self._buf(tag + ".order", 2 * N, torch.int32)[:2 * N]
+        counts = self._buf(tag + ".order_cnt", int(self.lib.nrms_sequence_partition_count_ints(N)) + 2, torch.int32)
+        rc = self.lib.nrms_sequence_partition(_lib.ptr(ids), N, L, _lib.ptr(order), _lib.ptr(counts), _stream())
+        _lib.check(rc, "nrms_sequence_partition")
+        return order, counts
+
+    def encode_text(self, flat, ids, tag, p_attn=0.0, seed=0, out=None, split=None):
+        """ids [N, L] (validated) -> [N, d]: embedding, MHSA with W_O, additive attention (nrms_naml.py:152-158).
+        split = (order, n_real) from partition(): the kernel chain runs on the n_real sequences with a real token (gathered; their
+        dropout counters stay those of the full batch, desc.seq_index), the all-padding ones take the closed form."""
+        N, L = ids.shape
+        d = self.dims.word_embed_size
         if out is None:
-            out = torch.empty(N, self.dims.word_embed_size, dtype=torch.float32, device=self.device)
-        desc = self._desc("news_encoder", N, L, p_attn, seed)
-        acts = self._acts(tag, desc, gather=True)
+            out = torch.empty(N, d, dtype=torch.float32, device=self.device)
         w = self._ptrs(_lib.EncoderWeights, flat, "news_encoder")
-        rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), _lib.ptr(ids), None, None, C.byref(acts), _lib.ptr(out), _stream())
-        _lib.check(rc, "nrms_encoder_fwd(%s)" % tag)
+        if split is None:
+            desc = self._desc("news_encoder", N, L, p_attn, seed)
+            acts = self._acts(tag, desc, gather=True)
+            rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), _lib.ptr(ids), None, None, C.byref(acts), _lib.ptr(out), _stream())
+            _lib.check(rc, "nrms_encoder_fwd(%s)" % tag)
+            return out
+        order, n_real = split
+        n_empty = N - n_real
+        if n_real:
+            rows = order[:n_real].to(torch.int64)
+            ids_c = self._buf(tag + ".ids_c", N * L, torch.int64)[:n_real * L].view(n_real, L)
+            torch.index_select(ids, 0, rows, out=ids_c)
+            desc = self._desc("news_encoder", n_real, L, p_attn, seed)
+            desc.seq_index = order.data_ptr()
+            acts = self._acts(tag, desc, gather=True)
+            out_c = self._buf(tag + ".out_c", N * d)[:n_real * d].view(n_real, d)
+            rc = self.lib.nrms_encoder_fwd(C.byref(desc), C.byref(w), _lib.ptr(ids_c), None, None, C.byref(acts), _lib.ptr(out_c), _stream())
+            _lib.check(rc, "nrms_encoder_fwd(%s)" % tag)
+            out.index_copy_(0, rows, out_c)
+        if n_empty:
+            elist = order[N:N + n_empty]
+            desc_e = self._desc("news_encoder", n_empty, L, p_attn, seed)
+            ews = self._empty_ws(desc_e)
+            out_e = self._buf(tag + ".out_e", N * d)[:n_empty * d].view(n_empty, d)
+            rc = self.lib.nrms_encoder_empty_fwd(C.byref(desc_e), C.byref(w), _lib.ptr(elist), _lib.ptr(out_e), _lib.ptr(ews),
+                                                 C.c_size_t(ews.numel() * 4), _stream())
+            _lib.check(rc, "nrms_encoder_empty_fwd(%s)" % tag)
+            out.index_copy_(0, elist.to(torch.int64), out_e)
         return out
+
+    def _empty_ws(self, desc_e):
+        nb = int(self.lib.nrms_encoder_empty_workspace_bytes(C.byref(desc_e)))
+        if nb == 0:
+            _lib.check(-1, "nrms_encoder_empty_workspace_bytes")
+        return self._buf("empty_ws", (nb + 3) // 4 + 64)
+
+    def encode_text_backward(self, flat, gflat, ids, tag, dout, p_attn, seed, ws, split=None):
+        """Backward of encode_text (training forward): accumulates the word-level encoder's gradients into gflat."""
+        N, L = ids.shape
+        wn, gn = self._ptrs(_lib.EncoderWeights, flat, "news_encoder"), self._ptrs(_lib.EncoderGrads, gflat, "news_encoder")
+        if split is None:
+            desc = self._desc("news_encoder", N, L, p_attn, seed)
+            rc = self.lib.nrms_encoder_bwd(C.byref(desc), C.byref(wn), _lib.ptr(ids), None, None, C.byref(self._acts(tag, desc, gather=True)),
+                                           _lib.ptr(dout), C.byref(gn), None, _lib.ptr(ws), C.c_size_t(ws.numel() * 4), _stream())
+            _lib.check(rc, "nrms_encoder_bwd(%s)" % tag)
+            return
+        order, n_real = split
+        n_empty = N - n_real
+        d = self.dims.word_embed_size
+        if n_real:
+            rows = order[:n_real].to(torch.int64)
+            ids_c = self._buf(tag + ".ids_c", N * L, torch.int64)[:n_real * L].view(n_real, L)      # (as the forward left it)
+            dout_c = self._buf(tag + ".dout_c", N * d)[:n_real * d].view(n_real, d)
+            torch.index_select(dout, 0, rows, out=dout_c)
+            desc = self._desc("news_encoder", n_real, L, p_attn, seed)
+            desc.seq_index = order.data_ptr()
+            rc = self.lib.nrms_encoder_bwd(C.byref(desc), C.byref(wn), _lib.ptr(ids_c), None, None, C.byref(self._acts(tag, desc, gather=True)),
+                                           _lib.ptr(dout_c), C.byref(gn), None, _lib.ptr(ws), C.c_size_t(ws.numel() * 4), _stream())
+            _lib.check(rc, "nrms_encoder_bwd(%s)" % tag)
+        if n_empty:
+            elist = order[N:N + n_empty]
+            dout_e = self._buf(tag + ".dout_e", N * d)[:n_empty * d].view(n_empty, d)
+            torch.index_select(dout, 0, elist.to(torch.int64), out=dout_e)
+            desc_e = self._desc("news_encoder", n_empty, L, p_attn, seed)
+            ews = self._empty_ws(desc_e)
+            rc = self.lib.nrms_encoder_empty_bwd(C.byref(desc_e), C.byref(wn), _lib.ptr(elist), _lib.ptr(dout_e), C.byref(gn), _lib.ptr(ews),
+                                                 C.c_size_t(ews.numel() * 4), _stream())
+            _lib.check(rc, "nrms_encoder_empty_bwd(%s)" % tag)
 
     def _features_desc(self, flat, n, tv, av, categ, subcateg, p_drop, seed):
         d = self.dims
@@ -186,8 +270,16 @@ class NamlEngine(NRMSEngine):
         d = self.dims
         tv = self._buf("title_vec" + sfx, N * d.word_embed_size)[:N * d.word_embed_size].view(N, -1)
         av = self._buf("abst_vec" + sfx, N * d.word_embed_size)[:N * d.word_embed_size].view(N, -1)
-        self.encode_text(flat, ids_t, "title" + sfx, p_drop, seed, out=tv)
-        self.encode_text(flat, ids_a, "abst" + sfx, p_drop, seed ^ 0x5DEECE66D1CE4E5B, out=av)
+        split_t = split_a = None
+        if self._split_ok(ids_t.shape[1]) and self._split_ok(ids_a.shape[1]):
+            # the lists of both passes, then ONE read of their sizes (the only host synchronisation of the step: the chain's grids
+            # are sized by the number of sequences that hold a real token)
+            (ot, ct), (oa, ca) = self.partition(ids_t, "title" + sfx), self.partition(ids_a, "abst" + sfx)
+            n_t, n_a = (int(v) for v in torch.stack([ct[0], ca[0]]).cpu())
+            split_t, split_a = (ot, n_t), (oa, n_a)
+        self.last_split = (split_t, split_a)
+        self.encode_text(flat, ids_t, "title" + sfx, p_drop, seed, out=tv, split=split_t)
+        self.encode_text(flat, ids_a, "abst" + sfx, p_drop, seed ^ 0x5DEECE66D1CE4E5B, out=av, split=split_a)
         if out is None:
             out = torch.empty(N, d.news_feature_size, dtype=torch.float32, device=self.device)
         f = self._features_desc(flat, N, tv, av, categ, subcateg, p_drop, seed)
@@ -277,7 +369,8 @@ class NamlEngine(NRMSEngine):
         if training:
             self._gen += 1
             self._saved = dict(B=B, H=H, C=Cn, N=N, ids_t=ids_t, ids_a=ids_a, categ=categ, subcateg=subcateg, feat=feat,
-                               stats=stats, normed=normed, user=user, mask=cand_mask, p=float(p_drop), seed=seed, gen=self._gen)
+                               stats=stats, normed=normed, user=user, mask=cand_mask, p=float(p_drop), seed=seed, gen=self._gen,
+                               split=self.last_split)
         return scores
 
     def _forward_dedup(self, flat, dims, ids_t, ids_a, categ, subcateg, cand_mask):
@@ -347,11 +440,8 @@ class NamlEngine(NRMSEngine):
                                              C.c_void_p(gb + 4 * self._off("news_encoder.subcategory_embedding.weight")), _stream())
         _lib.check(rc, "nrms_news_features_bwd")
         # the two passes of the word-level encoder accumulate into the same weight and table gradients
-        wn, gn = self._ptrs(_lib.EncoderWeights, flat, "news_encoder"), self._ptrs(_lib.EncoderGrads, gflat, "news_encoder")
-        for tag, desc, ids, dout in (("title", desc_t, sv["ids_t"], dtv), ("abst", desc_a, sv["ids_a"], dav)):
-            rc = self.lib.nrms_encoder_bwd(C.byref(desc), C.byref(wn), _lib.ptr(ids), None, None,
-                                           C.byref(self._acts(tag, desc, gather=True)), _lib.ptr(dout), C.byref(gn), None,
-                                           _lib.ptr(ws), C.c_size_t(ws.numel() * 4), _stream())
-            _lib.check(rc, "nrms_encoder_bwd(%s)" % tag)
+        split_t, split_a = sv["split"]
+        self.encode_text_backward(flat, gflat, sv["ids_t"], "title", dtv, p, seed, ws, split_t)
+        self.encode_text_backward(flat, gflat, sv["ids_a"], "abst", dav, p, seed ^ 0x5DEECE66D1CE4E5B, ws, split_a)
         if table_grad_ready is not None:
             table_grad_ready()
