@@ -370,10 +370,13 @@ int nrms_csr_from_padded(int64_t n_seg, int32_t K, const int64_t* lists, int64_t
 size_t nrms_sequence_partition_count_ints(int32_t n_seq);
 int nrms_sequence_partition(const int64_t* ids, int32_t n_seq, int32_t seq_len, int32_t* order /* [2 * n_seq] */, int32_t* counts, void* stream);
 size_t nrms_encoder_empty_workspace_bytes(const nrms_encoder_desc* desc);
+size_t nrms_encoder_empty_saved_bytes(const nrms_encoder_desc* desc);
+/* saved: nrms_encoder_empty_saved_bytes(desc) bytes that the forward fills (the rows' kept-key factors and pooling weights) and the
+ * backward of the same sequences reads; null in the forward = inference. */
 int nrms_encoder_empty_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int32_t* seq_index, float* out,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           void* saved, void* workspace, size_t workspace_bytes, void* stream);
 int nrms_encoder_empty_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int32_t* seq_index, const float* dout,
-                           const nrms_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+                           const void* saved, const nrms_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Index side of a HieRec-style hierarchical interest model (BASELINE configs[3]; SURVEY f-4; PARITY UNPINNED: no reference
  * implementation, checked against oracle/segpool_oracle.py).  A user's clicked news (H <= 64 history slots, `valid` = the

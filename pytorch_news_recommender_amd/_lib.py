@@ -103,9 +103,11 @@ SIGNATURES = {
     "nrms_sequence_partition_count_ints": (C.c_size_t, [C.c_int32]),
     "nrms_sequence_partition": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_encoder_empty_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
-    "nrms_encoder_empty_fwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "nrms_encoder_empty_bwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.POINTER(EncoderGrads), C.c_void_p,
-                                         C.c_size_t, C.c_void_p]),
+    "nrms_encoder_empty_saved_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
+    "nrms_encoder_empty_fwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    "nrms_encoder_empty_bwd": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(EncoderGrads),
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
     "nrms_csr_from_padded": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_hier_add_embedding_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "nrms_hier_add_embedding_bwd": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -17,7 +17,7 @@
 // rows.  The caller runs the chain on the other sequences (compacted, with desc.seq_index so that their dropout counters stay those
 // of the full batch) and this file on the all-padding ones.  The dropout decisions are the attention kernel's own (site 2, element
 // ((seq * h + head) * S + i) * S + j of the FULL batch's numbering): nrms_dropout_keep_mask replays them for the oracle.
-// One wave per sequence, fp32 FMA arithmetic; partial sums per wave, added in a fixed order.
+// One wave per sequence, fp32 FMA arithmetic; partial sums per workgroup, added in a fixed order.
 #include "common.h"
 
 namespace nrms {
@@ -36,7 +36,9 @@ struct EmptyArgs {
     const float* q_vec;
     float* out;                     // forward  [n_seq][d]
     const float* dout;              // backward [n_seq][d]
-    float* partial;                 // backward [n_waves][(h + 1) q + q + (h + 1) d]
+    float* partial;                 // backward [n_workgroups][(h + 1) q + q]
+    float* saved;                   // [n_seq][64][EM_HMAX + 1]: c_i0 .. c_i7, w_i of every row (forward writes, backward reads; null: inference)
+    float* saved_wc;                // [n_seq][EM_HMAX]: sum_i w_i c_ih
 };
 
 // consts: u_h = W_O[:, head h] b_v^(h);  v_h = W_add u_h (h = 1 .. H), v_0 = W_add b_O + b_add.  One workgroup.
@@ -52,12 +54,14 @@ __global__ __launch_bounds__(1024) void empty_consts_kernel(int d, int h, int dk
     }
     __threadfence_block();
     __syncthreads();
-    for (int i = threadIdx.x; i < (h + 1) * q; i += 1024) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < (h + 1) * q; i += 16) {                        // a wave per output: coalesced rows of W_add
         const int hh = i / q, n = i - hh * q;
         const float* x = hh == 0 ? b_o : u + (long)(hh - 1) * d;
-        float acc = hh == 0 ? b_add[n] : 0.f;
-        for (int o = 0; o < d; ++o) acc += w_add[(long)n * d + o] * x[o];
-        v[i] = acc;
+        float acc = 0.f;
+        for (int o = lane; o < d; o += 64) acc += w_add[(long)n * d + o] * x[o];
+        acc = wave_sum(acc);
+        if (lane == 0) v[i] = acc + (hh == 0 ? b_add[n] : 0.f);
     }
 }
 
@@ -79,18 +83,23 @@ __device__ __forceinline__ float empty_keep_factor(const Dropout& pd, long unit,
     return (float)cnt * pd.inv_keep / (float)S;
 }
 
+// tanh through one exponential: absolute error ~1e-7 (the rows it feeds are softmax logits and (1 - t^2) factors)
+__device__ __forceinline__ float em_tanh(float z) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * z)); }
+
 // shared by both directions: c (LDS [64][EM_HMAX], also returned for this lane's row), s_i -> w_i of this lane's row
 template <bool BWD>
 __device__ __forceinline__ void empty_rows(const EmptyArgs& a, long seq, int lane, float (*cs)[EM_HMAX], const float (&vreg)[EM_HMAX + 1][EM_QL],
                                            const float (&qv)[EM_QL], float (&c)[EM_HMAX], float& w_i) {
     const long sidx = a.seq_index != nullptr ? (long)a.seq_index[seq] : seq;
-#pragma unroll
-    for (int hh = 0; hh < EM_HMAX; ++hh) {
-        c[hh] = (hh < a.h && lane < a.S) ? empty_keep_factor(a.pd, sidx * a.h + hh, a.S, lane) : 0.f;
-        cs[lane][hh] = c[hh];
+    // the S * h (row, head) factors, spread over the 64 lanes (a row per lane would leave 44 lanes idle on a 20-word title)
+    for (int item = lane; item < 64 * EM_HMAX; item += 64) {
+        const int i = item / EM_HMAX, hh = item - i * EM_HMAX;
+        cs[i][hh] = (hh < a.h && i < a.S) ? empty_keep_factor(a.pd, sidx * a.h + hh, a.S, i) : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int hh = 0; hh < EM_HMAX; ++hh) c[hh] = cs[lane][hh];
     float s_mine = -3.0e38f;
     for (int i = 0; i < a.S; ++i) {
         float part = 0.f;
@@ -101,7 +110,7 @@ __device__ __forceinline__ void empty_rows(const EmptyArgs& a, long seq, int lan
 #pragma unroll
                 for (int hh = 0; hh < EM_HMAX; ++hh)
                     if (hh < a.h) z += cs[i][hh] * vreg[hh + 1][j];
-                part += tanhf(z) * qv[j];
+                part += em_tanh(z) * qv[j];
             }
         }
         part = wave_sum(part);
@@ -146,44 +155,55 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_fwd_kernel(EmptyArgs a) {
                 a.out[seq * a.d + o] = y;
             }
         }
+        if (a.saved != nullptr) {
+            // for the backward: [c_i0 .. c_i7 | w_i] per row, [sum_i w_i c_ih] per sequence (Philox and the softmax are not redone)
+            float* sv = a.saved + (seq * 64 + lane) * (EM_HMAX + 1);
+#pragma unroll
+            for (int hh = 0; hh < EM_HMAX; ++hh) sv[hh] = c[hh];
+            sv[EM_HMAX] = w_i;
+            if (lane < EM_HMAX) a.saved_wc[seq * EM_HMAX + lane] = lane == 0 ? wc[0] : (lane == 1 ? wc[1] : (lane == 2 ? wc[2] : (lane == 3 ? wc[3] :
+                                                                     (lane == 4 ? wc[4] : (lane == 5 ? wc[5] : (lane == 6 ? wc[6] : wc[7]))))));
+        }
         __builtin_amdgcn_wave_barrier();                                 // cs is rewritten by the next sequence
     }
 }
 
+// A_h += c_ih dZ_i, A_0 += dZ_i, d(q_vec) += ds_i t_i over this workgroup's sequences (t recomputed from the saved factors)
 __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
     __shared__ float cs_all[EM_WPB][64][EM_HMAX];
     __shared__ float ds_all[EM_WPB][64];
+    __shared__ float acc_s[(EM_HMAX + 1) * 64 * EM_QL + 64 * EM_QL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*cs)[EM_HMAX] = cs_all[wave];
     float* dsb = ds_all[wave];
     float vreg[EM_HMAX + 1][EM_QL], qv[EM_QL];
     empty_load_consts(a, lane, vreg, qv);
-    float A[EM_HMAX + 1][EM_QL], dqv[EM_QL], G[EM_HMAX + 1][EM_DL];
+    float A[EM_HMAX + 1][EM_QL], dqv[EM_QL];
 #pragma unroll
-    for (int hh = 0; hh <= EM_HMAX; ++hh) {
+    for (int hh = 0; hh <= EM_HMAX; ++hh)
 #pragma unroll
         for (int j = 0; j < EM_QL; ++j) A[hh][j] = 0.f;
 #pragma unroll
-        for (int j = 0; j < EM_DL; ++j) G[hh][j] = 0.f;
-    }
-#pragma unroll
     for (int j = 0; j < EM_QL; ++j) dqv[j] = 0.f;
     for (long seq = (long)blockIdx.x * EM_WPB + wave; seq < a.n_seq; seq += (long)gridDim.x * EM_WPB) {
-        float c[EM_HMAX], w_i;
-        empty_rows<true>(a, seq, lane, cs, vreg, qv, c, w_i);
-        // g = d(out) of this sequence; <g, u_h>, <g, b_O>
-        float g[EM_DL], gu[EM_HMAX + 1];
+        const float* sv = a.saved + (seq * 64 + lane) * (EM_HMAX + 1);
+        float c[EM_HMAX];
+#pragma unroll
+        for (int hh = 0; hh < EM_HMAX; ++hh) { c[hh] = sv[hh]; cs[lane][hh] = c[hh]; }
+        const float w_i = sv[EM_HMAX];
+        // <g, u_h>, <g, b_O> with g = d(out) of this sequence
+        float gu[EM_HMAX + 1];
 #pragma unroll
         for (int hh = 0; hh <= EM_HMAX; ++hh) gu[hh] = 0.f;
 #pragma unroll
         for (int j = 0; j < EM_DL; ++j) {
             const int o = lane + 64 * j;
-            g[j] = o < a.d ? a.dout[seq * a.d + o] : 0.f;
             if (o < a.d) {
-                gu[0] += g[j] * a.b_o[o];
+                const float g = a.dout[seq * a.d + o];
+                gu[0] += g * a.b_o[o];
 #pragma unroll
                 for (int hh = 0; hh < EM_HMAX; ++hh)
-                    if (hh < a.h) gu[hh + 1] += g[j] * a.consts[(long)hh * a.d + o];
+                    if (hh < a.h) gu[hh + 1] += g * a.consts[(long)hh * a.d + o];
             }
         }
 #pragma unroll
@@ -194,18 +214,9 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
         for (int hh = 0; hh < EM_HMAX; ++hh) dw += c[hh] * gu[hh + 1];
         const float sumwd = wave_sum(w_i * dw);
         dsb[lane] = w_i * (dw - sumwd);                                  // 0 beyond the sequence (w_i = 0)
-        // G_h += (sum_i w_i c_ih) g, G_0 += g
-#pragma unroll
-        for (int hh = 0; hh < EM_HMAX; ++hh) {
-            const float wc = hh < a.h ? wave_sum(w_i * c[hh]) : 0.f;
-#pragma unroll
-            for (int j = 0; j < EM_DL; ++j) G[hh + 1][j] += wc * g[j];
-        }
-#pragma unroll
-        for (int j = 0; j < EM_DL; ++j) G[0][j] += g[j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // dZ_i = ds_i q_vec (1 - t_i^2) with t recomputed; A_h += c_ih dZ_i, A_0 += dZ_i, d(q_vec) += ds_i t_i   (lanes = columns)
+        // dZ_i = ds_i q_vec (1 - t_i^2); lanes = columns
         for (int i = 0; i < a.S; ++i) {
             const float ds = dsb[i];
 #pragma unroll
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
 #pragma unroll
                     for (int hh = 0; hh < EM_HMAX; ++hh)
                         if (hh < a.h) z += cs[i][hh] * vreg[hh + 1][j];
-                    const float t = tanhf(z);
+                    const float t = em_tanh(z);
                     const float dz = ds * qv[j] * (1.0f - t * t);
                     dqv[j] += ds * t;
                     A[0][j] += dz;
@@ -227,25 +238,47 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // this wave's share: [A_0 .. A_h | d(q_vec) | G_0 .. G_h]
-    float* out = a.partial + ((long)blockIdx.x * EM_WPB + wave) * ((long)(a.h + 1) * a.q + a.q + (long)(a.h + 1) * a.d);
+    // the workgroup's share [A_0 .. A_h | d(q_vec)]: its four waves add theirs in wave order (LDS), one row per workgroup
+    const long share = (long)(a.h + 1) * a.q + a.q;
+    for (int wv = 0; wv < EM_WPB; ++wv) {
+        if (wave == wv) {
 #pragma unroll
-    for (int hh = 0; hh <= EM_HMAX; ++hh) {
-        if (hh <= a.h) {
+            for (int hh = 0; hh <= EM_HMAX; ++hh) {
+                if (hh <= a.h) {
 #pragma unroll
-            for (int j = 0; j < EM_QL; ++j) { const int n = lane + 64 * j; if (n < a.q) out[(long)hh * a.q + n] = A[hh][j]; }
+                    for (int j = 0; j < EM_QL; ++j) {
+                        const int n = lane + 64 * j;
+                        if (n < a.q) { float* o = acc_s + (long)hh * a.q + n; *o = wv == 0 ? A[hh][j] : *o + A[hh][j]; }
+                    }
+                }
+            }
+            float* o2 = acc_s + (long)(a.h + 1) * a.q;
+#pragma unroll
+            for (int j = 0; j < EM_QL; ++j) { const int n = lane + 64 * j; if (n < a.q) o2[n] = wv == 0 ? dqv[j] : o2[n] + dqv[j]; }
         }
+        __syncthreads();
     }
-    float* o2 = out + (long)(a.h + 1) * a.q;
+    float* out = a.partial + (long)blockIdx.x * share;
+    for (long e = threadIdx.x; e < share; e += 64 * EM_WPB) out[e] = acc_s[e];
+}
+
+// G_0 = sum_seq g, G_h = sum_seq (sum_i w_i c_ih) g: workgroup b adds the sequences of its chunk in order, thread = column
+__global__ __launch_bounds__(512) void empty_g_kernel(int n_seq, int chunk, int d, int h, const float* wc, const float* dout, float* partial) {
+    const int o = threadIdx.x;
+    const int s0 = blockIdx.x * chunk, s1 = min(s0 + chunk, n_seq);
+    float acc[EM_HMAX + 1];
 #pragma unroll
-    for (int j = 0; j < EM_QL; ++j) { const int n = lane + 64 * j; if (n < a.q) o2[n] = dqv[j]; }
-    float* o3 = o2 + a.q;
+    for (int hh = 0; hh <= EM_HMAX; ++hh) acc[hh] = 0.f;
+    if (o < d) {
+        for (int s = s0; s < s1; ++s) {
+            const float g = dout[(long)s * d + o];
+            acc[0] += g;
 #pragma unroll
-    for (int hh = 0; hh <= EM_HMAX; ++hh) {
-        if (hh <= a.h) {
-#pragma unroll
-            for (int j = 0; j < EM_DL; ++j) { const int o = lane + 64 * j; if (o < a.d) o3[(long)hh * a.d + o] = G[hh][j]; }
+            for (int hh = 0; hh < EM_HMAX; ++hh) acc[hh + 1] += wc[(long)s * EM_HMAX + hh] * g;
         }
+#pragma unroll
+        for (int hh = 0; hh <= EM_HMAX; ++hh)
+            if (hh <= h) partial[((long)blockIdx.x * (h + 1) + hh) * d + o] = acc[hh];
     }
 }
 
@@ -299,7 +332,7 @@ __global__ __launch_bounds__(256) void empty_update_kernel(int d, int h, int dk,
     }
 }
 
-struct EmptyWs { size_t consts, partial, red, D, total; int n_wg; long share; };
+struct EmptyWs { size_t consts, partial, partial_g, red, D, total; int n_wg, n_wg_fwd, n_chunks, chunk; long share, share_a; };
 static size_t em_up256(size_t x) { return (x + 255) / 256 * 256; }
 static EmptyWs empty_layout(const nrms_encoder_desc* d) {
     EmptyWs w;
@@ -308,9 +341,15 @@ static EmptyWs empty_layout(const nrms_encoder_desc* d) {
     const int h = d->n_heads;
     w.share = (long)(h + 1) * d->q_dim + d->q_dim + (long)(h + 1) * d->d_model;
     const int want = (d->n_seq + EM_WPB - 1) / EM_WPB;
-    w.n_wg = want < 1 ? 1 : (want > 256 ? 256 : want);
+    w.n_wg = want < 1 ? 1 : (want > 1024 ? 1024 : want);                  // backward: one partial row per workgroup
+    w.n_wg_fwd = want < 1 ? 1 : (want > 4096 ? 4096 : want);
     w.consts = take(((size_t)h * d->d_model + (size_t)(h + 1) * d->q_dim) * 4);
-    w.partial = take((size_t)w.n_wg * EM_WPB * w.share * 4);
+    w.share_a = (long)(h + 1) * d->q_dim + d->q_dim;
+    w.n_chunks = d->n_seq < 256 ? (d->n_seq > 0 ? d->n_seq : 1) : 256;
+    w.chunk = (d->n_seq + w.n_chunks - 1) / w.n_chunks;
+    if (w.chunk < 1) w.chunk = 1;
+    w.partial = take((size_t)w.n_wg * w.share_a * 4);
+    w.partial_g = take((size_t)w.n_chunks * (h + 1) * d->d_model * 4);
     w.red = take((size_t)w.share * 4);
     w.D = take((size_t)(h + 1) * d->d_model * 4);
     w.total = off;
@@ -350,8 +389,13 @@ extern "C" size_t nrms_encoder_empty_workspace_bytes(const nrms_encoder_desc* de
     return empty_layout(desc).total;
 }
 
+extern "C" size_t nrms_encoder_empty_saved_bytes(const nrms_encoder_desc* desc) {
+    if (empty_validate(desc, "encoder_empty_saved_bytes")) return 0;
+    return ((size_t)desc->n_seq * 64 * (EM_HMAX + 1) + (size_t)desc->n_seq * EM_HMAX) * sizeof(float);
+}
+
 extern "C" int nrms_encoder_empty_fwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int32_t* seq_index, float* out,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+                                      void* saved, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = empty_validate(desc, "encoder_empty_fwd");
     if (rc) return rc;
     if (desc->n_seq == 0) return NRMS_OK;
@@ -364,16 +408,20 @@ extern "C" int nrms_encoder_empty_fwd(const nrms_encoder_desc* desc, const nrms_
     rc = empty_args(&a, desc, w, seq_index, (char*)workspace, L, s);
     if (rc) return rc;
     a.out = out;
-    hipLaunchKernelGGL(empty_fwd_kernel, dim3(L.n_wg), dim3(64 * EM_WPB), 0, s, a);
+    a.saved = (float*)saved;
+    a.saved_wc = saved != nullptr ? (float*)saved + (size_t)desc->n_seq * 64 * (EM_HMAX + 1) : nullptr;
+    hipLaunchKernelGGL(empty_fwd_kernel, dim3(L.n_wg_fwd), dim3(64 * EM_WPB), 0, s, a);
     return check_launch("encoder_empty_fwd");
 }
 
 extern "C" int nrms_encoder_empty_bwd(const nrms_encoder_desc* desc, const nrms_encoder_weights* w, const int32_t* seq_index,
-                                      const float* dout, const nrms_encoder_grads* g, void* workspace, size_t workspace_bytes, void* stream) {
+                                      const float* dout, const void* saved, const nrms_encoder_grads* g, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
     int rc = empty_validate(desc, "encoder_empty_bwd");
     if (rc) return rc;
     if (desc->n_seq == 0) return NRMS_OK;
     NRMS_REQUIRE(w && w->b_qkv && w->w_o && w->b_o && w->w_add && w->b_add && w->q_vec && dout, "encoder_empty_bwd: null argument");
+    NRMS_REQUIRE(saved != nullptr, "encoder_empty_bwd: `saved` (what nrms_encoder_empty_fwd wrote for these sequences) is required");
     NRMS_REQUIRE(g && g->b_qkv && g->w_o && g->b_o && g->w_add && g->b_add && g->q_vec, "encoder_empty_bwd: null gradient buffer");
     const EmptyWs L = empty_layout(desc);
     if (workspace == nullptr || workspace_bytes < L.total) { set_error("encoder_empty_bwd: workspace %zu < required %zu bytes", workspace_bytes, L.total); return NRMS_EWORKSPACE; }
@@ -388,8 +436,14 @@ extern "C" int nrms_encoder_empty_bwd(const nrms_encoder_desc* desc, const nrms_
     const int d = a.d, h = a.h, dk = a.dk, q = a.q;
     float* red = (float*)(base + L.red);
     float* D = (float*)(base + L.D);
+    a.saved = (float*)saved;
+    a.saved_wc = (float*)saved + (size_t)desc->n_seq * 64 * (EM_HMAX + 1);
+    float* part_g = (float*)(base + L.partial_g);
     hipLaunchKernelGGL(empty_bwd_kernel, dim3(L.n_wg), dim3(64 * EM_WPB), 0, s, a);
-    hipLaunchKernelGGL(empty_reduce_kernel, dim3((unsigned)((L.share + 255) / 256)), dim3(256), 0, s, L.share, L.n_wg * EM_WPB, (const float*)a.partial, red);
+    hipLaunchKernelGGL(empty_g_kernel, dim3(L.n_chunks), dim3(512), 0, s, desc->n_seq, L.chunk, d, h, (const float*)a.saved_wc, dout, part_g);
+    hipLaunchKernelGGL(empty_reduce_kernel, dim3((unsigned)((L.share_a + 255) / 256)), dim3(256), 0, s, L.share_a, L.n_wg, (const float*)a.partial, red);
+    const long share_g = (long)(h + 1) * d;
+    hipLaunchKernelGGL(empty_reduce_kernel, dim3((unsigned)((share_g + 255) / 256)), dim3(256), 0, s, share_g, L.n_chunks, (const float*)part_g, red + L.share_a);
     hipLaunchKernelGGL(empty_finish_kernel, dim3(1), dim3(1024), 0, s, d, h, dk, q, (const float*)red, w->w_add, w->w_o, D, g->b_o, g->b_add, g->q_vec,
                        g->b_qkv + 2 * (long)d);
     const long n_upd = (long)q * d + (long)d * d;

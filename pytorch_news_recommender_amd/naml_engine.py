@@ -208,7 +208,8 @@ class NamlEngine(NRMSEngine):
             desc_e = self._desc("news_encoder", n_empty, L, p_attn, seed)
             ews = self._empty_ws(desc_e)
             out_e = self._buf(tag + ".out_e", N * d)[:n_empty * d].view(n_empty, d)
-            rc = self.lib.nrms_encoder_empty_fwd(C.byref(desc_e), C.byref(w), _lib.ptr(elist), _lib.ptr(out_e), _lib.ptr(ews),
+            saved = self._buf(tag + ".empty_saved", (int(self.lib.nrms_encoder_empty_saved_bytes(C.byref(desc_e))) + 3) // 4)
+            rc = self.lib.nrms_encoder_empty_fwd(C.byref(desc_e), C.byref(w), _lib.ptr(elist), _lib.ptr(out_e), _lib.ptr(saved), _lib.ptr(ews),
                                                  C.c_size_t(ews.numel() * 4), _stream())
             _lib.check(rc, "nrms_encoder_empty_fwd(%s)" % tag)
             out.index_copy_(0, elist.to(torch.int64), out_e)
@@ -249,8 +250,9 @@ class NamlEngine(NRMSEngine):
             torch.index_select(dout, 0, elist.to(torch.int64), out=dout_e)
             desc_e = self._desc("news_encoder", n_empty, L, p_attn, seed)
             ews = self._empty_ws(desc_e)
-            rc = self.lib.nrms_encoder_empty_bwd(C.byref(desc_e), C.byref(wn), _lib.ptr(elist), _lib.ptr(dout_e), C.byref(gn), _lib.ptr(ews),
-                                                 C.c_size_t(ews.numel() * 4), _stream())
+            saved = self._buf(tag + ".empty_saved", (int(self.lib.nrms_encoder_empty_saved_bytes(C.byref(desc_e))) + 3) // 4)   # (as the forward left it)
+            rc = self.lib.nrms_encoder_empty_bwd(C.byref(desc_e), C.byref(wn), _lib.ptr(elist), _lib.ptr(dout_e), _lib.ptr(saved), C.byref(gn),
+                                                 _lib.ptr(ews), C.c_size_t(ews.numel() * 4), _stream())
             _lib.check(rc, "nrms_encoder_empty_bwd(%s)" % tag)
 
     def _features_desc(self, flat, n, tv, av, categ, subcateg, p_drop, seed):

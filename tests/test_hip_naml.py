@@ -345,11 +345,16 @@ def test_all_padding_closed_form_equals_the_chain(geom, p):
     desc_e = eng._desc("news_encoder", n, S, p, seed)
     ews = eng._empty_ws(desc_e)
     out_e = torch.empty(n, d, device="cuda")
-    _lib.check(lib.nrms_encoder_empty_fwd(C.byref(desc_e), C.byref(w), _lib.ptr(sidx), _lib.ptr(out_e), _lib.ptr(ews), C.c_size_t(ews.numel() * 4),
-                                          stream), "empty_fwd")
+    saved = torch.empty(lib.nrms_encoder_empty_saved_bytes(C.byref(desc_e)) // 4, device="cuda")
+    _lib.check(lib.nrms_encoder_empty_fwd(C.byref(desc_e), C.byref(w), _lib.ptr(sidx), _lib.ptr(out_e), _lib.ptr(saved), _lib.ptr(ews),
+                                          C.c_size_t(ews.numel() * 4), stream), "empty_fwd")
+    out_inf = torch.empty(n, d, device="cuda")                 # inference form: nothing saved, same vectors
+    _lib.check(lib.nrms_encoder_empty_fwd(C.byref(desc_e), C.byref(w), _lib.ptr(sidx), _lib.ptr(out_inf), None, _lib.ptr(ews),
+                                          C.c_size_t(ews.numel() * 4), stream), "empty_fwd")
+    assert torch.equal(out_inf, out_e)
     g_e = torch.zeros_like(flat)
-    _lib.check(lib.nrms_encoder_empty_bwd(C.byref(desc_e), C.byref(w), _lib.ptr(sidx), _lib.ptr(dout), C.byref(eng._ptrs(_lib.EncoderGrads, g_e, "news_encoder")),
-                                          _lib.ptr(ews), C.c_size_t(ews.numel() * 4), stream), "empty_bwd")
+    _lib.check(lib.nrms_encoder_empty_bwd(C.byref(desc_e), C.byref(w), _lib.ptr(sidx), _lib.ptr(dout), _lib.ptr(saved),
+                                          C.byref(eng._ptrs(_lib.EncoderGrads, g_e, "news_encoder")), _lib.ptr(ews), C.c_size_t(ews.numel() * 4), stream), "empty_bwd")
     torch.cuda.synchronize()
     a, b = out_chain.cpu().numpy(), out_e.cpu().numpy()
     assert np.abs(a).max() > 1e-3
@@ -366,7 +371,7 @@ def test_all_padding_closed_form_equals_the_chain(geom, p):
         tol = 3e-5 * scale + 1e-8 if scale > 1e-6 else 1e-6
         assert np.abs(ga - gb).max() <= tol, (name, float(np.abs(ga - gb).max()), scale)
     # second call accumulates
-    _lib.check(lib.nrms_encoder_empty_bwd(C.byref(desc_e), C.byref(w), _lib.ptr(sidx), _lib.ptr(dout), C.byref(eng._ptrs(_lib.EncoderGrads, g_e, "news_encoder")),
-                                          _lib.ptr(ews), C.c_size_t(ews.numel() * 4), stream), "empty_bwd")
+    _lib.check(lib.nrms_encoder_empty_bwd(C.byref(desc_e), C.byref(w), _lib.ptr(sidx), _lib.ptr(dout), _lib.ptr(saved),
+                                          C.byref(eng._ptrs(_lib.EncoderGrads, g_e, "news_encoder")), _lib.ptr(ews), C.c_size_t(ews.numel() * 4), stream), "empty_bwd")
     n_wa = "news_encoder.additive_attention.linear.weight"
     assert np.allclose(lay.view(g_e, n_wa).cpu().numpy(), 2 * lay.view(g_chain, n_wa).cpu().numpy(), rtol=1e-4, atol=1e-7)

@@ -36,9 +36,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # field order / widths of the POD structs (x86-64 SysV): desc = 8 x 4 bytes + u64
-    assert ctypes.sizeof(_lib.EncoderDesc) == 64
-    assert _lib.EncoderDesc.seed.offset == 48 and _lib.EncoderDesc.loss_scale.offset == 56
+    # field order / widths of the POD structs (x86-64 SysV): desc = 12 x 4 bytes, u64, 2 x 4 bytes, one pointer
+    assert ctypes.sizeof(_lib.EncoderDesc) == 72
+    assert _lib.EncoderDesc.seed.offset == 48 and _lib.EncoderDesc.loss_scale.offset == 56 and _lib.EncoderDesc.seq_index.offset == 64
     assert ctypes.sizeof(_lib.EncoderWeights) == 64 and ctypes.sizeof(_lib.EncoderGrads) == 64
     assert ctypes.sizeof(_lib.EncoderActs) == 56
 
@@ -464,7 +464,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     str(src), "-o", str(exe), "-L", lib_dir, "-lnrms_hip", "-Wl,-rpath," + lib_dir,
                     "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], check=True, capture_output=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(None, 3)
-    assert int(out[0]) == ctypes.sizeof(_lib.EncoderDesc) == 64
+    assert int(out[0]) == ctypes.sizeof(_lib.EncoderDesc) == 72
     assert int(out[1]) > 4 * 120 * 300 * 4 and int(out[2]) == 0 and "seq_len" in out[3]
 
 

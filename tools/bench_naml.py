@@ -37,7 +37,7 @@ rows = []
 for name in ("qkv_proj_fwd", "out_proj_fwd", "attn_fwd", "attn_bwd", "wide_attn_fwd", "wide_attn_bwd", "addattn_fwd", "addattn_proj_fwd", "addattn_bwd_rows",
              "dctx_bwd", "dwadd_bwd", "dwo_bwd", "dattn_bwd", "dwqkv_bwd", "dx_bwd", "gather_dropout", "scatter_dropout",
              "features_fwd", "features_bwd", "layernorm_fwd", "layernorm_bwd", "colsum_add", "transpose", "permute_rows",
-             "split_planes", "compact_rows", "sanitize_ids", "click", "ce_loss", "adam", "tn_reduce"):
+             "split_planes", "empty_seq_fwd", "empty_seq_bwd", "title_order", "compact_rows", "sanitize_ids", "click", "ce_loss", "adam", "tn_reduce"):
     t, k = eng.timing_read(name)
     if k:
         rows.append((t / 3, name, k / 3))
