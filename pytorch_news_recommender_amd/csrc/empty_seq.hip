@@ -41,28 +41,29 @@ struct EmptyArgs {
     float* saved_wc;                // [n_seq][EM_HMAX]: sum_i w_i c_ih
 };
 
-// consts: u_h = W_O[:, head h] b_v^(h);  v_h = W_add u_h (h = 1 .. H), v_0 = W_add b_O + b_add.  One workgroup.
-__global__ __launch_bounds__(1024) void empty_consts_kernel(int d, int h, int dk, int q, const float* b_v, const float* w_o, const float* b_o,
-                                                            const float* w_add, const float* b_add, float* consts) {
-    float* u = consts;
-    float* v = consts + (long)h * d;
-    for (int i = threadIdx.x; i < h * d; i += 1024) {
-        const int hh = i / d, o = i - hh * d;
-        float acc = 0.f;
-        for (int j = 0; j < dk; ++j) acc += w_o[(long)o * d + hh * dk + j] * b_v[hh * dk + j];
-        u[i] = acc;
-    }
-    __threadfence_block();
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < (h + 1) * q; i += 16) {                        // a wave per output: coalesced rows of W_add
-        const int hh = i / q, n = i - hh * q;
-        const float* x = hh == 0 ? b_o : u + (long)(hh - 1) * d;
-        float acc = 0.f;
-        for (int o = lane; o < d; o += 64) acc += w_add[(long)n * d + o] * x[o];
-        acc = wave_sum(acc);
-        if (lane == 0) v[i] = acc + (hh == 0 ? b_add[n] : 0.f);
-    }
+// consts: u_h = W_O[:, head h] b_v^(h);  v_h = W_add u_h (h = 1 .. H), v_0 = W_add b_O + b_add
+__global__ __launch_bounds__(256) void empty_consts_u_kernel(int d, int h, int dk, const float* b_v, const float* w_o, float* u) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * d) return;
+    const int hh = i / d, o = i - hh * d;
+    const float* row = w_o + (long)o * d + hh * dk;
+    float a0 = 0.f, a1 = 0.f;
+    int j = 0;
+    for (; j + 2 <= dk; j += 2) { a0 += row[j] * b_v[hh * dk + j]; a1 += row[j + 1] * b_v[hh * dk + j + 1]; }
+    if (j < dk) a0 += row[j] * b_v[hh * dk + j];
+    u[i] = a0 + a1;
+}
+__global__ __launch_bounds__(1024) void empty_consts_v_kernel(int d, int h, int q, const float* u, const float* b_o, const float* w_add, const float* b_add,
+                                                              float* v) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 6);                   // a wave per output: coalesced rows of W_add
+    if (i >= (h + 1) * q) return;
+    const int hh = i / q, n = i - hh * q;
+    const float* x = hh == 0 ? b_o : u + (long)(hh - 1) * d;
+    float acc = 0.f;
+    for (int o = lane; o < d; o += 64) acc += w_add[(long)n * d + o] * x[o];
+    acc = wave_sum(acc);
+    if (lane == 0) v[i] = acc + (hh == 0 ? b_add[n] : 0.f);
 }
 
 // c_ih of this lane's row: the kept keys of query `row` in unit (seq, head) -- the attention kernel's counters (attention.hip,
@@ -87,7 +88,7 @@ __device__ __forceinline__ float empty_keep_factor(const Dropout& pd, long unit,
 __device__ __forceinline__ float em_tanh(float z) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * z)); }
 
 // shared by both directions: c (LDS [64][EM_HMAX], also returned for this lane's row), s_i -> w_i of this lane's row
-template <bool BWD>
+template <int HT>
 __device__ __forceinline__ void empty_rows(const EmptyArgs& a, long seq, int lane, float (*cs)[EM_HMAX], const float (&vreg)[EM_HMAX + 1][EM_QL],
                                            const float (&qv)[EM_QL], float (&c)[EM_HMAX], float& w_i) {
     const long sidx = a.seq_index != nullptr ? (long)a.seq_index[seq] : seq;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void empty_rows(const EmptyArgs& a, long seq, int lan
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int hh = 0; hh < EM_HMAX; ++hh) c[hh] = cs[lane][hh];
+    for (int hh = 0; hh < HT; ++hh) c[hh] = cs[lane][hh];
     float s_mine = -3.0e38f;
     for (int i = 0; i < a.S; ++i) {
         float part = 0.f;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void empty_rows(const EmptyArgs& a, long seq, int lan
             if (lane + 64 * j < a.q) {
                 float z = vreg[0][j];
 #pragma unroll
-                for (int hh = 0; hh < EM_HMAX; ++hh)
+                for (int hh = 0; hh < HT; ++hh)
                     if (hh < a.h) z += cs[i][hh] * vreg[hh + 1][j];
                 part += em_tanh(z) * qv[j];
             }
@@ -121,6 +122,7 @@ __device__ __forceinline__ void empty_rows(const EmptyArgs& a, long seq, int lan
     w_i = e / wave_sum(e);
 }
 
+template <int HT>
 __device__ __forceinline__ void empty_load_consts(const EmptyArgs& a, int lane, float (&vreg)[EM_HMAX + 1][EM_QL], float (&qv)[EM_QL]) {
     const float* v = a.consts + (long)a.h * a.d;
 #pragma unroll
@@ -128,29 +130,30 @@ __device__ __forceinline__ void empty_load_consts(const EmptyArgs& a, int lane, 
         const int n = lane + 64 * j;
         qv[j] = n < a.q ? a.q_vec[n] : 0.f;
 #pragma unroll
-        for (int hh = 0; hh <= EM_HMAX; ++hh) vreg[hh][j] = (n < a.q && hh <= a.h) ? v[(long)hh * a.q + n] : 0.f;
+        for (int hh = 0; hh <= HT; ++hh) vreg[hh][j] = (n < a.q && hh <= a.h) ? v[(long)hh * a.q + n] : 0.f;
     }
 }
 
+template <int HT>
 __global__ __launch_bounds__(64 * EM_WPB) void empty_fwd_kernel(EmptyArgs a) {
     __shared__ float cs_all[EM_WPB][64][EM_HMAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*cs)[EM_HMAX] = cs_all[wave];
     float vreg[EM_HMAX + 1][EM_QL], qv[EM_QL];
-    empty_load_consts(a, lane, vreg, qv);
+    empty_load_consts<HT>(a, lane, vreg, qv);
     for (long seq = (long)blockIdx.x * EM_WPB + wave; seq < a.n_seq; seq += (long)gridDim.x * EM_WPB) {
         float c[EM_HMAX], w_i;
-        empty_rows<false>(a, seq, lane, cs, vreg, qv, c, w_i);
+        empty_rows<HT>(a, seq, lane, cs, vreg, qv, c, w_i);
         float wc[EM_HMAX];
 #pragma unroll
-        for (int hh = 0; hh < EM_HMAX; ++hh) wc[hh] = hh < a.h ? wave_sum(w_i * c[hh]) : 0.f;
+        for (int hh = 0; hh < HT; ++hh) wc[hh] = hh < a.h ? wave_sum(w_i * c[hh]) : 0.f;
 #pragma unroll
         for (int j = 0; j < EM_DL; ++j) {
             const int o = lane + 64 * j;
             if (o < a.d) {
                 float y = a.b_o[o];
 #pragma unroll
-                for (int hh = 0; hh < EM_HMAX; ++hh)
+                for (int hh = 0; hh < HT; ++hh)
                     if (hh < a.h) y += wc[hh] * a.consts[(long)hh * a.d + o];
                 a.out[seq * a.d + o] = y;
             }
@@ -159,16 +162,21 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_fwd_kernel(EmptyArgs a) {
             // for the backward: [c_i0 .. c_i7 | w_i] per row, [sum_i w_i c_ih] per sequence (Philox and the softmax are not redone)
             float* sv = a.saved + (seq * 64 + lane) * (EM_HMAX + 1);
 #pragma unroll
-            for (int hh = 0; hh < EM_HMAX; ++hh) sv[hh] = c[hh];
+            for (int hh = 0; hh < EM_HMAX; ++hh) sv[hh] = hh < HT ? c[hh] : 0.f;
             sv[EM_HMAX] = w_i;
-            if (lane < EM_HMAX) a.saved_wc[seq * EM_HMAX + lane] = lane == 0 ? wc[0] : (lane == 1 ? wc[1] : (lane == 2 ? wc[2] : (lane == 3 ? wc[3] :
-                                                                     (lane == 4 ? wc[4] : (lane == 5 ? wc[5] : (lane == 6 ? wc[6] : wc[7]))))));
+            if (lane < EM_HMAX) {
+                float v = 0.f;
+#pragma unroll
+                for (int hh = 0; hh < HT; ++hh) v = lane == hh ? wc[hh] : v;
+                a.saved_wc[seq * EM_HMAX + lane] = v;
+            }
         }
         __builtin_amdgcn_wave_barrier();                                 // cs is rewritten by the next sequence
     }
 }
 
 // A_h += c_ih dZ_i, A_0 += dZ_i, d(q_vec) += ds_i t_i over this workgroup's sequences (t recomputed from the saved factors)
+template <int HT>
 __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
     __shared__ float cs_all[EM_WPB][64][EM_HMAX];
     __shared__ float ds_all[EM_WPB][64];
@@ -177,10 +185,10 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
     float (*cs)[EM_HMAX] = cs_all[wave];
     float* dsb = ds_all[wave];
     float vreg[EM_HMAX + 1][EM_QL], qv[EM_QL];
-    empty_load_consts(a, lane, vreg, qv);
+    empty_load_consts<HT>(a, lane, vreg, qv);
     float A[EM_HMAX + 1][EM_QL], dqv[EM_QL];
 #pragma unroll
-    for (int hh = 0; hh <= EM_HMAX; ++hh)
+    for (int hh = 0; hh <= HT; ++hh)
 #pragma unroll
         for (int j = 0; j < EM_QL; ++j) A[hh][j] = 0.f;
 #pragma unroll
@@ -189,12 +197,12 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
         const float* sv = a.saved + (seq * 64 + lane) * (EM_HMAX + 1);
         float c[EM_HMAX];
 #pragma unroll
-        for (int hh = 0; hh < EM_HMAX; ++hh) { c[hh] = sv[hh]; cs[lane][hh] = c[hh]; }
+        for (int hh = 0; hh < HT; ++hh) { c[hh] = sv[hh]; cs[lane][hh] = c[hh]; }
         const float w_i = sv[EM_HMAX];
         // <g, u_h>, <g, b_O> with g = d(out) of this sequence
         float gu[EM_HMAX + 1];
 #pragma unroll
-        for (int hh = 0; hh <= EM_HMAX; ++hh) gu[hh] = 0.f;
+        for (int hh = 0; hh <= HT; ++hh) gu[hh] = 0.f;
 #pragma unroll
         for (int j = 0; j < EM_DL; ++j) {
             const int o = lane + 64 * j;
@@ -202,16 +210,16 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
                 const float g = a.dout[seq * a.d + o];
                 gu[0] += g * a.b_o[o];
 #pragma unroll
-                for (int hh = 0; hh < EM_HMAX; ++hh)
+                for (int hh = 0; hh < HT; ++hh)
                     if (hh < a.h) gu[hh + 1] += g * a.consts[(long)hh * a.d + o];
             }
         }
 #pragma unroll
-        for (int hh = 0; hh <= EM_HMAX; ++hh) gu[hh] = hh <= a.h ? wave_sum(gu[hh]) : 0.f;
+        for (int hh = 0; hh <= HT; ++hh) gu[hh] = hh <= a.h ? wave_sum(gu[hh]) : 0.f;
         // softmax backward over the rows (lane = row)
         float dw = gu[0];
 #pragma unroll
-        for (int hh = 0; hh < EM_HMAX; ++hh) dw += c[hh] * gu[hh + 1];
+        for (int hh = 0; hh < HT; ++hh) dw += c[hh] * gu[hh + 1];
         const float sumwd = wave_sum(w_i * dw);
         dsb[lane] = w_i * (dw - sumwd);                                  // 0 beyond the sequence (w_i = 0)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -224,14 +232,14 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
                 if (lane + 64 * j < a.q) {
                     float z = vreg[0][j];
 #pragma unroll
-                    for (int hh = 0; hh < EM_HMAX; ++hh)
+                    for (int hh = 0; hh < HT; ++hh)
                         if (hh < a.h) z += cs[i][hh] * vreg[hh + 1][j];
                     const float t = em_tanh(z);
                     const float dz = ds * qv[j] * (1.0f - t * t);
                     dqv[j] += ds * t;
                     A[0][j] += dz;
 #pragma unroll
-                    for (int hh = 0; hh < EM_HMAX; ++hh)
+                    for (int hh = 0; hh < HT; ++hh)
                         if (hh < a.h) A[hh + 1][j] += cs[i][hh] * dz;
                 }
             }
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(64 * EM_WPB) void empty_bwd_kernel(EmptyArgs a) {
     for (int wv = 0; wv < EM_WPB; ++wv) {
         if (wave == wv) {
 #pragma unroll
-            for (int hh = 0; hh <= EM_HMAX; ++hh) {
+            for (int hh = 0; hh <= HT; ++hh) {
                 if (hh <= a.h) {
 #pragma unroll
                     for (int j = 0; j < EM_QL; ++j) {
@@ -282,36 +290,60 @@ __global__ __launch_bounds__(512) void empty_g_kernel(int n_seq, int chunk, int 
     }
 }
 
-// red[e] = sum over the waves' shares, ascending
-__global__ __launch_bounds__(256) void empty_reduce_kernel(long n_elems, int n_waves, const float* partial, float* red) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_elems) return;
-    float acc = 0.f;
-    for (int w = 0; w < n_waves; ++w) acc += partial[(long)w * n_elems + e];
-    red[e] = acc;
+// red[e] = sum over the workgroups' shares in a fixed association: four row quarters (four partial sums each, rows ascending), added
+// in quarter order.  Thread = (element, quarter): 64 elements per workgroup.
+__global__ __launch_bounds__(256) void empty_reduce_kernel(long n_elems, int n_rows, const float* partial, float* red) {
+    __shared__ float part[4][64];
+    const int el = threadIdx.x & 63, qt = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
+    const int per = (n_rows + 3) / 4;
+    const int r0 = qt * per, r1 = min(r0 + per, n_rows);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < n_elems) {
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            a0 += partial[(long)r * n_elems + e];
+            a1 += partial[(long)(r + 1) * n_elems + e];
+            a2 += partial[(long)(r + 2) * n_elems + e];
+            a3 += partial[(long)(r + 3) * n_elems + e];
+        }
+        for (; r < r1; ++r) a0 += partial[(long)r * n_elems + e];
+    }
+    part[qt][el] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (qt == 0 && e < n_elems) red[e] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
 }
 
-// D_h = G_h + W_add^T A_h (kept in `D` for the rank-1 updates); the bias gradients.  One workgroup.
-__global__ __launch_bounds__(1024) void empty_finish_kernel(int d, int h, int dk, int q, const float* red, const float* w_add, const float* w_o,
-                                                            float* D, float* db_o, float* db_add, float* dq_vec, float* db_v) {
-    const float* A = red;
-    const float* dqv = red + (long)(h + 1) * q;
-    const float* G = dqv + q;
-    for (int i = threadIdx.x; i < (h + 1) * d; i += 1024) {
-        const int hh = i / d, o = i - hh * d;
-        float acc = G[i];
-        for (int n = 0; n < q; ++n) acc += w_add[(long)n * d + o] * A[(long)hh * q + n];
-        D[i] = acc;
-        if (hh == 0) db_o[o] += acc;
+// D_h = G_h + W_add^T A_h (kept in `D` for the rank-1 updates), d(b_O) += D_0: workgroup = h, thread = column
+__global__ __launch_bounds__(512) void empty_d_kernel(int d, int q, const float* red, long g_off, const float* w_add, float* D, float* db_o) {
+    const int hh = blockIdx.x, o = threadIdx.x;
+    if (o >= d) return;
+    const float* A = red + (long)hh * q;
+    float a0 = red[g_off + (long)hh * d + o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int n = 0;
+    for (; n + 4 <= q; n += 4) {
+        a0 += w_add[(long)n * d + o] * A[n];
+        a1 += w_add[(long)(n + 1) * d + o] * A[n + 1];
+        a2 += w_add[(long)(n + 2) * d + o] * A[n + 2];
+        a3 += w_add[(long)(n + 3) * d + o] * A[n + 3];
     }
-    for (int n = threadIdx.x; n < q; n += 1024) { db_add[n] += A[n]; dq_vec[n] += dqv[n]; }
-    __threadfence_block();
-    __syncthreads();
-    for (int c = threadIdx.x; c < h * dk; c += 1024) {
-        const int hh = c / dk;
-        float acc = 0.f;
-        for (int o = 0; o < d; ++o) acc += w_o[(long)o * d + c] * D[(long)(hh + 1) * d + o];
-        db_v[c] += acc;
+    for (; n < q; ++n) a0 += w_add[(long)n * d + o] * A[n];
+    const float acc = (a0 + a1) + (a2 + a3);
+    D[(long)hh * d + o] = acc;
+    if (hh == 0) db_o[o] += acc;
+}
+// d(b_add) += A_0, d(q_vec) += sum ds t, d(b_v^(h)) += W_O[:, head h]^T D_h.  One workgroup.
+__global__ __launch_bounds__(512) void empty_finish_kernel(int d, int h, int dk, int q, const float* red, const float* w_o, const float* D, float* db_add,
+                                                           float* dq_vec, float* db_v) {
+    const float* dqv = red + (long)(h + 1) * q;
+    for (int n = threadIdx.x; n < q; n += 512) { db_add[n] += red[n]; dq_vec[n] += dqv[n]; }
+    for (int c = threadIdx.x; c < h * dk; c += 512) {
+        const float* Dh = D + (long)(c / dk + 1) * d;
+        float a0 = 0.f, a1 = 0.f;
+        int o = 0;
+        for (; o + 2 <= d; o += 2) { a0 += w_o[(long)o * d + c] * Dh[o]; a1 += w_o[(long)(o + 1) * d + c] * Dh[o + 1]; }
+        if (o < d) a0 += w_o[(long)o * d + c] * Dh[o];
+        db_v[c] += a0 + a1;
     }
 }
 
@@ -375,8 +407,10 @@ static int empty_args(EmptyArgs* a, const nrms_encoder_desc* desc, const nrms_en
     a->pd = make_dropout(desc->seed, desc->p_drop_attn);
     a->consts = (const float*)(base + L.consts);
     a->b_o = w->b_o; a->q_vec = w->q_vec;
-    hipLaunchKernelGGL(empty_consts_kernel, dim3(1), dim3(1024), 0, s, a->d, a->h, a->dk, a->q, w->b_qkv + 2 * (long)a->d, w->w_o, w->b_o, w->w_add,
-                       w->b_add, (float*)(base + L.consts));
+    float* u = (float*)(base + L.consts);
+    hipLaunchKernelGGL(empty_consts_u_kernel, dim3(cdiv((long)a->h * a->d, 256)), dim3(256), 0, s, a->d, a->h, a->dk, w->b_qkv + 2 * (long)a->d, w->w_o, u);
+    hipLaunchKernelGGL(empty_consts_v_kernel, dim3(cdiv((long)(a->h + 1) * a->q, 16)), dim3(1024), 0, s, a->d, a->h, a->q, (const float*)u, w->b_o, w->w_add,
+                       w->b_add, u + (long)a->h * a->d);
     return check_launch("encoder_empty(consts)");
 }
 
@@ -410,7 +444,12 @@ extern "C" int nrms_encoder_empty_fwd(const nrms_encoder_desc* desc, const nrms_
     a.out = out;
     a.saved = (float*)saved;
     a.saved_wc = saved != nullptr ? (float*)saved + (size_t)desc->n_seq * 64 * (EM_HMAX + 1) : nullptr;
-    hipLaunchKernelGGL(empty_fwd_kernel, dim3(L.n_wg_fwd), dim3(64 * EM_WPB), 0, s, a);
+    switch ((a.h + 1) / 2) {
+        case 1: hipLaunchKernelGGL(empty_fwd_kernel<2>, dim3(L.n_wg_fwd), dim3(64 * EM_WPB), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(empty_fwd_kernel<4>, dim3(L.n_wg_fwd), dim3(64 * EM_WPB), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(empty_fwd_kernel<6>, dim3(L.n_wg_fwd), dim3(64 * EM_WPB), 0, s, a); break;
+        default: hipLaunchKernelGGL(empty_fwd_kernel<8>, dim3(L.n_wg_fwd), dim3(64 * EM_WPB), 0, s, a); break;
+    }
     return check_launch("encoder_empty_fwd");
 }
 
@@ -439,12 +478,18 @@ extern "C" int nrms_encoder_empty_bwd(const nrms_encoder_desc* desc, const nrms_
     a.saved = (float*)saved;
     a.saved_wc = (float*)saved + (size_t)desc->n_seq * 64 * (EM_HMAX + 1);
     float* part_g = (float*)(base + L.partial_g);
-    hipLaunchKernelGGL(empty_bwd_kernel, dim3(L.n_wg), dim3(64 * EM_WPB), 0, s, a);
+    switch ((h + 1) / 2) {
+        case 1: hipLaunchKernelGGL(empty_bwd_kernel<2>, dim3(L.n_wg), dim3(64 * EM_WPB), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(empty_bwd_kernel<4>, dim3(L.n_wg), dim3(64 * EM_WPB), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(empty_bwd_kernel<6>, dim3(L.n_wg), dim3(64 * EM_WPB), 0, s, a); break;
+        default: hipLaunchKernelGGL(empty_bwd_kernel<8>, dim3(L.n_wg), dim3(64 * EM_WPB), 0, s, a); break;
+    }
     hipLaunchKernelGGL(empty_g_kernel, dim3(L.n_chunks), dim3(512), 0, s, desc->n_seq, L.chunk, d, h, (const float*)a.saved_wc, dout, part_g);
-    hipLaunchKernelGGL(empty_reduce_kernel, dim3((unsigned)((L.share_a + 255) / 256)), dim3(256), 0, s, L.share_a, L.n_wg, (const float*)a.partial, red);
+    hipLaunchKernelGGL(empty_reduce_kernel, dim3((unsigned)((L.share_a + 63) / 64)), dim3(256), 0, s, L.share_a, L.n_wg, (const float*)a.partial, red);
     const long share_g = (long)(h + 1) * d;
-    hipLaunchKernelGGL(empty_reduce_kernel, dim3((unsigned)((share_g + 255) / 256)), dim3(256), 0, s, share_g, L.n_chunks, (const float*)part_g, red + L.share_a);
-    hipLaunchKernelGGL(empty_finish_kernel, dim3(1), dim3(1024), 0, s, d, h, dk, q, (const float*)red, w->w_add, w->w_o, D, g->b_o, g->b_add, g->q_vec,
+    hipLaunchKernelGGL(empty_reduce_kernel, dim3((unsigned)((share_g + 63) / 64)), dim3(256), 0, s, share_g, L.n_chunks, (const float*)part_g, red + L.share_a);
+    hipLaunchKernelGGL(empty_d_kernel, dim3(h + 1), dim3(512), 0, s, d, q, (const float*)red, L.share_a, w->w_add, D, g->b_o);
+    hipLaunchKernelGGL(empty_finish_kernel, dim3(1), dim3(512), 0, s, d, h, dk, q, (const float*)red, w->w_o, (const float*)D, g->b_add, g->q_vec,
                        g->b_qkv + 2 * (long)d);
     const long n_upd = (long)q * d + (long)d * d;
     hipLaunchKernelGGL(empty_update_kernel, dim3((unsigned)((n_upd + 255) / 256)), dim3(256), 0, s, d, h, dk, q, (const float*)red, (const float*)D,
