@@ -284,7 +284,9 @@ def eval_path_leg(model, dev):
 def naml_leg(dev, B):
     """SURVEY f-3: one nrms_naml train step (model/nrms_naml.py) at the reference's own shapes -- title 20 and abstract
     40 words through the shared word-level encoder (6 heads, W_O), 100-wide category embeddings, LayerNorm, the 800-wide
-    user encoder (8 heads, q = 400), dropout 0.2 -- in the bf16x3 mode (no fused fp16 kernels for this topology yet)."""
+    user encoder (8 heads, q = 400), dropout 0.2 -- in the bf16x3 mode (no fused fp16 kernels for this topology yet).  The
+    all-padding title / abstract sequences (history padding slots, 41 % of the batch) take the closed form of csrc/empty_seq.hip;
+    the kernel chain runs on the others, compacted."""
     from pytorch_news_recommender_amd.model.nrms_naml_hip import Model as NamlModel
     shape = synth.NamlShape(batch_size=B)
     cfg = Config("nrms_naml")
