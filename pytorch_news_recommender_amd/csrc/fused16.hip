@@ -63,7 +63,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? F16_FWD_WGS : 1) void fused_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
     const int S = a.S;
-    constexpr int KP = F16_KP, DP = F16_DP, QP = F16_QP;
+    constexpr int KP = F16_KP, DP = F16_DP;
     const int n_head_tiles = 3 * a.h;
 
     // ---- which sequence this wave owns.  With an order list, workgroups [0, ceil(n_ne / 4)) take the titles that

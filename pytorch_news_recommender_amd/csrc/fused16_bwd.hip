@@ -285,7 +285,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hh = lane >> 5;
     const int S = a.S;
-    constexpr int KP = F16_KP, DP = F16_DP;
+    constexpr int KP = F16_KP;
     constexpr float NEG = -3.0e38f;
     for (int i = tid; i < B16_RED; i += F16_THREADS) red[i] = 0.f;
     h8 idf[2];

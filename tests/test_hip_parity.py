@@ -66,7 +66,7 @@ def fwd_bwd(model, batch):
     loss = torch.nn.CrossEntropyLoss()(scores, torch.zeros(len(scores), dtype=torch.long, device=scores.device))
     loss.backward()
     grads = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters()}
-    return scores.detach().cpu().numpy(), float(loss), grads
+    return scores.detach().cpu().numpy(), float(loss.detach()), grads
 
 
 ILL_CONDITIONED = ("W_K.bias", "additive_attention.linear.bias", "user_encoder.additive_attention.attention_query_vector")
