@@ -311,8 +311,9 @@ typedef struct nrms_news_features {
     const int64_t* subcateg; /* [n] */
 } nrms_news_features;
 int nrms_news_features_fwd(const nrms_news_features* f, float* out, void* stream);
-/* dout [n, 2 d_text + 2 d_cat] -> d_title_vec, d_abst_vec [n, d_text] (overwritten); the table gradients are ACCUMULATED
- * into d_cat_table / d_sub_table, row 0 (padding_idx = 0, nrms_naml.py:107-108) untouched; atomic-free. */
+/* dout [n, 2 d_text + 2 d_cat] -> d_title_vec, d_abst_vec [n, d_text] (overwritten; d_title_vec also holds the table sums' per-chunk
+ * partial results during the call); the table gradients are ACCUMULATED into d_cat_table / d_sub_table, row 0 (padding_idx = 0,
+ * nrms_naml.py:107-108) untouched; atomic-free (slot chunks in ascending order). */
 int nrms_news_features_bwd(const nrms_news_features* f, const float* dout, float* d_title_vec, float* d_abst_vec,
                            float* d_cat_table, float* d_sub_table, void* stream);
 
@@ -393,11 +394,12 @@ int nrms_hier_tree_build(int32_t B, int32_t H, const uint8_t* valid, const int64
                          int32_t* l1_ptr, int32_t* l1_idx, int32_t* l1_sub, int32_t* l1_top, int32_t* l1_cnt,
                          int32_t* l2_ptr, int32_t* l2_idx, int32_t* l2_top, int32_t* l2_cnt, int32_t* l3_ptr,
                          int32_t* l3_idx, int32_t* n_valid, void* scratch, size_t scratch_bytes, void* stream);
-/* interest of an occupied slot = its aggregate + the embedding of its (sub-)topic: u[slot] += table[id[slot]] where cnt[slot] > 0;
+/* interest of an occupied slot = its aggregate + the embedding of its (sub-)topic: u[slot] += table[id[slot]] where cnt[slot] > 0
+ * (table [n_ids, d]; an id outside it adds nothing and takes no gradient);
  * backward: dtable[r] += sum of du over the occupied slots with id == r, in a fixed order (per-chunk partial sums in `workspace`,
  * then the chunks in ascending order; no atomics). */
-int nrms_hier_add_embedding_fwd(int64_t n_slots, int32_t d, const int32_t* id, const int32_t* cnt, const float* table, float* u,
-                                void* stream);
+int nrms_hier_add_embedding_fwd(int64_t n_slots, int32_t d, int32_t n_ids, const int32_t* id, const int32_t* cnt, const float* table,
+                                float* u, void* stream);
 size_t nrms_hier_add_embedding_bwd_workspace_bytes(int64_t n_slots, int32_t d, int32_t n_ids);
 int nrms_hier_add_embedding_bwd(int64_t n_slots, int32_t d, int32_t n_ids, const int32_t* id, const int32_t* cnt,
                                 const float* du, float* dtable, void* workspace, size_t workspace_bytes, void* stream);

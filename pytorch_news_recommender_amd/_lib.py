@@ -99,7 +99,7 @@ SIGNATURES = {
     "nrms_segment_pool_bwd": (C.c_int, [C.POINTER(SegPoolDesc)] + [C.c_void_p] * 12 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "nrms_hier_tree_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "nrms_hier_tree_build": (C.c_int, [C.c_int32, C.c_int32] + [C.c_void_p] * 16 + [C.c_size_t, C.c_void_p]),
-    "nrms_hier_add_embedding_fwd": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrms_hier_add_embedding_fwd": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_sequence_partition_count_ints": (C.c_size_t, [C.c_int32]),
     "nrms_sequence_partition": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrms_encoder_empty_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),

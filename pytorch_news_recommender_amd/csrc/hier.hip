@@ -172,14 +172,15 @@ __global__ __launch_bounds__(64 * HIER_WPB) void hier_emit_kernel(HierEmitArgs a
 }
 
 // u[slot][:] += table[id[slot]][:] for the occupied slots
-__global__ __launch_bounds__(256) void hier_addemb_kernel(long n_slots, int d4, const int* id, const int* cnt, const float* table, float* u) {
+__global__ __launch_bounds__(256) void hier_addemb_kernel(long n_slots, int d4, int n_ids, const int* id, const int* cnt, const float* table, float* u) {
     const long total = n_slots * d4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long s = i / d4;
         const int c = (int)(i - s * d4);
-        if (cnt[s] <= 0) continue;
+        const int r = id[s];
+        if (cnt[s] <= 0 || r < 0 || r >= n_ids) continue;          // (an id outside the table: no embedding, as in the backward)
         f32x4 v = *reinterpret_cast<const f32x4*>(u + i * 4);
-        v += *reinterpret_cast<const f32x4*>(table + ((long)id[s] * d4 + c) * 4);
+        v += *reinterpret_cast<const f32x4*>(table + ((long)r * d4 + c) * 4);
         *reinterpret_cast<f32x4*>(u + i * 4) = v;
     }
 }
@@ -339,16 +340,16 @@ extern "C" int nrms_hier_tree_build(int32_t B, int32_t H, const uint8_t* valid, 
     return check_launch("hier_tree_build");
 }
 
-extern "C" int nrms_hier_add_embedding_fwd(int64_t n_slots, int32_t d, const int32_t* id, const int32_t* cnt, const float* table,
+extern "C" int nrms_hier_add_embedding_fwd(int64_t n_slots, int32_t d, int32_t n_ids, const int32_t* id, const int32_t* cnt, const float* table,
                                            float* u, void* stream) {
-    NRMS_REQUIRE(n_slots >= 0 && d > 0 && (d & 3) == 0, "hier_add_embedding_fwd: n_slots=%ld d=%d", (long)n_slots, d);
+    NRMS_REQUIRE(n_slots >= 0 && d > 0 && (d & 3) == 0 && n_ids > 0, "hier_add_embedding_fwd: n_slots=%ld d=%d n_ids=%d", (long)n_slots, d, n_ids);
     if (n_slots == 0) return NRMS_OK;
     NRMS_REQUIRE(id && cnt && table && u, "hier_add_embedding_fwd: null argument");
     hipStream_t s = (hipStream_t)stream;
     long blocks = (n_slots * (d / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     TimingScope ts("hier_addemb", s);
-    hipLaunchKernelGGL(hier_addemb_kernel, dim3((int)blocks), dim3(256), 0, s, (long)n_slots, d / 4, id, cnt, table, u);
+    hipLaunchKernelGGL(hier_addemb_kernel, dim3((int)blocks), dim3(256), 0, s, (long)n_slots, d / 4, n_ids, id, cnt, table, u);
     return check_launch("hier_add_embedding_fwd");
 }
 

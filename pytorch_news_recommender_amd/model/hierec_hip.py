@@ -106,10 +106,10 @@ class HieRecEngine(NRMSEngine):
         prec = self._pool_precision()
         pools = [SegmentPool(d, q, prec, rows_unique=True) for _ in range(3)]
         u1 = pools[0].forward(hist, *W[LEVELS[0]], t["l1_ptr"], t["l1_idx"])
-        _lib.check(self.lib.nrms_hier_add_embedding_fwd(C.c_int64(n), d, _lib.ptr(t["l1_sub"]), _lib.ptr(t["l1_cnt"]),
+        _lib.check(self.lib.nrms_hier_add_embedding_fwd(C.c_int64(n), d, self.n_sub, _lib.ptr(t["l1_sub"]), _lib.ptr(t["l1_cnt"]),
                                                         _lib.ptr(lay.view(flat, "subtopic_embedding.weight")), _lib.ptr(u1), _stream()), "add_embedding")
         u2 = pools[1].forward(u1, *W[LEVELS[1]], t["l2_ptr"], t["l2_idx"])
-        _lib.check(self.lib.nrms_hier_add_embedding_fwd(C.c_int64(n), d, _lib.ptr(t["l2_top"]), _lib.ptr(t["l2_cnt"]),
+        _lib.check(self.lib.nrms_hier_add_embedding_fwd(C.c_int64(n), d, self.n_top, _lib.ptr(t["l2_top"]), _lib.ptr(t["l2_cnt"]),
                                                         _lib.ptr(lay.view(flat, "topic_embedding.weight")), _lib.ptr(u2), _stream()), "add_embedding")
         ug = pools[2].forward(u2, *W[LEVELS[2]], t["l3_ptr"], t["l3_idx"])
         # ---- hierarchical matching

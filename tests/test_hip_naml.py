@@ -375,3 +375,33 @@ def test_all_padding_closed_form_equals_the_chain(geom, p):
                                           C.byref(eng._ptrs(_lib.EncoderGrads, g_e, "news_encoder")), _lib.ptr(ews), C.c_size_t(ews.numel() * 4), stream), "empty_bwd")
     n_wa = "news_encoder.additive_attention.linear.weight"
     assert np.allclose(lay.view(g_e, n_wa).cpu().numpy(), 2 * lay.view(g_chain, n_wa).cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_sequence_partition_lists_and_seq_index_rules():
+    """nrms_sequence_partition: the two lists (sequences with a real token / all-padding ones, ascending) and their sizes;
+    desc.seq_index is refused where the counters it renumbers do not exist or would not be the only ones to move."""
+    import ctypes as C
+    from pytorch_news_recommender_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, S = 1000, 20
+    ids = rng.integers(1, 50, size=(n, S), dtype=np.int64)
+    empty = rng.random(n) < 0.4
+    ids[empty] = 0
+    ids[~empty, 5:] = 0                                   # padding tails do not make a sequence all-padding
+    d_ids = torch.from_numpy(ids).cuda()
+    order = torch.full((2 * n,), -1, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(lib.nrms_sequence_partition_count_ints(n) + 2, dtype=torch.int32, device="cuda")
+    _lib.check(lib.nrms_sequence_partition(_lib.ptr(d_ids), n, S, _lib.ptr(order), _lib.ptr(counts), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "partition")
+    o, c = order.cpu().numpy(), counts.cpu().numpy()
+    assert c[0] == int((~empty).sum()) and c[1] == int(empty.sum())
+    assert np.array_equal(o[:c[0]], np.flatnonzero(~empty)) and np.array_equal(o[n:n + c[1]], np.flatnonzero(empty))
+    base = dict(n_seq=4, seq_len=20, d_model=300, n_heads=6, q_dim=200, vocab=100, p_drop_embed=0.0, p_drop_ctx=0.0,
+                precision=_lib.NRMS_PRECISION_BF16X3, use_output_proj=1, mask_mode=0, flags=_lib.NRMS_FLAG_PAD_ROW_ZERO, seed=1, loss_scale=0.0,
+                p_drop_attn=0.2, seq_index=order.data_ptr())
+    assert lib.nrms_encoder_bwd_workspace_bytes(C.byref(_lib.EncoderDesc(**base))) > 0
+    for kw in (dict(p_drop_ctx=0.1), dict(p_drop_embed=0.1), dict(n_heads=3, flags=0), dict(precision=_lib.NRMS_PRECISION_FP16, use_output_proj=0, n_heads=10, p_drop_attn=0.0)):
+        args = dict(base)
+        args.update(kw)
+        assert lib.nrms_encoder_bwd_workspace_bytes(C.byref(_lib.EncoderDesc(**args))) == 0, kw
+        assert b"seq_index" in lib.nrms_last_error(), (kw, lib.nrms_last_error())
