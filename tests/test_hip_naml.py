@@ -405,3 +405,41 @@ def test_sequence_partition_lists_and_seq_index_rules():
         args.update(kw)
         assert lib.nrms_encoder_bwd_workspace_bytes(C.byref(_lib.EncoderDesc(**args))) == 0, kw
         assert b"seq_index" in lib.nrms_last_error(), (kw, lib.nrms_last_error())
+
+
+_FULL = {}
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_naml_against_the_oracle_at_the_benchmarked_size(mode):
+    """512 users at the reference's own widths (title 20 / abstract 40 words, d = 300, 800-wide user encoder) -- the batch
+    bench.py's nrms_naml leg times -- against the ORACLE's batched CPU forward: the training-mode path (dropout 0: the sequence
+    partition, the kernel chain on the compacted 59 %, the closed form on 23 000 all-padding sequences) and the evaluation path
+    (distinct news only).  Scores are O(10): the absolute 1e-4 of the bf16x3 row is 1e-5 relative."""
+    import time
+    from oracle import naml_oracle as nml
+    shape = synth.NamlShape(batch_size=512)
+    params = synth.make_params_naml(shape, seed=0)
+    batch = synth.make_batch_naml(shape, seed=1)
+    if "ref" not in _FULL:                              # one CPU forward (tens of seconds) for both modes
+        t0 = time.time()
+        with torch.no_grad():
+            _FULL["ref"] = nml.forward(nml.to_torch(params), tbatch(batch), shape.title_heads_num, shape.user_heads_num).numpy()
+        print("naml oracle forward at 512 users: %.1f s" % (time.time() - t0))
+    ref = _FULL["ref"]
+    live = batch["candidate_mask"] != 0
+    model = make_model(shape, params, dropout=0.0, precision=mode)
+    model.train()                                       # dropout 0: the training forward's kernels, deterministic
+    with torch.no_grad():
+        s_train = model(tbatch(batch)).cpu().numpy()
+    eng = model.engine
+    (order_t, n_t), (order_a, n_a) = eng.last_split
+    N = 512 * 55
+    assert 0.5 * N < n_t < 0.7 * N and 0.5 * N < n_a < 0.7 * N    # the all-padding history slots took the closed form
+    model.eval()
+    with torch.no_grad():
+        s_eval = model(tbatch(batch)).cpu().numpy()
+    for name, s in (("train-mode", s_train), ("eval", s_eval)):
+        err = float(np.abs(s - ref)[live].max())
+        print("naml %-6s %-10s max |score - oracle| = %.2e over %d scores (max |score| %.1f)" % (mode, name, err, int(live.sum()), float(np.abs(ref[live]).max())))
+        assert err <= TOL[mode]["score"] * 1.5, (name, err)
