@@ -557,3 +557,35 @@ def test_graph_sampler_draws_co_clicked_news_of_the_batch():
         if not users:
             assert (nb[r] < 0).all()
     assert n_some > B * H
+
+
+@pytest.mark.parametrize("name", ["hierec", "graph"])
+def test_f4_models_build_on_cpu_and_refuse_to_run_there(name):
+    """The row f-4 models (no reference counterpart, parity unpinned) keep the plugin contract -- Model(config), the NRMS news
+    encoder's parameter names first, state_dict round trip -- and, like every model of this build, have NO CPU path: a forward
+    on CPU parameters raises instead of computing something else."""
+    import importlib
+    from pytorch_news_recommender_amd import _lib, synth
+    from pytorch_news_recommender_amd.config import Config
+    shape = synth.Shape(n_words=40, word_embed_size=16, num_attention_heads=2, query_vector_dim=8, batch_size=3, history_len=4,
+                        n_candidates=2, n_words_title=5)
+    cfg = Config(name)
+    cfg.__nrms__()
+    cfg.word_embed_size, cfg.num_attention_heads, cfg.query_vector_dim = 16, 2, 8
+    cfg.subcategory_nums, cfg.category_nums = 9, 5
+    if name == "hierec":
+        params = synth.make_params_hierec(shape, 9, 5, seed=1)
+        batch = synth.make_batch_hierec(shape, 9, 5, seed=2)
+    else:
+        params = synth.make_params_graph(shape, seed=1)
+        batch = synth.make_batch_graph(shape, 3, seed=2)
+    mod = importlib.import_module("pytorch_news_recommender_amd.model." + {"hierec": "hierec_hip", "graph": "graph_hip"}[name])
+    m = mod.Model(cfg, pretrained_word_embedding=params["news_encoder.word_embedding.0.weight"])
+    res = m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    assert not res.missing_keys and not res.unexpected_keys
+    names = list(m.state_dict())
+    assert names[0] == "news_encoder.word_embedding.0.weight" and set(names) == set(params)
+    for k, v in params.items():                                  # parameters are views of one flat buffer, values intact
+        assert np.array_equal(m.state_dict()[k].numpy(), v), k
+    with pytest.raises(_lib.NrmsError, match="no CPU"):
+        m({k: torch.from_numpy(np.asarray(v)) for k, v in batch.items()})
