@@ -209,34 +209,6 @@ __device__ __forceinline__ void tile_mma(f32x16& acc, const Ring& ring, int n, c
     }
 }
 
-// The same for the products whose operand is an x row (features 0 .. d - 1, the ones column at d, zeros up to KP): k-steps at or
-// beyond nk = ceil((d + 1) / 16) multiply zeros and are not issued (d = 300: 19 of the 20).  nk is uniform (a kernel argument).
-template <bool W_IS_A, class Ring, int NS, class Between = NoPrefetch>
-__device__ __forceinline__ void tile_mma_x(f32x16& acc, const Ring& ring, int n, const h8 (&op)[NS], int nk, Between between = Between()) {
-    static_assert(NS % 4 == 0, "k-steps in groups of 4");
-    h8 wa[4], wb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wa[i] = ring.frag(n, i);
-#pragma unroll
-    for (int g = 0; g < NS / 4; ++g) {
-        if (g + 1 < NS / 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (g & 1) wa[i] = ring.frag(n, 4 * (g + 1) + i);
-                else wb[i] = ring.frag(n, 4 * (g + 1) + i);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const h8& w = (g & 1) ? wb[i] : wa[i];
-            if (g + 1 < NS / 4 || 4 * g + i < nk)              // (only the last group can hold an all-zero step: KP - 64 < d + 1)
-                acc = W_IS_A ? mfma32h(w, op[4 * g + i], acc) : mfma32h(op[4 * g + i], w, acc);
-        }
-        between(g);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // r[4g + e] = v[8g + 4hh + e]: a per-ROW vector (bias) in the accumulator's register order.  Loaded at the top of a
 // tile step and ADDED after the MFMAs: as the accumulator's initial value it would put a global-load latency in
 // front of every tile.

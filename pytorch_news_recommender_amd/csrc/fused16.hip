@@ -372,7 +372,6 @@ __global__ __launch_bounds__(F16_THREADS, F16_FWD_WGS) void fused_fwd16p_kernel(
     constexpr int KP = F16_KP, DP = F16_DP;
     const int n_head_tiles = 3 * a.h;
     constexpr float NEG = -3.0e38f;
-    const int nk_x = (a.d + 1 + 15) >> 4;                           // k-steps of an x row that hold data (tile_mma_x)
 
     // ---- which titles this wave owns
     const int n_long = a.order_cnt[0], n_e = a.order_cnt[1], n_short = a.order_cnt[2];
@@ -478,15 +477,15 @@ __global__ __launch_bounds__(F16_THREADS, F16_FWD_WGS) void fused_fwd16p_kernel(
             f32x16 qt = zero16(), kt = zero16(), vv = zero16();
             auto pre = [&](int g) { if (n + AH < n_steps) ring.load_piece_at(n + AH, tile_at(n + AH), g); };
             if (!any_live && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
-            if (any_live) tile_mma_x<true>(qt, ring, n, xf, nk_x, pre);
+            if (any_live) tile_mma<true>(qt, ring, n, xf, pre);
             ring.step_barrier(n);
             ++n;
             if (!any_live && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
-            if (any_live) tile_mma_x<true>(kt, ring, n, xf, nk_x, pre);
+            if (any_live) tile_mma<true>(kt, ring, n, xf, pre);
             ring.step_barrier(n);
             ++n;
             if (!any_live && n + AH < n_steps) ring.load_at(n + AH, tile_at(n + AH));
-            if (any_live) tile_mma_x<false>(vv, ring, n, xf, nk_x, pre);
+            if (any_live) tile_mma<false>(vv, ring, n, xf, pre);
             if (any_live) {
                 // S^T[j][i] (rows j = keys in registers, columns i = queries), masked / weighted by the additive bias
                 f32x16 st = mfma32h(acc_frag(kt, 0), acc_frag(qt, 0), zero16());

@@ -287,7 +287,6 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
     const int S = a.S;
     constexpr int KP = F16_KP;
     constexpr float NEG = -3.0e38f;
-    const int nk_x = (a.d + 1 + 15) >> 4;                           // k-steps of an x row that hold data (tile_mma_x)
     for (int i = tid; i < B16_RED; i += F16_THREADS) red[i] = 0.f;
     h8 idf[2];
 #pragma unroll
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 f32x16 t = zero16();
-                if (live) tile_mma_x<true>(t, ring, n, xf[b], nk_x);
+                if (live) tile_mma<true>(t, ring, n, xf[b]);
                 qf[b][0] = acc_frag(t, 0); qf[b][1] = acc_frag(t, 1);
             }
             ring.store(n + 2);
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 f32x16 t = zero16();
-                if (live) tile_mma_x<true>(t, ring, n, xf[b], nk_x);
+                if (live) tile_mma<true>(t, ring, n, xf[b]);
                 kf[b][0] = acc_frag(t, 0); kf[b][1] = acc_frag(t, 1);
             }
             ring.store(n + 2);
@@ -416,7 +415,7 @@ __global__ __launch_bounds__(F16_THREADS, SB == 1 ? 8 / F16_WAVES : 1) void fuse
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
                 f32x16 t = zero16();
-                if (live) tile_mma_x<true>(t, ring, n, xf[b], nk_x);
+                if (live) tile_mma<true>(t, ring, n, xf[b]);
                 vf[b][0] = acc_frag(t, 0); vf[b][1] = acc_frag(t, 1);
             }
             ring.store(n + 2);
